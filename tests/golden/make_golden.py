@@ -1,0 +1,429 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/*.npz from the REFERENCE.
+
+Runs only in the build container (needs /root/reference, read-only, imported
+unmodified with PYTHONDONTWRITEBYTECODE=1).  The reference never travels: what
+is committed are the .npz files (inputs are re-derivable from seeds through
+detgen.py, expected outputs are stored) plus this script.
+
+Import shims: torchvision / cv2 / kornia are absent from the
+image and are not on the hot path -> empty stub modules; `hidden_models/*`
+imports `options.HiDDenConfiguration` and `model.conv_bn_relu`, which do not
+exist in the reference tree -> a dataclass with the fields the modules read,
+and an alias `model` -> `hidden_models`.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import dataclasses
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import detgen  # noqa: E402
+
+REF = "/root/reference"
+warnings.filterwarnings("ignore")
+torch.set_num_threads(8)
+
+
+# --------------------------------------------------------------------------- shims
+def install_shims():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tv.transforms = tvt
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tvt
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    k = types.ModuleType("kornia")
+    kf = types.ModuleType("kornia.filters")
+
+    class _Absent(nn.Module):
+        def __init__(self, *a, **kw):
+            super().__init__()
+
+        def forward(self, x):
+            raise RuntimeError("kornia is absent from this image")
+
+    kf.MedianBlur = _Absent
+    kf.GaussianBlur2d = _Absent
+    k.filters = kf
+    sys.modules["kornia"] = k
+    sys.modules["kornia.filters"] = kf
+
+    # options.HiDDenConfiguration: fields read at encoder.py:13-25, decoder.py:15-22,
+    # discriminator.py:12-18, hidden.py:27,99-100
+    import options as ref_options
+
+    @dataclasses.dataclass
+    class HiDDenConfiguration:
+        H: int
+        W: int
+        message_length: int = 30
+        encoder_blocks: int = 4
+        encoder_channels: int = 64
+        decoder_blocks: int = 7
+        decoder_channels: int = 64
+        use_discriminator: bool = True
+        use_vgg: bool = False
+        discriminator_blocks: int = 3
+        discriminator_channels: int = 64
+        decoder_loss: float = 1.0
+        encoder_loss: float = 0.7
+        adversarial_loss: float = 1e-3
+
+    ref_options.HiDDenConfiguration = HiDDenConfiguration
+    import hidden_models
+    import hidden_models.conv_bn_relu
+
+    sys.modules["model"] = hidden_models
+    sys.modules["model.conv_bn_relu"] = hidden_models.conv_bn_relu
+    return HiDDenConfiguration
+
+
+def npy(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+# --------------------------------------------------------------------------- block JPEG (noise_layers/jpeg.py)
+def gen_jpeg(out):
+    from noise_layers.jpeg import Jpeg, JpegSS, JpegMask
+
+    kinds = {"Jpeg": Jpeg, "JpegSS": JpegSS, "JpegMask": JpegMask}
+    # (H, W) all pad to a square multiple of 8 -- the only shapes for which the
+    # reference's split/cat block reshuffle (jpeg.py:123-127) is self-consistent.
+    sizes = [(16, 16), (64, 64), (30, 27)]
+    seed = 100
+    for kname, K in kinds.items():
+        for Q in (10, 50, 75, 90):
+            for (H, W) in sizes:
+                for sub in (0, 2):
+                    if (H, W) == (64, 64) and Q in (10, 75) and sub == 2:
+                        continue  # keep the fixture small
+                    seed += 1
+                    x = detgen.uniform((2, 3, H, W), seed).requires_grad_(True)
+                    g = detgen.normal((2, 3, H, W), seed + 5000)
+                    layer = K(Q, subsample=sub)
+                    y = layer(x)
+                    (y * g).sum().backward()
+                    key = f"{kname}_Q{Q}_{H}x{W}_s{sub}"
+                    out[key + "/seed"] = np.int64(seed)
+                    out[key + "/y"] = npy(y)
+                    out[key + "/gx"] = npy(x.grad)
+                    out[key + "/name"] = np.array(layer.name)
+    # one block's DCT coefficients (a7: yuv_dct) for a known-answer test
+    x = detgen.uniform((1, 3, 8, 8), 4242)
+    layer = Jpeg(50)
+    coef, pw, ph = layer.yuv_dct(x, 0)
+    out["dct_block/x_seed"] = np.int64(4242)
+    out["dct_block/coef"] = npy(coef)
+    q = layer.std_quantization(coef, layer.scale_factor)
+    out["dct_block/q50"] = npy(q)
+
+
+# --------------------------------------------------------------------------- DiffJPEG stages (utils/JPEG.py)
+def gen_diffjpeg(out):
+    import utils.JPEG as RJ
+
+    seed = 300
+    for quality in (50, 75, 90):
+        for (H, W) in ((32, 32), (64, 64), (32, 48)):
+            for rname, rfn in (("round", torch.round), ("round0", RJ.round_only_at_0)):
+                seed += 1
+                factor = RJ.quality_to_factor(quality)
+                comp = RJ.compress_jpeg(rounding=rfn, factor=factor)
+                dec = RJ.decompress_jpeg(H, W, rounding=rfn, factor=factor)
+                x = detgen.uniform((2, 3, H, W), seed).requires_grad_(True)
+                g = detgen.normal((2, 3, H, W), seed + 5000)
+                y, cb, cr = comp(x)
+                rec = dec(y, cb, cr)
+                (rec * g).sum().backward()
+                key = f"DiffJPEG_q{quality}_{H}x{W}_{rname}"
+                out[key + "/seed"] = np.int64(seed)
+                out[key + "/y"] = npy(y)
+                out[key + "/cb"] = npy(cb)
+                out[key + "/cr"] = npy(cr)
+                out[key + "/rec"] = npy(rec)
+                out[key + "/gx"] = npy(x.grad)
+    out["quality_to_factor"] = np.array([[q, RJ.quality_to_factor(q)] for q in (10, 25, 50, 75, 90, 95)], dtype=np.float64)
+    xs = torch.linspace(-2.0, 2.0, 81)
+    out["round_only_at_0/x"] = npy(xs)
+    out["round_only_at_0/y"] = npy(RJ.round_only_at_0(xs))
+    out["diff_round/y"] = npy(RJ.diff_round(xs))
+
+
+# --------------------------------------------------------------------------- stencil / resample attacks
+def gen_attacks(out):
+    from noise_layers.gaussian_blur import GaussianBlur
+    from noise_layers.resize import Resize
+    from noise_layers.crop import Crop
+    from noise_layers.combined import Combined
+    from noise_layers.identity import Identity
+    from noise_layers.jpeg import Jpeg, JpegSS, JpegMask
+    from models.modules.Quantization import Quantization
+
+    # a11: GaussianBlur.forward hard-codes .cuda() (gaussian_blur.py:55); use its
+    # own kernel builder and apply the returned depthwise conv on CPU.
+    gb = GaussianBlur()
+    conv = gb.get_gaussian_kernel(channels=3)
+    out["gauss/kernel"] = npy(conv.weight[0, 0])
+    for i, (H, W) in enumerate(((16, 16), (33, 47), (64, 64))):
+        x = detgen.uniform((2, 3, H, W), 500 + i).requires_grad_(True)
+        g = detgen.normal((2, 3, H, W), 5500 + i)
+        y = conv(x)
+        (y * g).sum().backward()
+        out[f"gauss_{H}x{W}/seed"] = np.int64(500 + i)
+        out[f"gauss_{H}x{W}/y"] = npy(y)
+        out[f"gauss_{H}x{W}/gx"] = npy(x.grad)
+
+    # a13: Resize with explicit ratio
+    rs = Resize()
+    i = 0
+    for (H, W) in ((32, 32), (48, 40)):
+        for r in (0.5, 0.7, 1.3):
+            i += 1
+            x = detgen.uniform((2, 3, H, W), 600 + i).requires_grad_(True)
+            g = detgen.normal((2, 3, H, W), 5600 + i)
+            y = rs(x, resize_ratio=r)
+            (y * g).sum().backward()
+            key = f"resize_{H}x{W}_r{r}"
+            out[key + "/seed"] = np.int64(600 + i)
+            out[key + "/y"] = npy(y)
+            out[key + "/gx"] = npy(x.grad)
+
+    # a14: Crop with explicit apex
+    cr = Crop()
+    i = 0
+    for (H, W), apex in (((32, 32), (4, 28, 2, 26)), ((64, 64), (8, 56, 8, 56)), ((40, 48), (0, 31, 5, 48))):
+        i += 1
+        x = detgen.uniform((2, 3, H, W), 700 + i).requires_grad_(True)
+        g = detgen.normal((2, 3, H, W), 5700 + i)
+        np.random.seed(0)
+        y, ap = cr(x, apex=apex)
+        (y * g).sum().backward()
+        key = f"crop_{H}x{W}_{'_'.join(map(str, apex))}"
+        out[key + "/seed"] = np.int64(700 + i)
+        out[key + "/apex"] = np.array(ap, dtype=np.int64)
+        out[key + "/y"] = npy(y)
+        out[key + "/gx"] = npy(x.grad)
+    # random-apex bookkeeping (crop.py:13-30,33-40): numpy-seeded draws
+    for s in (1, 2, 3):
+        np.random.seed(s)
+        x = detgen.uniform((1, 3, 32, 32), 750 + s)
+        y, ap = cr(x)
+        out[f"crop_rand_seed{s}/apex"] = np.array(ap, dtype=np.int64)
+        out[f"crop_rand_seed{s}/y"] = npy(y)
+
+    # a16: Quantization
+    qz = Quantization()
+    x = detgen.uniform((2, 3, 16, 16), 800, lo=-0.2, hi=1.2).requires_grad_(True)
+    g = detgen.normal((2, 3, 16, 16), 5800)
+    y = qz(x)
+    (y * g).sum().backward()
+    out["quant/seed"] = np.int64(800)
+    out["quant/y"] = npy(y)
+    out["quant/gx"] = npy(x.grad)
+
+    # a9 / a15: Combined dispatch + names
+    comb = Combined([JpegMask(80), Jpeg(80), JpegSS(70), Identity()])
+    x = detgen.uniform((1, 3, 16, 16), 900)
+    names = []
+    for k in range(4):
+        y = comb(x, id=k)
+        names.append(comb.name)
+        out[f"combined_id{k}/y"] = npy(y)
+    out["combined/names"] = np.array(names)
+    out["combined/seed"] = np.int64(900)
+
+
+# --------------------------------------------------------------------------- HiDDeN nets
+def gen_hidden(out, Cfg):
+    from hidden_models.conv_bn_relu import ConvBNRelu
+    from hidden_models.encoder import Encoder
+    from hidden_models.decoder import Decoder
+    from hidden_models.discriminator import Discriminator
+
+    # a1
+    for (cin, cout) in ((3, 64), (64, 64), (64, 30)):
+        m = detgen.fill_module(ConvBNRelu(cin, cout)).train()
+        x = detgen.normal((2, cin, 16, 16), 1000 + cin + cout).requires_grad_(True)
+        g = detgen.normal((2, cout, 16, 16), 6000 + cin + cout)
+        y = m(x)
+        (y * g).sum().backward()
+        key = f"cbr_{cin}_{cout}"
+        out[key + "/seed"] = np.int64(1000 + cin + cout)
+        out[key + "/y"] = npy(y)
+        out[key + "/gx"] = npy(x.grad)
+        out[key + "/gw"] = npy(m.layers[0].weight.grad)
+        out[key + "/gb"] = npy(m.layers[0].bias.grad)
+        out[key + "/ggamma"] = npy(m.layers[1].weight.grad)
+        out[key + "/gbeta"] = npy(m.layers[1].bias.grad)
+        out[key + "/running_mean"] = npy(m.layers[1].running_mean)
+        out[key + "/running_var"] = npy(m.layers[1].running_var)
+
+    # a2-a4 at 2x3x32x32
+    cfg = Cfg(H=32, W=32)
+    enc = detgen.fill_module(Encoder(cfg)).train()
+    dec = detgen.fill_module(Decoder(cfg)).train()
+    dis = detgen.fill_module(Discriminator(cfg)).train()
+    img = detgen.uniform((2, 3, 32, 32), 1100).requires_grad_(True)
+    msg = detgen.bits((2, 30), 1101)
+    e = enc(img, msg.clone())
+    ge = detgen.normal((2, 3, 32, 32), 6100)
+    (e * ge).sum().backward()
+    out["enc32/y"] = npy(e)
+    out["enc32/gimg"] = npy(img.grad)
+    for n, p in enc.named_parameters():
+        out[f"enc32/g/{n}"] = npy(detgen.subsample(p.grad, 97))
+    x = detgen.uniform((2, 3, 32, 32), 1102).requires_grad_(True)
+    d = dec(x)
+    gd = detgen.normal((2, 30), 6101)
+    (d * gd).sum().backward()
+    out["dec32/y"] = npy(d)
+    out["dec32/gx"] = npy(x.grad)
+    for n, p in dec.named_parameters():
+        out[f"dec32/g/{n}"] = npy(detgen.subsample(p.grad, 97))
+    x = detgen.uniform((2, 3, 32, 32), 1103).requires_grad_(True)
+    d = dis(x)
+    gd = detgen.normal((2, 1), 6102)
+    (d * gd).sum().backward()
+    out["dis32/y"] = npy(d)
+    out["dis32/gx"] = npy(x.grad)
+    for n, p in dis.named_parameters():
+        out[f"dis32/g/{n}"] = npy(detgen.subsample(p.grad, 97))
+    out["param_counts"] = np.array([sum(p.numel() for p in m.parameters()) for m in (enc, dec, dis)], dtype=np.int64)
+
+    # config C1: encoder -> identity -> decoder, single 128x128 frame
+    cfg = Cfg(H=128, W=128)
+    enc = detgen.fill_module(Encoder(cfg)).train()
+    dec = detgen.fill_module(Decoder(cfg)).train()
+    img = detgen.uniform((1, 3, 128, 128), 1200)
+    msg = detgen.bits((1, 30), 1201)
+    e = enc(img, msg.clone())
+    d = dec(e)
+    out["c1/encoded_sub"] = npy(detgen.subsample(e, 13))
+    out["c1/encoded_mean_abs"] = np.float64(e.abs().mean().item())
+    out["c1/decoded"] = npy(d)
+
+
+# --------------------------------------------------------------------------- full GAN step (hidden.py:54-118 order)
+def gen_step(out, Cfg):
+    from hidden_models.encoder import Encoder
+    from hidden_models.decoder import Decoder
+    from hidden_models.discriminator import Discriminator
+    from noise_layers.jpeg import Jpeg, JpegSS, JpegMask
+    from noise_layers.identity import Identity
+
+    for nname, noise in (("JpegSS50", JpegSS(50)), ("Jpeg50", Jpeg(50)), ("JpegMask50", JpegMask(50)), ("Identity", Identity())):
+        cfg = Cfg(H=32, W=32)
+        enc = detgen.fill_module(Encoder(cfg)).train()
+        dec = detgen.fill_module(Decoder(cfg)).train()
+        dis = detgen.fill_module(Discriminator(cfg)).train()
+        # hidden.py:24-25 -- one Adam over encoder_decoder.parameters() (encoder then decoder), one over D
+        opt_ed = torch.optim.Adam(list(enc.parameters()) + list(dec.parameters()))
+        opt_d = torch.optim.Adam(dis.parameters())
+        bce = nn.BCEWithLogitsLoss()
+        mse = nn.MSELoss()
+        images = detgen.uniform((4, 3, 32, 32), 2000)
+        messages = detgen.bits((4, 30), 2001)
+        B = 4
+        for it in range(2):
+            opt_d.zero_grad()
+            t1 = torch.full((B, 1), 1.0)
+            t0 = torch.full((B, 1), 0.0)
+            d_cover = dis(images)
+            l_dc = bce(d_cover, t1)
+            l_dc.backward()
+            encoded = enc(images, messages.clone())
+            noised = noise(encoded)
+            decoded = dec(noised)
+            d_enc = dis(encoded.detach())
+            l_de = bce(d_enc, t0)
+            l_de.backward()
+            if it == 0:
+                for n, p in dis.named_parameters():
+                    out[f"step_{nname}/gD/{n}"] = npy(detgen.subsample(p.grad, 31))
+            opt_d.step()
+            opt_ed.zero_grad()
+            d_enc2 = dis(encoded)
+            l_adv = bce(d_enc2, t1)
+            l_enc = mse(encoded, images)
+            l_dec = mse(decoded, messages)
+            g_loss = cfg.adversarial_loss * l_adv + cfg.encoder_loss * l_enc + cfg.decoder_loss * l_dec
+            g_loss.backward()
+            if it == 0:
+                for n, p in enc.named_parameters():
+                    out[f"step_{nname}/gE/{n}"] = npy(detgen.subsample(p.grad, 31))
+                for n, p in dec.named_parameters():
+                    out[f"step_{nname}/gDec/{n}"] = npy(detgen.subsample(p.grad, 31))
+                out[f"step_{nname}/encoded"] = npy(encoded)
+                out[f"step_{nname}/noised"] = npy(noised)
+                out[f"step_{nname}/decoded"] = npy(decoded)
+            opt_ed.step()
+            dr = decoded.detach().numpy().round().clip(0, 1)
+            biterr = np.sum(np.abs(dr - messages.numpy())) / (B * 30)
+            out[f"step_{nname}/losses_it{it}"] = np.array(
+                [g_loss.item(), l_enc.item(), l_dec.item(), biterr, l_adv.item(), l_dc.item(), l_de.item()], dtype=np.float64)
+        for n, p in list(enc.state_dict().items()):
+            out[f"step_{nname}/wE/{n}"] = npy(detgen.subsample(p.float(), 31))
+        for n, p in list(dec.state_dict().items()):
+            out[f"step_{nname}/wDec/{n}"] = npy(detgen.subsample(p.float(), 31))
+        for n, p in list(dis.state_dict().items()):
+            out[f"step_{nname}/wD/{n}"] = npy(detgen.subsample(p.float(), 31))
+
+
+# --------------------------------------------------------------------------- UNet
+def gen_unet(out):
+    from network.UNet import UNet
+
+    net = detgen.fill_module(UNet(3, 1, 32)).train()
+    out["param_count"] = np.int64(sum(p.numel() for p in net.parameters()))
+    for (B, H) in ((1, 32), (2, 64)):
+        net.zero_grad()
+        x = detgen.uniform((B, 3, H, H), 3000 + H).requires_grad_(True)
+        g = detgen.normal((B, 1, H, H), 8000 + H)
+        y = net(x)
+        (y * g).sum().backward()
+        key = f"unet_{B}x{H}"
+        out[key + "/seed"] = np.int64(3000 + H)
+        out[key + "/y"] = npy(y)
+        out[key + "/gx"] = npy(x.grad)
+        for n, p in net.named_parameters():
+            out[f"{key}/g/{n}"] = npy(detgen.subsample(p.grad, 997))
+            out[f"{key}/gnorm/{n}"] = np.float64(p.grad.norm().item())
+        # reset running stats so the second case starts from a fresh module too
+        for m in net.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.reset_running_stats()
+
+
+def main():
+    Cfg = install_shims()
+    jobs = {
+        "jpeg": lambda o: gen_jpeg(o),
+        "diffjpeg": lambda o: gen_diffjpeg(o),
+        "attacks": lambda o: gen_attacks(o),
+        "hidden": lambda o: gen_hidden(o, Cfg),
+        "step": lambda o: gen_step(o, Cfg),
+        "unet": lambda o: gen_unet(o),
+    }
+    which = sys.argv[1:] or list(jobs)
+    for name in which:
+        out = {}
+        jobs[name](out)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {len(out)} arrays -> {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,273 @@
+"""CPU: pin the oracle (oracle/*) against the golden vectors generated from the
+reference's own modules (tests/golden/make_golden.py).  Tolerances are fp32
+round-off of re-associated arithmetic (einsum vs split/cat matmul)."""
+import numpy as np
+import pytest
+import torch
+
+import detgen
+from oracle import attacks_ref, diffjpeg_ref, hidden_ref, jpeg_ref, unet_ref
+
+
+def close(a, b, rtol=1e-5, atol=1e-5):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def jpeg_cases(g):
+    keys = sorted({k.split("/")[0] for k in g.files if k.startswith("Jpeg")})
+    return keys
+
+
+def test_jpeg_layers(golden):
+    g = golden("jpeg")
+    n = 0
+    nflip = 0
+    for key in jpeg_cases(g):
+        kind, Q, size, sub = key.split("_")
+        mode = {"Jpeg": "round", "JpegSS": "ss", "JpegMask": "mask"}[kind]
+        Q = int(Q[1:])
+        H, W = map(int, size.split("x"))
+        sub = int(sub[1:])
+        seed = int(g[key + "/seed"])
+        x = detgen.uniform((2, 3, H, W), seed).requires_grad_(True)
+        gy = detgen.normal((2, 3, H, W), seed + 5000)
+        y = jpeg_ref.jpeg_layer(x, Q, mode, sub)
+        (y * gy).sum().backward()
+        assert str(g[key + "/name"]) == jpeg_ref.layer_name(mode, Q)
+        ref = g[key + "/y"]
+        if mode == "round":
+            # a coefficient that lands within fp32 round-off of .5 may flip; such a flip
+            # changes <= one 8x8 block by table/255.  Count them instead of failing.
+            bad = np.abs(y.detach().numpy() - ref) > 2e-4
+            nflip += int(bad.any())
+            assert bad.mean() < 0.02, key
+        else:
+            close(y, ref, rtol=1e-4, atol=2e-5)
+        close(x.grad, g[key + "/gx"], rtol=1e-3, atol=2e-4)
+        n += 1
+    assert n >= 60
+    assert nflip <= 2
+
+
+def test_jpeg_dct_block_known_answer(golden):
+    g = golden("jpeg")
+    x = detgen.uniform((1, 3, 8, 8), int(g["dct_block/x_seed"]))
+    coef = jpeg_ref.yuv_dct(x)
+    close(coef, g["dct_block/coef"], rtol=1e-5, atol=1e-3)
+    lum, chroma = jpeg_ref.quant_tables(jpeg_ref.scale_factor(50))
+    tbl = torch.stack([lum, chroma, chroma])[None]
+    q = torch.round(coef / tbl)
+    assert (q.numpy() != g["dct_block/q50"]).mean() < 0.02
+    # DCT matrix orthonormal (jpeg.py:117-121)
+    C = jpeg_ref.dct_matrix().double()
+    np.testing.assert_allclose((C @ C.t()).numpy(), np.eye(8), atol=1e-6)
+
+
+def test_jpeg_known_facts():
+    assert jpeg_ref.scale_factor(50) == 1.0
+    assert abs(jpeg_ref.scale_factor(90) - 0.2) < 1e-12
+    assert jpeg_ref.scale_factor(10) == 5.0
+    m = jpeg_ref.mask_tables()
+    assert m[0].sum() == 25 and m[1].sum() == 9 and m[2].sum() == 9
+    lum, chroma = jpeg_ref.quant_tables(jpeg_ref.scale_factor(100))
+    assert lum.min() == 1 and chroma.min() == 1  # clamp(min=1)
+
+
+def test_diffjpeg(golden):
+    g = golden("diffjpeg")
+    keys = sorted({k.split("/")[0] for k in g.files if k.startswith("DiffJPEG")})
+    assert len(keys) == 18
+    for key in keys:
+        _, q, size, rname = key.split("_")
+        q = int(q[1:])
+        H, W = map(int, size.split("x"))
+        seed = int(g[key + "/seed"])
+        rfn = torch.round if rname == "round" else diffjpeg_ref.round_only_at_0
+        x = detgen.uniform((2, 3, H, W), seed).requires_grad_(True)
+        gy = detgen.normal((2, 3, H, W), seed + 5000)
+        f = diffjpeg_ref.quality_to_factor(q)
+        y, cb, cr = diffjpeg_ref.compress(x, f, rfn)
+        rec = diffjpeg_ref.decompress(y, cb, cr, H, W, f)
+        (rec * gy).sum().backward()
+        if rname == "round":
+            assert (np.abs(y.detach().numpy() - g[key + "/y"]) > 1e-3).mean() < 1e-3
+            assert (np.abs(rec.detach().numpy() - g[key + "/rec"]) > 2e-4).mean() < 0.02
+        else:
+            close(y, g[key + "/y"], rtol=1e-4, atol=1e-4)
+            close(cb, g[key + "/cb"], rtol=1e-4, atol=1e-4)
+            close(cr, g[key + "/cr"], rtol=1e-4, atol=1e-4)
+            close(rec, g[key + "/rec"], rtol=1e-4, atol=2e-5)
+        close(x.grad, g[key + "/gx"], rtol=1e-3, atol=2e-4)
+    for q, f in g["quality_to_factor"]:
+        assert diffjpeg_ref.quality_to_factor(q) == f
+    xs = torch.from_numpy(g["round_only_at_0/x"])
+    close(diffjpeg_ref.round_only_at_0(xs), g["round_only_at_0/y"], atol=1e-7)
+    close(diffjpeg_ref.diff_round(xs), g["diff_round/y"], atol=1e-7)
+
+
+def test_gaussian(golden):
+    g = golden("attacks")
+    close(attacks_ref.gaussian_kernel(), g["gauss/kernel"], atol=1e-7)
+    k = attacks_ref.gaussian_kernel().numpy()
+    np.testing.assert_allclose(k[0], [0.1019, 0.1154, 0.1019], atol=1e-4)
+    np.testing.assert_allclose(k[1, 1], 0.1308, atol=1e-4)
+    for (H, W) in ((16, 16), (33, 47), (64, 64)):
+        seed = int(g[f"gauss_{H}x{W}/seed"])
+        x = detgen.uniform((2, 3, H, W), seed).requires_grad_(True)
+        gy = detgen.normal((2, 3, H, W), seed + 5000)
+        y = attacks_ref.gaussian_blur(x)
+        (y * gy).sum().backward()
+        close(y, g[f"gauss_{H}x{W}/y"], atol=1e-6)
+        close(x.grad, g[f"gauss_{H}x{W}/gx"], atol=1e-5)
+
+
+def test_resize_crop_quant_combined(golden):
+    g = golden("attacks")
+    for key in sorted({k.split("/")[0] for k in g.files if k.startswith("resize_")}):
+        _, size, r = key.split("_")
+        H, W = map(int, size.split("x"))
+        r = float(r[1:])
+        seed = int(g[key + "/seed"])
+        x = detgen.uniform((2, 3, H, W), seed).requires_grad_(True)
+        gy = detgen.normal((2, 3, H, W), seed + 5000)
+        y = attacks_ref.resize(x, r)
+        (y * gy).sum().backward()
+        close(y, g[key + "/y"], atol=1e-6)
+        close(x.grad, g[key + "/gx"], atol=1e-5)
+    for key in sorted({k.split("/")[0] for k in g.files if k.startswith("crop_") and "rand" not in k}):
+        parts = key.split("_")
+        H, W = map(int, parts[1].split("x"))
+        apex = tuple(map(int, parts[2:]))
+        seed = int(g[key + "/seed"])
+        x = detgen.uniform((2, 3, H, W), seed).requires_grad_(True)
+        gy = detgen.normal((2, 3, H, W), seed + 5000)
+        y, ap = attacks_ref.crop(x, apex=apex)
+        (y * gy).sum().backward()
+        assert tuple(ap) == tuple(g[key + "/apex"])
+        close(y, g[key + "/y"], atol=1e-6)
+        close(x.grad, g[key + "/gx"], atol=1e-5)
+    for s in (1, 2, 3):
+        np.random.seed(s)
+        x = detgen.uniform((1, 3, 32, 32), 750 + s)
+        y, ap = attacks_ref.crop(x)
+        assert tuple(ap) == tuple(g[f"crop_rand_seed{s}/apex"])
+        close(y, g[f"crop_rand_seed{s}/y"], atol=1e-6)
+    x = detgen.uniform((2, 3, 16, 16), int(g["quant/seed"]), lo=-0.2, hi=1.2).requires_grad_(True)
+    gy = detgen.normal((2, 3, 16, 16), 5800)
+    y = attacks_ref.quantization(x)
+    (y * gy).sum().backward()
+    close(y, g["quant/y"], atol=0)
+    close(x.grad, g["quant/gx"], atol=0)
+    close(attacks_ref.quantization(y.detach()), y.detach().numpy(), atol=0)  # idempotent
+    assert list(g["combined/names"]) == ["JpegMask80", "Jpeg80", "JpegSS70", "Identity"]
+    assert attacks_ref.combined_pick(4, 2) == 2 and 0 <= attacks_ref.combined_pick(4, 7) < 4
+
+
+def test_median_definition():
+    # parity unpinned (kornia absent): check the definition against a direct loop
+    x = detgen.uniform((1, 2, 7, 9), 77)
+    for k in (3, 5):
+        y = attacks_ref.median_blur(x, k)
+        p = k // 2
+        xp = np.pad(x.numpy(), ((0, 0), (0, 0), (p, p), (p, p)))
+        for (c, i, j) in ((0, 0, 0), (1, 3, 4), (1, 6, 8), (0, 2, 8)):
+            assert y[0, c, i, j].item() == np.median(xp[0, c, i:i + k, j:j + k])
+
+
+def test_hidden_modules(golden):
+    g = golden("hidden")
+    for (cin, cout) in ((3, 64), (64, 64), (64, 30)):
+        key = f"cbr_{cin}_{cout}"
+        m = detgen.fill_module(hidden_ref.ConvBNRelu(cin, cout)).train()
+        x = detgen.normal((2, cin, 16, 16), 1000 + cin + cout).requires_grad_(True)
+        gy = detgen.normal((2, cout, 16, 16), 6000 + cin + cout)
+        y = m(x)
+        (y * gy).sum().backward()
+        close(y, g[key + "/y"], atol=1e-5)
+        close(x.grad, g[key + "/gx"], rtol=1e-4, atol=1e-4)
+        close(m.layers[0].weight.grad, g[key + "/gw"], rtol=1e-4, atol=1e-3)
+        close(m.layers[1].weight.grad, g[key + "/ggamma"], rtol=1e-4, atol=1e-3)
+        close(m.layers[1].bias.grad, g[key + "/gbeta"], rtol=1e-4, atol=1e-3)
+        close(m.layers[1].running_mean, g[key + "/running_mean"], atol=1e-6)
+        close(m.layers[1].running_var, g[key + "/running_var"], atol=1e-6)
+    cfg = hidden_ref.HiDDenConfiguration(H=32, W=32)
+    enc = detgen.fill_module(hidden_ref.Encoder(cfg)).train()
+    dec = detgen.fill_module(hidden_ref.Decoder(cfg)).train()
+    dis = detgen.fill_module(hidden_ref.Discriminator(cfg)).train()
+    assert list(g["param_counts"]) == [sum(p.numel() for p in m.parameters()) for m in (enc, dec, dis)]
+    assert list(g["param_counts"]) == [169347, 242556, 76097]
+    img = detgen.uniform((2, 3, 32, 32), 1100).requires_grad_(True)
+    msg = detgen.bits((2, 30), 1101)
+    e = enc(img, msg)
+    (e * detgen.normal((2, 3, 32, 32), 6100)).sum().backward()
+    close(e, g["enc32/y"], atol=1e-5)
+    close(img.grad, g["enc32/gimg"], rtol=1e-3, atol=1e-4)
+    for n, p in enc.named_parameters():
+        close(detgen.subsample(p.grad, 97), g[f"enc32/g/{n}"], rtol=1e-3, atol=1e-3)
+    x = detgen.uniform((2, 3, 32, 32), 1102).requires_grad_(True)
+    d = dec(x)
+    (d * detgen.normal((2, 30), 6101)).sum().backward()
+    close(d, g["dec32/y"], atol=1e-5)
+    close(x.grad, g["dec32/gx"], rtol=1e-3, atol=1e-5)
+    x = detgen.uniform((2, 3, 32, 32), 1103).requires_grad_(True)
+    d = dis(x)
+    (d * detgen.normal((2, 1), 6102)).sum().backward()
+    close(d, g["dis32/y"], atol=1e-5)
+    close(x.grad, g["dis32/gx"], rtol=1e-3, atol=1e-5)
+    # config C1
+    cfg = hidden_ref.HiDDenConfiguration(H=128, W=128)
+    enc = detgen.fill_module(hidden_ref.Encoder(cfg)).train()
+    dec = detgen.fill_module(hidden_ref.Decoder(cfg)).train()
+    e = enc(detgen.uniform((1, 3, 128, 128), 1200), detgen.bits((1, 30), 1201))
+    d = dec(e)
+    close(detgen.subsample(e, 13), g["c1/encoded_sub"], atol=1e-5)
+    close(d, g["c1/decoded"], atol=1e-5)
+
+
+@pytest.mark.parametrize("nname", ["JpegSS50", "Jpeg50", "JpegMask50", "Identity"])
+def test_full_step(golden, nname):
+    g = golden("step")
+    noise = {
+        "JpegSS50": lambda x: jpeg_ref.jpeg_layer(x, 50, "ss"),
+        "Jpeg50": lambda x: jpeg_ref.jpeg_layer(x, 50, "round"),
+        "JpegMask50": lambda x: jpeg_ref.jpeg_layer(x, 50, "mask"),
+        "Identity": lambda x: x,
+    }[nname]
+    cfg = hidden_ref.HiDDenConfiguration(H=32, W=32)
+    h = hidden_ref.HiddenRef(cfg, noise)
+    for m in (h.encoder, h.decoder, h.discriminator):
+        detgen.fill_module(m)
+    images = detgen.uniform((4, 3, 32, 32), 2000)
+    messages = detgen.bits((4, 30), 2001)
+    for it in range(2):
+        losses, (enc, noised, dec), grads = h.train_on_batch(images, messages)
+        ref = g[f"step_{nname}/losses_it{it}"]
+        got = [losses[k] for k in ("loss           ", "encoder_mse    ", "dec_mse        ", "bitwise-error  ",
+                                   "adversarial_bce", "discr_cover_bce", "discr_encod_bce")]
+        np.testing.assert_allclose(got, ref, rtol=2e-3 if it else 1e-4, atol=1e-5)
+        if it == 0:
+            close(enc, g[f"step_{nname}/encoded"], atol=1e-5)
+            close(dec, g[f"step_{nname}/decoded"], atol=1e-4)
+            for n, gr in grads["D"].items():
+                close(detgen.subsample(gr, 31), g[f"step_{nname}/gD/{n}"], rtol=1e-3, atol=1e-5)
+            for n, gr in grads["E"].items():
+                close(detgen.subsample(gr, 31), g[f"step_{nname}/gE/{n}"], rtol=1e-3, atol=1e-5)
+            for n, gr in grads["Dec"].items():
+                close(detgen.subsample(gr, 31), g[f"step_{nname}/gDec/{n}"], rtol=1e-3, atol=1e-5)
+
+
+def test_unet(golden):
+    g = golden("unet")
+    net = detgen.fill_module(unet_ref.UNet(3, 1, 32)).train()
+    assert int(g["param_count"]) == sum(p.numel() for p in net.parameters()) == 7763041
+    for (B, H) in ((1, 32), (2, 64)):
+        net.zero_grad()
+        key = f"unet_{B}x{H}"
+        x = detgen.uniform((B, 3, H, H), 3000 + H).requires_grad_(True)
+        y = net(x)
+        (y * detgen.normal((B, 1, H, H), 8000 + H)).sum().backward()
+        close(y, g[key + "/y"], atol=1e-5)
+        close(x.grad, g[key + "/gx"], rtol=1e-3, atol=1e-5)
+        for n, p in net.named_parameters():
+            np.testing.assert_allclose(p.grad.norm().item(), float(g[f"{key}/gnorm/{n}"]), rtol=1e-3, atol=1e-5)
