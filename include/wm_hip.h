@@ -1,0 +1,235 @@
+/*
+ * wm_hip.h -- C ABI of libwm_hip.so, the MI355X (gfx950) kernel library behind the
+ * watermark embed -> attack -> extract training step.
+ *
+ * The reference (yingqichao/video-watermarking-forgery-detection) has no native code and
+ * no FFI: every GPU kernel it runs is reached through torch.nn modules.  The entry points
+ * below are therefore the operator boundary a maintainer of the reference would bind with
+ * ctypes to replace, module by module, the torch ops listed next to
+ * each function ("replaces:" = reference file:line, paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C: raw device pointers + explicit sizes, no torch / C++ types;
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library never
+ *     allocates, frees or keeps a pointer after the call returns;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant,
+ *     and holds no mutable global state; safe under hipGraph capture;
+ *   - return value: 0 = ok, <0 = error (WM_E_*); wm_last_error_string() gives the text of
+ *     the last error on the calling thread.  No C++ exception crosses the boundary;
+ *   - activations are NHWC ("pixel-major"): element (b,h,w,c) lives at
+ *     base[((b*H + h)*W + w) * ld + c], ld >= C the per-pixel channel stride (lets a tensor
+ *     be a channel-slice of a wider one).  dtype of activations/packed weights:
+ *     WM_F32 (parity path, exact f32 MFMA) or WM_BF16 (production path, f32 accumulate).
+ *     Parameters, gradients of parameters, statistics and images at the attack boundary
+ *     are always f32; images at the attack boundary are NCHW planes like the reference.
+ */
+#ifndef WM_HIP_H
+#define WM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WM_F32 0
+#define WM_BF16 1
+
+#define WM_OK 0
+#define WM_E_BADARG (-1)   /* null pointer, non-positive size, unsupported dtype */
+#define WM_E_SHAPE (-2)    /* shape / alignment the kernels do not support */
+#define WM_E_HIP (-3)      /* a HIP runtime call or launch failed */
+
+const char* wm_last_error_string(void);
+int wm_abi_version(void);
+
+/* ------------------------------------------------------------------ block-JPEG attack
+ * replaces: noise_layers/jpeg.py:226-240 (Jpeg.forward), :259-273 (JpegSS), :295-306 (JpegMask)
+ * with helpers :52-211.  x,y: [B,3,H,W] f32 NCHW.  mode 0 = round, 1 = round_ss, 2 = mask.
+ * tables: host pointer to 128 floats = luminance[64] then chrominance[64] quantisation
+ * tables, already scaled/rounded/clamped as std_quantization does (ignored for mode 2).
+ * subsample: 0 or 2.  One fused kernel: x255, pad, RGB->YUV, (subsample), DCT, quantise,
+ * de-quantise, IDCT, YUV->RGB, crop, /255.  Algorithmic traffic 24 B/px. */
+#define WM_JPEG_ROUND 0
+#define WM_JPEG_SS 1
+#define WM_JPEG_MASK 2
+int wm_jpeg_fwd(const float* x, float* y, int B, int H, int W, int mode, const float* tables,
+                int subsample, void* stream);
+/* gx = d(sum(gy*y))/dx.  x is read only for mode 1 (derivative of round_ss needs the
+ * pre-rounding coefficient); mode 0 writes zeros (torch.round has zero gradient). */
+int wm_jpeg_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int mode,
+                const float* tables, int subsample, void* stream);
+
+/* ------------------------------------------------------------------ DiffJPEG
+ * replaces: utils/JPEG.py:256-291 (compress_jpeg) + :431-469 (decompress_jpeg) as composed
+ * by DiffJPEG.forward :535-540.  H,W multiples of 16.  rounding 0 = torch.round,
+ * 1 = round_only_at_0, 2 = diff_round.  factor = quality_to_factor(quality). */
+int wm_diffjpeg_fwd(const float* x, float* y, int B, int H, int W, int rounding, float factor,
+                    void* stream);
+int wm_diffjpeg_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int rounding,
+                    float factor, void* stream);
+
+/* ------------------------------------------------------------------ stencil / resample attacks
+ * All on [B,C,H,W] f32 NCHW planes (N = B*C planes of H x W).
+ * gauss3: replaces noise_layers/gaussian_blur.py:53-56 (depthwise 3x3, zero pad 1); w9 = host
+ *         pointer to the 9 weights.  Backward of a symmetric stencil = the same stencil. */
+int wm_stencil3_fwd(const float* x, float* y, int N, int H, int W, const float* w9, void* stream);
+/* median k x k (k = 3 or 5), zero padding: replaces noise_layers/middle_filter.py:5-13
+ * (kornia MedianBlur).  idx (int8 per pixel, may be NULL) records which window tap was
+ * selected so the backward can route the gradient to it. */
+int wm_median_fwd(const float* x, float* y, int8_t* idx, int N, int H, int W, int k, void* stream);
+int wm_median_bwd(const float* gy, const int8_t* idx, float* gx, int N, int H, int W, int k,
+                  void* stream);
+/* bicubic (A=-0.75, align_corners=False, no antialias) and bilinear resampling of the
+ * sub-rectangle [h0,h0+hs) x [w0,w0+ws) of x[N,H,W] to y[N,OH,OW]; replaces
+ * F.interpolate in noise_layers/resize.py:42-51 and noise_layers/crop.py:48-53.
+ * clamp01 != 0 clamps the output to [0,1] (resize.py:53).  The backward is the transpose
+ * (gather form, deterministic); gy_mask_src (may be NULL) is the un-clamped forward output,
+ * used to zero the gradient where the clamp was active. */
+#define WM_BILINEAR 0
+#define WM_BICUBIC 1
+int wm_resample_fwd(const float* x, float* y, int N, int H, int W, int h0, int hs, int w0, int ws,
+                    int OH, int OW, int kind, int clamp01, void* stream);
+int wm_resample_bwd(const float* gy, const float* y_unclamped, float* gx, int N, int H, int W,
+                    int h0, int hs, int w0, int ws, int OH, int OW, int kind, int clamp01,
+                    void* stream);
+/* Quantization: round(255 x)/255; replaces models/modules/Quantization.py:7-14 (the backward
+ * is the identity and needs no kernel). */
+int wm_quant_fwd(const float* x, float* y, size_t n, void* stream);
+
+/* ------------------------------------------------------------------ layout / packing
+ * image planes [B,C,H,W] f32 -> NHWC dtype with per-pixel stride ld, written at channel
+ * offset c0; channels [c0+C, c0+C+zero_tail) are zero-filled (padding for MFMA K). */
+int wm_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int ld, int c0,
+                    int zero_tail, int dtype, void* stream);
+/* NHWC dtype (stride ld, offset c0) -> [B,C,H,W] f32 */
+int wm_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int ld, int c0, int dtype,
+                    void* stream);
+/* per-sample vector v[B,L] f32 broadcast over H x W into NHWC at channel offset c0
+ * (the expanded message of hidden_models/encoder.py:34-37). */
+int wm_broadcast_to_nhwc(const float* v, void* y, int B, int L, int H, int W, int ld, int c0,
+                         int dtype, void* stream);
+/* relu(scale*x+shift) of an NHWC tensor copied into another NHWC tensor (channel slice):
+ * materialises a BatchNorm+ReLU output where a consumer cannot fuse it (concat). */
+int wm_bnrelu_copy(const void* x, int ldx, const float* scale, const float* shift, void* y, int ldy,
+                   int c0, size_t npix, int C, int dtype, void* stream);
+/* conv weight [Cout,Cin,3,3] f32 (PyTorch layout) -> packed [9][CoutP][CinP] dtype, zero padded.
+ * perm (host int[Cin], may be NULL): packed input channel perm[ci] holds reference channel ci.
+ * transpose != 0 builds the dgrad operand instead: [9][CinP][CoutP] with taps flipped. */
+int wm_pack_w3x3(const float* w, void* wp, int Cout, int Cin, int CoutP, int CinP, const int* perm,
+                 int transpose, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ conv 3x3, stride 1, pad 1
+ * replaces: nn.Conv2d(…,3,1,padding=1) inside hidden_models/conv_bn_relu.py:11-15 and
+ * network/UNet.py:67-97, as an implicit GEMM on MFMA (M = pixels, N = Cout, K = 9*Cin).
+ *   x  : NHWC [B,H,W,Cin] stride ldx.  If in_scale/in_shift != NULL the kernel applies
+ *        relu(in_scale[c]*x+in_shift[c]) while staging (fused BatchNorm+ReLU of the producer);
+ *        zero padding is applied after that transform, as the reference pads the activated map.
+ *   wp : packed weights from wm_pack_w3x3 (transpose=0), [9][CoutP][CinP]; CinP == Cin here.
+ *   bias: f32[CoutP] or NULL.   y: NHWC [B,H,W,CoutP] stride ldy (raw conv output).
+ *   stat_partials: NULL, or f32[wm_conv3x3_nparts(B,H,W)][2][CoutP]: per-workgroup sums of y
+ *        and y^2 (from the f32 accumulators) for the BatchNorm batch statistics.
+ * Cin multiple of 16 (bf16) / 8 (f32); CoutP multiple of 32.  The same entry point computes
+ * dgrad when given dy and the transposed pack. */
+int wm_conv3x3_nparts(int B, int H, int W);
+int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const float* bias, const float* in_scale,
+                   const float* in_shift, void* y, int ldy, float* stat_partials, int B, int H,
+                   int W, int Cin, int CoutP, int dtype, void* stream);
+/* weight gradient: dW[co,ci,kh,kw] = sum_{b,h,w} a[b,h+kh-1,w+kw-1,ci] * dy[b,h,w,co], with
+ * a = x or relu(in_scale*x+in_shift).  Writes f32 partial slabs ws[nslabs][9][CinP][CoutP]
+ * (nslabs = wm_conv3x3_wgrad_nslabs) and reduces them into dw[Cout,Cin,3,3] (PyTorch layout,
+ * overwritten or accumulated).  perm as in wm_pack_w3x3 (device int[Cin] or NULL). */
+int wm_conv3x3_wgrad_nslabs(int B, int H, int W);
+size_t wm_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout);
+int wm_conv3x3_wgrad(const void* x, int ldx, const float* in_scale, const float* in_shift,
+                     const void* dy, int lddy, float* ws, float* dw, int accumulate, int B, int H,
+                     int W, int Cin, int Cout, const int* perm_dev, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ BatchNorm2d (training)
+ * replaces nn.BatchNorm2d + nn.ReLU of conv_bn_relu.py:12-14 / UNet.py:67-97.
+ * finalize: partial sums -> batch mean / biased var; scale = gamma*invstd,
+ * shift = beta - mean*scale; running stats updated with `momentum` and the unbiased var
+ * (count/(count-1)), as torch does.  C real channels, CP padded (scale=shift=0 there). */
+int wm_bn_finalize(const float* partials, int nparts, int C, int CP, double count, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var, float momentum,
+                   float eps, float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* backward through ReLU + BatchNorm given g = dL/d(relu output) and the raw conv output y:
+ *   pass 1 (reduce): partial sums of gz = g*[scale*y+shift>0] and gz*xhat   -> partials
+ *   finalize       : dgamma, dbeta (f32[C], overwritten or accumulated), coefficient vectors
+ *   pass 2 (apply) : dy = scale*(gz - c1 - xhat*c2), written as NHWC dtype; also column sums
+ *                    of dy for the conv bias gradient.
+ * g may be a per-sample vector gvec[B,CP] (gradient of a global average pool, already
+ * divided by H*W) instead of a tensor: pass g=NULL and gvec. */
+int wm_bn_bwd_nparts(size_t npix);
+int wm_bn_bwd_reduce(const void* g, int ldg, const float* gvec, const void* y, int ldy,
+                     const float* scale, const float* shift, const float* mean, const float* invstd,
+                     float* partials, int B, size_t hw, int CP, int dtype, void* stream);
+int wm_bn_bwd_finalize(const float* partials, int nparts, int C, int CP, double count,
+                       const float* gamma, const float* invstd, float* dgamma, float* dbeta,
+                       int accumulate, float* coef /* [3][CP]: a=gamma*invstd, c1, c2 */, void* stream);
+int wm_bn_bwd_apply(const void* g, int ldg, const float* gvec, const void* y, int ldy,
+                    const float* scale, const float* shift, const float* mean, const float* invstd,
+                    const float* coef, void* dy, int lddy, float* dbias_partials, int B, size_t hw,
+                    int CP, int dtype, void* stream);
+/* column sums of partial rows: out[c] (+)= sum_p partials[p][c] (bias gradients). */
+int wm_colsum_finalize(const float* partials, int nparts, int C, int ldp, float* out, int accumulate,
+                       void* stream);
+
+/* ------------------------------------------------------------------ heads
+ * global average pool of relu(scale*y+shift): replaces nn.AdaptiveAvgPool2d((1,1)) at
+ * hidden_models/decoder.py:24 / discriminator.py:16.  out f32[B,CP]. */
+int wm_bnrelu_avgpool(const void* y, int ldy, const float* scale, const float* shift, float* out,
+                      int B, size_t hw, int CP, int dtype, void* stream);
+/* 1x1 conv Cin->Cout (Cout <= 4) on relu(scale*y+shift): replaces nn.Conv2d(64,3,1) at
+ * hidden_models/encoder.py:28,42 and the sigmoid head of network/UNet.py:41-43,65.
+ * w f32[Cout,Cin], bias f32[Cout]; out f32 NCHW [B,Cout,H,W]; act 0 = none, 1 = sigmoid. */
+int wm_conv1x1_head_fwd(const void* y, int ldy, const float* scale, const float* shift, const float* w,
+                        const float* bias, float* out, int B, size_t hw, int Cin, int Cout, int act,
+                        int dtype, void* stream);
+/* backward: gout f32 NCHW [B,Cout,H,W] (for act=1 the caller passes the gradient wrt the
+ * pre-sigmoid logits) -> g NHWC dtype [B,H,W,Cin] (gradient wrt the ReLU output), and
+ * partial sums for dw[Cout,Cin], dbias[Cout]: partials f32[nparts][Cout*(Cin+1)]. */
+int wm_conv1x1_head_nparts(size_t npix);
+int wm_conv1x1_head_bwd(const void* y, int ldy, const float* scale, const float* shift, const float* w,
+                        const float* gout, void* g, int ldg, float* partials, int B, size_t hw, int Cin,
+                        int Cout, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ UNet pieces
+ * 2x2 max pool of relu(scale*y+shift): replaces nn.MaxPool2d(2,2) (network/UNet.py:14-20).
+ * Writes the activated full-resolution map too when act_out != NULL (the skip tensor). */
+int wm_bnrelu_maxpool2(const void* y, int ldy, const float* scale, const float* shift, void* pooled,
+                       int ldp, void* act_out, int lda, int c0a, int B, int H, int W, int C, int dtype,
+                       void* stream);
+/* gradient of the pool scattered back to full resolution, added to g_skip when given. */
+int wm_maxpool2_bwd(const void* y, int ldy, const float* scale, const float* shift, const void* gpooled,
+                    int ldgp, const void* g_skip, int ldgs, void* g, int ldg, int B, int H, int W, int C,
+                    int dtype, void* stream);
+/* ConvTranspose2d k=2 s=2 (network/UNet.py:24-38) on relu(scale*x+shift):
+ * w f32[Cin,Cout,2,2], bias f32[Cout]; y NHWC [B,2H,2W,*] at channel offset c0. */
+int wm_upconv2x2_fwd(const void* x, int ldx, const float* scale, const float* shift, const float* w,
+                     const float* bias, void* y, int ldy, int c0, int B, int H, int W, int Cin, int Cout,
+                     int dtype, void* stream);
+int wm_upconv2x2_bwd(const void* x, int ldx, const float* scale, const float* shift, const float* w,
+                     const void* gy, int ldgy, int c0, void* gx, int ldgx, float* dw_partials,
+                     int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ losses / optimiser
+ * sum((a-b)^2) partials and gradient 2*w*(a-b)/n of nn.MSELoss (hidden.py:37,90). */
+int wm_mse_fwd_bwd(const float* a, const float* b, float* grad_a, float gscale, float* loss_partials,
+                   int nparts, size_t n, void* stream);
+/* y = a + s*b (f32), used to combine image-space gradients. */
+int wm_axpy(float* a, const float* b, float s, size_t n, void* stream);
+/* Adam / AdamW step over one flat f32 parameter buffer (torch.optim.Adam semantics,
+ * hidden.py:24-25: lr 1e-3, betas (0.9,0.999), eps 1e-8, weight_decay 0, no amsgrad).
+ * step = 1-based step count.  decoupled != 0 gives AdamW. */
+int wm_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int decoupled, int step, float grad_scale,
+                 void* stream);
+/* sum of squares partials (clip_grad_norm_) */
+int wm_sumsq(const float* x, size_t n, float* partials, int nparts, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WM_HIP_H */

@@ -1,0 +1,66 @@
+"""In-tree build of libwm_hip.so (hipcc, gfx950 only).
+
+    python -m video_watermarking_forgery_detection_amd.build [--force]
+
+Objects and the shared library are written next to the sources
+(csrc/_build/*.o, lib/libwm_hip.so); they are git-ignored but travel to the GPU
+box with the gpurun snapshot.  hipcc cross-compiles without a GPU.
+"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(CSRC, "_build")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "libwm_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(PKG, "..", "include", "wm_hip.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, src + ".o")
+    sp = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), _deps_mtime()):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = _sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in res]
+    changed = any(c for _, c in res)
+    if changed or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[wm build] {LIB} ({'rebuilt' if changed else 'up to date'}; {len(srcs)} sources)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,80 @@
+// Internal helpers shared by the gfx950 kernels of libwm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/wm_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- error plumbing (thread-local text, no exceptions across the ABI)
+void wm_set_error(const char* fmt, ...);
+#define WM_REQUIRE(cond, code, ...)                 \
+    do {                                            \
+        if (!(cond)) {                              \
+            wm_set_error(__VA_ARGS__);              \
+            return (code);                          \
+        }                                           \
+    } while (0)
+#define WM_LAUNCH_CHECK(name)                                                        \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            wm_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return WM_E_HIP;                                                         \
+        }                                                                            \
+    } while (0)
+
+static inline int wm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- dtype helpers
+template <typename T> struct wm_dtype;
+template <> struct wm_dtype<float> { static constexpr int id = WM_F32; };
+template <> struct wm_dtype<bf16_t> { static constexpr int id = WM_BF16; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 16-byte vector of T: 4 floats or 8 bf16
+template <typename T> struct vec16;
+template <> struct vec16<float> {
+    static constexpr int N = 4;
+    float4 v;
+    __device__ __forceinline__ float get(int i) const { return ((const float*)&v)[i]; }
+    __device__ __forceinline__ void set(int i, float f) { ((float*)&v)[i] = f; }
+};
+template <> struct vec16<bf16_t> {
+    static constexpr int N = 8;
+    bf16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float f) { v[i] = (bf16_t)f; }
+};
+
+// wave-level sum (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+#define WM_DISPATCH_DTYPE(dtype, NAME, ...)                                    \
+    do {                                                                       \
+        if ((dtype) == WM_F32) {                                               \
+            using T = float;                                                   \
+            __VA_ARGS__;                                                       \
+        } else if ((dtype) == WM_BF16) {                                       \
+            using T = bf16_t;                                                  \
+            __VA_ARGS__;                                                       \
+        } else {                                                               \
+            wm_set_error("%s: unsupported dtype %d", NAME, (int)(dtype));      \
+            return WM_E_BADARG;                                                \
+        }                                                                      \
+    } while (0)
