@@ -127,24 +127,26 @@ int wm_pack_w3x3(const float* w, void* wp, int Cout, int Cin, int CoutP, int Cin
  *        relu(in_scale[c]*x+in_shift[c]) while staging (fused BatchNorm+ReLU of the producer);
  *        zero padding is applied after that transform, as the reference pads the activated map.
  *   wp : packed weights from wm_pack_w3x3 (transpose=0), [9][CoutP][CinP]; CinP == Cin here.
- *   bias: f32[CoutP] or NULL.   y: NHWC [B,H,W,CoutP] stride ldy (raw conv output).
+ *   bias: f32[nbias] (nbias <= CoutP, the real Cout) or NULL.   y: NHWC [B,H,W,CoutP] stride ldy (raw conv output).
  *   stat_partials: NULL, or f32[wm_conv3x3_nparts(B,H,W)][2][CoutP]: per-workgroup sums of y
  *        and y^2 (from the f32 accumulators) for the BatchNorm batch statistics.
  * Cin multiple of 16 (bf16) / 8 (f32); CoutP multiple of 32.  The same entry point computes
  * dgrad when given dy and the transposed pack. */
 int wm_conv3x3_nparts(int B, int H, int W);
-int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const float* bias, const float* in_scale,
-                   const float* in_shift, void* y, int ldy, float* stat_partials, int B, int H,
+int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const float* bias, int nbias,
+                   const float* in_scale, const float* in_shift, void* y, int ldy, float* stat_partials, int B, int H,
                    int W, int Cin, int CoutP, int dtype, void* stream);
 /* weight gradient: dW[co,ci,kh,kw] = sum_{b,h,w} a[b,h+kh-1,w+kw-1,ci] * dy[b,h,w,co], with
  * a = x or relu(in_scale*x+in_shift).  Writes f32 partial slabs ws[nslabs][9][CinP][CoutP]
  * (nslabs = wm_conv3x3_wgrad_nslabs) and reduces them into dw[Cout,Cin,3,3] (PyTorch layout,
  * overwritten or accumulated).  perm as in wm_pack_w3x3 (device int[Cin] or NULL). */
 int wm_conv3x3_wgrad_nslabs(int B, int H, int W);
-size_t wm_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout);
-int wm_conv3x3_wgrad(const void* x, int ldx, const float* in_scale, const float* in_shift,
-                     const void* dy, int lddy, float* ws, float* dw, int accumulate, int B, int H,
-                     int W, int Cin, int Cout, const int* perm_dev, int dtype, void* stream);
+size_t wm_conv3x3_wgrad_ws_bytes(int B, int H, int W, int CinX, int CoutY);
+/* CinX / CoutY: channel counts of the x / dy tensors (padded, packed order);
+ * Cin / Cout: the reference parameter's dims (dw is [Cout,Cin,3,3]). */
+int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift,
+                     const void* dy, int lddy, int CoutY, float* ws, float* dw, int accumulate, int B,
+                     int H, int W, int Cin, int Cout, const int* perm_dev, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm2d (training)
  * replaces nn.BatchNorm2d + nn.ReLU of conv_bn_relu.py:12-14 / UNet.py:67-97.
@@ -179,8 +181,10 @@ int wm_colsum_finalize(const float* partials, int nparts, int C, int ldp, float*
 /* ------------------------------------------------------------------ heads
  * global average pool of relu(scale*y+shift): replaces nn.AdaptiveAvgPool2d((1,1)) at
  * hidden_models/decoder.py:24 / discriminator.py:16.  out f32[B,CP]. */
+int wm_avgpool_slices(size_t hw);
 int wm_bnrelu_avgpool(const void* y, int ldy, const float* scale, const float* shift, float* out,
-                      int B, size_t hw, int CP, int dtype, void* stream);
+                      float* ws /* f32[B * wm_avgpool_slices(hw) * CP] */, int B, size_t hw, int CP, int dtype,
+                      void* stream);
 /* 1x1 conv Cin->Cout (Cout <= 4) on relu(scale*y+shift): replaces nn.Conv2d(64,3,1) at
  * hidden_models/encoder.py:28,42 and the sigmoid head of network/UNet.py:41-43,65.
  * w f32[Cout,Cin], bias f32[Cout]; out f32 NCHW [B,Cout,H,W]; act 0 = none, 1 = sigmoid. */

@@ -1,0 +1,298 @@
+"""GPU parity of the conv-path HIP kernels (through the C ABI) against plain PyTorch fp32 CPU
+ops of the same definition: conv3x3 implicit GEMM (fwd, dgrad, wgrad), BatchNorm statistics /
+backward, heads, Adam.  f32 path: tight tolerance (exact-f32 MFMA, different summation order);
+bf16 path: tolerance of bf16 inputs (2^-8 relative) documented per assert."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import detgen
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(x, dtype, ld=None):
+    """[B,C,H,W] f32 cpu -> [B,H,W,ld] cuda (zero padded channels)."""
+    B, C, H, W = x.shape
+    ld = ld or C
+    out = torch.zeros(B, H, W, ld, dtype=dtype, device="cuda")
+    out[..., :C] = x.permute(0, 2, 3, 1).to(dtype).cuda()
+    return out
+
+
+def nchw(t, C):
+    return t[..., :C].float().permute(0, 3, 1, 2).cpu()
+
+
+CASES = [  # B, H, W, Cin, Cout
+    (2, 20, 37, 16, 64),
+    (1, 32, 32, 64, 64),
+    (2, 16, 16, 112, 64),
+    (1, 33, 16, 64, 32),
+    (1, 16, 48, 32, 128),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv3x3_fwd_and_stats(dtype, case):
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, Cin, Cout = case
+    x = detgen.normal((B, Cin, H, W), 1)
+    w = detgen.normal((Cout, Cin, 3, 3), 2, std=(2.0 / (9 * Cin)) ** 0.5)
+    bias = detgen.normal((Cout,), 3, std=0.1)
+    if dtype == torch.bfloat16:  # compare against the same bf16-rounded operands
+        x = x.bfloat16().float(); w = w.bfloat16().float()
+    ref = F.conv2d(x, w, bias, padding=1)
+    wp = ops.pack_w3x3(w.cuda(), Cout, Cin, dtype)
+    y, st = ops.conv3x3_fwd(nhwc(x, dtype), wp, bias.cuda(), None, None, True)
+    got = nchw(y, Cout)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2  # bf16 output rounding: 2^-8 * |y| (|y| <~ 4)
+    torch.testing.assert_close(got, ref, rtol=tol, atol=tol)
+    # statistics come from the f32 accumulators: tight in both modes
+    s = st.sum(0).cpu()
+    torch.testing.assert_close(s[0], ref.sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
+    torch.testing.assert_close(s[1], (ref * ref).sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3x3_fused_input_transform(dtype):
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, Cin, Cout = 2, 24, 24, 64, 64
+    x = detgen.normal((B, Cin, H, W), 4)
+    w = detgen.normal((Cout, Cin, 3, 3), 5, std=0.06)
+    sc = detgen.normal((Cin,), 6, std=0.5, mean=1.0)
+    sh = detgen.normal((Cin,), 7, std=0.5)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float(); w = w.bfloat16().float()
+    a = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    if dtype == torch.bfloat16:
+        a = a.bfloat16().float()  # the kernel rounds the activated value when it stages it
+    ref = F.conv2d(a, w, None, padding=1)  # zero padding AFTER the activation
+    wp = ops.pack_w3x3(w.cuda(), Cout, Cin, dtype)
+    y, _ = ops.conv3x3_fwd(nhwc(x, dtype), wp, None, sc.cuda(), sh.cuda(), False)
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(nchw(y, Cout), ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 20, 37, 64, 64), (1, 16, 16, 16, 64), (1, 24, 16, 64, 32)])
+def test_conv3x3_dgrad(dtype, case):
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, Cin, Cout = case
+    w = detgen.normal((Cout, Cin, 3, 3), 8, std=0.06)
+    dy = detgen.normal((B, Cout, H, W), 9)
+    if dtype == torch.bfloat16:
+        w = w.bfloat16().float(); dy = dy.bfloat16().float()
+    x = torch.zeros(B, Cin, H, W, requires_grad=True)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    CinP = max(32, Cin)  # dgrad output channels must be a multiple of 32
+    CoutP = Cout if Cout % 32 == 0 else 32
+    wpt = ops.pack_w3x3(w.cuda(), CoutP, CinP, dtype, transpose=True)     # [9][CinP][CoutP]
+    gx, _ = ops.conv3x3_fwd(nhwc(dy, dtype, CoutP), wpt, None, None, None, False)
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(nchw(gx, Cin), x.grad, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 20, 37, 64, 64), (1, 16, 16, 16, 64), (2, 32, 32, 64, 32), (1, 16, 32, 128, 64), (3, 48, 48, 64, 64)])
+def test_conv3x3_wgrad(dtype, case):
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, Cin, Cout = case
+    x = detgen.normal((B, Cin, H, W), 10)
+    dy = detgen.normal((B, Cout, H, W), 11)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float(); dy = dy.bfloat16().float()
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    dw = torch.full((Cout, Cin, 3, 3), 7.0, device="cuda")
+    ops.conv3x3_wgrad(nhwc(x, dtype), Cin, None, None, nhwc(dy, dtype), dw, accumulate=False)
+    scale = w.grad.abs().max().item()
+    tol = 1e-5 if dtype == torch.float32 else 1e-3   # products of bf16-exact inputs accumulate in f32
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=tol, atol=tol * scale)
+    # accumulate=True adds on top
+    ops.conv3x3_wgrad(nhwc(x, dtype), Cin, None, None, nhwc(dy, dtype), dw, accumulate=True)
+    torch.testing.assert_close(dw.cpu(), 2 * w.grad, rtol=tol, atol=2 * tol * scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wgrad_with_transform_and_perm(dtype):
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, Cout = 2, 16, 16, 64
+    Cref, CinX = 10, 16
+    perm = [9, 8, 7, 6, 5, 4, 3, 2, 1, 0]  # packed position of each reference channel
+    xr = detgen.normal((B, Cref, H, W), 12)
+    sc = detgen.normal((CinX,), 13, std=0.5, mean=1.0)
+    sh = detgen.normal((CinX,), 14, std=0.3)
+    dy = detgen.normal((B, Cout, H, W), 15)
+    xp = torch.zeros(B, CinX, H, W)
+    for ci, p in enumerate(perm):
+        xp[:, p] = xr[:, ci]
+    if dtype == torch.bfloat16:
+        xp = xp.bfloat16().float(); dy = dy.bfloat16().float()
+    a = torch.relu(xp * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    if dtype == torch.bfloat16:
+        a = a.bfloat16().float()
+    a_ref = torch.stack([a[:, p] for p in perm], 1)
+    w = torch.zeros(Cout, Cref, 3, 3, requires_grad=True)
+    F.conv2d(a_ref, w, None, padding=1).backward(dy)
+    dw = torch.zeros(Cout, Cref, 3, 3, device="cuda")
+    ops.conv3x3_wgrad(nhwc(xp, dtype), CinX, sc.cuda(), sh.cuda(), nhwc(dy, dtype), dw, False,
+                      perm_dev=torch.tensor(perm, dtype=torch.int32, device="cuda"))
+    tol = 1e-5 if dtype == torch.float32 else 1e-3
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=tol, atol=tol * w.grad.abs().max().item())
+    # forward pack with the same permutation
+    wv = detgen.normal((Cout, Cref, 3, 3), 16, std=0.1)
+    if dtype == torch.bfloat16:
+        wv = wv.bfloat16().float()
+    wp = ops.pack_w3x3(wv.cuda(), Cout, CinX, dtype, perm=perm)
+    y, _ = ops.conv3x3_fwd(nhwc(xp, dtype), wp, None, sc.cuda(), sh.cuda(), False)
+    ref = F.conv2d(a_ref, wv, None, padding=1)
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(nchw(y, Cout), ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,CP", [(64, 64), (30, 32)])
+def test_bn_train_fwd_bwd(dtype, C, CP):
+    """conv output y -> BN(train) -> ReLU, forward statistics/running stats and the full backward."""
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W = 3, 20, 24
+    y = detgen.normal((B, C, H, W), 20, std=1.5, mean=0.3)
+    g = detgen.normal((B, C, H, W), 21)
+    if dtype == torch.bfloat16:
+        y = y.bfloat16().float(); g = g.bfloat16().float()
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(detgen.normal((C,), 22, std=0.2, mean=1.0)); bn.bias.copy_(detgen.normal((C,), 23, std=0.2))
+    yr = y.clone().requires_grad_(True)
+    out = torch.relu(bn(yr))
+    out.backward(g)
+    # device side: statistics as the conv epilogue would emit them (one partial row)
+    yd = nhwc(y, dtype, CP)
+    part = torch.zeros(1, 2, CP, device="cuda")
+    part[0, 0, :C] = y.sum((0, 2, 3)).cuda(); part[0, 1, :C] = (y * y).sum((0, 2, 3)).cuda()
+    rm = torch.zeros(C, device="cuda"); rv = torch.ones(C, device="cuda")
+    gamma, beta = bn.weight.detach().cuda(), bn.bias.detach().cuda()
+    st = ops.bn_finalize(part, C, CP, B * H * W, gamma, beta, rm, rv, 0.1, 1e-5)
+    torch.testing.assert_close(rm.cpu(), bn.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv.cpu(), bn.running_var, rtol=1e-5, atol=1e-6)
+    act = torch.relu(yd[..., :C].float() * st[0, :C] + st[1, :C]).permute(0, 3, 1, 2).cpu()
+    torch.testing.assert_close(act, out.detach(), rtol=1e-4, atol=1e-4)
+    dgamma = torch.zeros(C, device="cuda"); dbeta = torch.zeros(C, device="cuda"); dbias = torch.zeros(C, device="cuda")
+    dy = ops.bn_bwd(nhwc(g, dtype, CP), None, yd, st, C, gamma, dgamma, dbeta, False, dbias)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    torch.testing.assert_close(nchw(dy, C), yr.grad, rtol=tol, atol=tol)
+    torch.testing.assert_close(dgamma.cpu(), bn.weight.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dbeta.cpu(), bn.bias.grad, rtol=1e-4, atol=1e-3)
+    assert dbias.abs().max().item() < (1e-2 if dtype == torch.float32 else 1.0)  # sum(dy) == 0 up to rounding
+    if CP > C:
+        assert dy[..., C:].abs().max().item() == 0.0
+    # gvec form: gradient of a global average pool
+    gv = detgen.normal((B, C), 24)
+    yr2 = y.clone().requires_grad_(True)
+    torch.relu(bn(yr2)).mean((2, 3)).backward(gv)
+    gvec = torch.zeros(B, CP, device="cuda"); gvec[:, :C] = (gv / (H * W)).cuda()
+    dy2 = ops.bn_bwd(None, gvec, yd, st, C, gamma, dgamma, dbeta, False, None)
+    torch.testing.assert_close(nchw(dy2, C), yr2.grad, rtol=tol, atol=tol * 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_heads(dtype):
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, Cin = 2, 12, 20, 64
+    y = detgen.normal((B, Cin, H, W), 30)
+    if dtype == torch.bfloat16:
+        y = y.bfloat16().float()
+    sc = detgen.normal((Cin,), 31, std=0.3, mean=1.0); sh = detgen.normal((Cin,), 32, std=0.3)
+    a = torch.relu(y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    # global average pool
+    pooled = ops.bnrelu_avgpool(nhwc(y, dtype), sc.cuda(), sh.cuda())
+    torch.testing.assert_close(pooled.cpu(), a.mean((2, 3)), rtol=1e-4, atol=1e-5)
+    # 1x1 head, Cout = 3 and 1 (sigmoid)
+    for Cout, act in ((3, 0), (1, 1)):
+        w = detgen.normal((Cout, Cin), 33 + Cout, std=0.2).requires_grad_(True)
+        b = detgen.normal((Cout,), 34 + Cout, std=0.2).requires_grad_(True)
+        ar = a.clone().requires_grad_(True)
+        lin = F.conv2d(ar, w.view(Cout, Cin, 1, 1), b)
+        ref = torch.sigmoid(lin) if act else lin
+        out = ops.conv1x1_head_fwd(nhwc(y, dtype), sc.cuda(), sh.cuda(), w.detach().cuda(), b.detach().cuda(), act)
+        torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+        gout = detgen.normal((B, Cout, H, W), 40)
+        lin.backward(gout)
+        dw = torch.zeros(Cout, Cin, device="cuda"); db = torch.zeros(Cout, device="cuda")
+        g = ops.conv1x1_head_bwd(nhwc(y, dtype), sc.cuda(), sh.cuda(), w.detach().cuda(), gout.cuda(), dw, db, False)
+        tol = 1e-4 if dtype == torch.float32 else 1e-2
+        torch.testing.assert_close(nchw(g, Cin), ar.grad, rtol=tol, atol=tol)
+        torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_layout_roundtrip_and_concat():
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W = 2, 9, 13
+    img = detgen.uniform((B, 3, H, W), 50)
+    for dtype in (torch.float32, torch.bfloat16):
+        x16 = torch.full((B, H, W, 16), 5.0, device="cuda", dtype=dtype)
+        ops.nchw_to_nhwc(img.cuda(), x16, 0, 13)
+        ref = torch.zeros(B, H, W, 16); ref[..., :3] = img.permute(0, 2, 3, 1)
+        torch.testing.assert_close(x16.float().cpu(), ref.to(dtype).float())
+        back = ops.nhwc_to_nchw(x16, 3, 0)
+        torch.testing.assert_close(back.cpu(), img.to(dtype).float())
+        cat = torch.full((B, H, W, 112), 9.0, device="cuda", dtype=dtype)
+        msg = detgen.bits((B, 30), 51)
+        feat = detgen.normal((B, 64, H, W), 52)
+        sc = detgen.normal((64,), 53, mean=1.0, std=0.2); sh = detgen.normal((64,), 54, std=0.2)
+        ops.bnrelu_copy(nhwc(feat, dtype), sc.cuda(), sh.cuda(), cat, 0, 64)
+        ops.broadcast_to_nhwc(msg.cuda(), cat, 64)
+        ops.nchw_to_nhwc(img.cuda(), cat, 94, 15)
+        c = cat.float().cpu()
+        fr = torch.relu(feat.to(dtype).float() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+        torch.testing.assert_close(c[..., :64], fr.to(dtype).float(), rtol=1e-2, atol=1e-2)
+        assert torch.equal(c[..., 64:94], msg.view(B, 1, 1, 30).expand(B, H, W, 30))
+        torch.testing.assert_close(c[..., 94:97], img.permute(0, 2, 3, 1).to(dtype).float())
+        assert c[..., 97:].abs().max() == 0
+
+
+def test_adam_matches_torch():
+    from video_watermarking_forgery_detection_amd import ops
+    n = 10007
+    p0 = detgen.normal((n,), 60);
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr])
+    p = p0.clone().cuda(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        g = detgen.normal((n,), 60 + step)
+        pr.grad = g.clone()
+        opt.step()
+        ops.adam_step(p, g.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.0, step)
+        torch.testing.assert_close(p.cpu(), pr.detach(), rtol=1e-6, atol=1e-6)
+    # AdamW
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=2e-4, betas=(0.9, 0.99), weight_decay=0.01)
+    p = p0.clone().cuda(); m.zero_(); v.zero_()
+    for step in range(1, 3):
+        g = detgen.normal((n,), 70 + step)
+        pr.grad = g.clone(); opt.step()
+        ops.adam_step(p, g.cuda(), m, v, 2e-4, 0.9, 0.99, 1e-8, 0.01, step, decoupled=True)
+        torch.testing.assert_close(p.cpu(), pr.detach(), rtol=1e-6, atol=1e-6)
+
+
+def test_mse_and_sumsq():
+    from video_watermarking_forgery_detection_amd import ops
+    a = detgen.normal((3, 3, 40, 40), 80); b = detgen.normal((3, 3, 40, 40), 81)
+    part, grad = ops.mse_fwd_bwd(a.cuda(), b.cuda(), 2.0 / a.numel())
+    torch.testing.assert_close(part.sum().cpu() / a.numel(), F.mse_loss(a, b), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(grad.cpu(), 2 * (a - b) / a.numel())
+    torch.testing.assert_close(ops.sumsq(a.cuda()).sum().cpu(), (a * a).sum(), rtol=1e-5, atol=1e-5)
+
+
+def test_shape_errors():
+    from video_watermarking_forgery_detection_amd import ops
+    x = torch.zeros(1, 8, 8, 24, device="cuda", dtype=torch.bfloat16)  # Cin=24 not a multiple of 16
+    wp = torch.zeros(9, 64, 24, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="multiple"):
+        ops.conv3x3_fwd(x, wp, None, None, None, False)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.conv3x3_fwd(x.cpu(), wp, None, None, None, False)

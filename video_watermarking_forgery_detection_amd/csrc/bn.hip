@@ -1,0 +1,343 @@
+// BatchNorm2d (training mode) + ReLU: statistics finalisation, backward (two streaming passes),
+// and the small consumers that apply the fused relu(scale*y+shift) on the fly
+// (global average pool, channel-slice copy).  gfx950, HBM-bound streaming kernels:
+// every thread moves 16-byte vectors of one pixel's channels, a wave covers whole pixels
+// (128 contiguous bytes per 64 bf16 channels), reductions go wave -> LDS -> per-workgroup
+// partial rows that a tiny second kernel sums in double (deterministic, no float atomics).
+//
+// Reference ops: nn.BatchNorm2d + nn.ReLU in hidden_models/conv_bn_relu.py:12-14 and
+// network/UNet.py:67-97; nn.AdaptiveAvgPool2d in hidden_models/decoder.py:24,
+// hidden_models/discriminator.py:16.
+#include "wm_common.h"
+
+namespace {
+
+constexpr int RED_THREADS = 256;
+
+// ------------------------------------------------------------------ forward statistics
+// partials: [nparts][2][CP] (sum, sum of squares).  One workgroup per 32 channels, 8 slices of parts.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nparts, int C, int CP,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* running_mean,
+                                                          float* running_var, float momentum, float eps,
+                                                          float* scale, float* shift, float* mean_out,
+                                                          float* invstd_out) {
+    __shared__ double s1[8][32], s2[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < CP) {
+        for (int p = sl; p < nparts; p += 8) {
+            a1 += (double)partials[((size_t)p * 2 + 0) * CP + c];
+            a2 += (double)partials[((size_t)p * 2 + 1) * CP + c];
+        }
+    }
+    s1[sl][cl] = a1; s2[sl][cl] = a2;
+    __syncthreads();
+    if (sl == 0 && c < CP) {
+        for (int k = 1; k < 8; ++k) { a1 += s1[k][cl]; a2 += s2[k][cl]; }
+        if (c < C) {
+            const double m = a1 / count;
+            double var = a2 / count - m * m;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = gamma[c] * invstd;
+            scale[c] = sc;
+            shift[c] = beta[c] - (float)m * sc;
+            mean_out[c] = (float)m;
+            invstd_out[c] = invstd;
+            if (running_mean) {
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+        } else {  // padded channel: contributes nothing downstream
+            scale[c] = 0.f; shift[c] = 0.f; mean_out[c] = 0.f; invstd_out[c] = 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward, pass 1
+// thread -> (pixel slot, 16-byte channel vector).  VPP vectors per pixel, PPB pixels per block-iteration.
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(RED_THREADS) void bn_bwd_kernel(const T* __restrict__ g, int ldg, const float* __restrict__ gvec,
+                                                             const T* __restrict__ y, int ldy,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ coef, T* __restrict__ dy, int lddy,
+                                                             float* __restrict__ partials, size_t npix, size_t hw, int CP) {
+    constexpr int VE = vec16<T>::N;
+    const int VPP = CP / VE;
+    const int PPB = RED_THREADS / VPP;  // pixels per block iteration (VPP divides 256 for CP in {32,64,128,256,512})
+    const int vv = threadIdx.x % VPP, ps = threadIdx.x / VPP;
+    const int c0 = vv * VE;
+    float sc[VE], sh[VE], mu[VE], is[VE], ca[VE], c1[VE], c2[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e];
+        if (APPLY) { ca[e] = coef[c0 + e]; c1[e] = coef[CP + c0 + e]; c2[e] = coef[2 * CP + c0 + e]; }
+    }
+    float a1[VE], a2[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    if (ps < PPB) {
+        for (size_t p = (size_t)blockIdx.x * PPB + ps; p < npix; p += (size_t)gridDim.x * PPB) {
+            const vec16<T> yv = *reinterpret_cast<const vec16<T>*>(y + p * ldy + c0);
+            vec16<T> gv;
+            const float* gb = nullptr;
+            if (g) gv = *reinterpret_cast<const vec16<T>*>(g + p * ldg + c0);
+            else gb = gvec + (p / hw) * CP + c0;
+            vec16<T> out;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float yy = yv.get(e);
+                const float gg = g ? gv.get(e) : gb[e];
+                const float z = sc[e] * yy + sh[e];
+                const float gz = z > 0.f ? gg : 0.f;
+                const float xh = (yy - mu[e]) * is[e];
+                if (APPLY) {
+                    const float d = ca[e] * (gz - c1[e] - xh * c2[e]);
+                    out.set(e, d);
+                    a1[e] += d;
+                } else {
+                    a1[e] += gz;
+                    a2[e] += gz * xh;
+                }
+            }
+            if (APPLY) *reinterpret_cast<vec16<T>*>(dy + p * lddy + c0) = out;
+        }
+    }
+    if (!partials) return;
+    // block reduction over the PPB pixel slots that share a channel vector
+    __shared__ float red[2][RED_THREADS][vec16<T>::N + 1];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { red[0][threadIdx.x][e] = a1[e]; red[1][threadIdx.x][e] = a2[e]; }
+    __syncthreads();
+    const int nwhich = APPLY ? 1 : 2;
+    for (int i = threadIdx.x; i < nwhich * CP; i += RED_THREADS) {
+        const int which = i / CP, c = i - which * CP;
+        const int v2 = c / VE, e = c - v2 * VE;
+        float s = 0.f;
+        for (int q = 0; q < PPB; ++q) s += red[which][q * VPP + v2][e];
+        partials[((size_t)blockIdx.x * nwhich + which) * CP + c] = s;
+    }
+}
+
+// partials [nparts][2][CP] -> dgamma, dbeta, coef[3][CP]
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, int CP,
+                                                              double count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ invstd, float* dgamma,
+                                                              float* dbeta, int accumulate, float* coef) {
+    __shared__ double s1[8][32], s2[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < CP) {
+        for (int p = sl; p < nparts; p += 8) {
+            a1 += (double)partials[((size_t)p * 2 + 0) * CP + c];
+            a2 += (double)partials[((size_t)p * 2 + 1) * CP + c];
+        }
+    }
+    s1[sl][cl] = a1; s2[sl][cl] = a2;
+    __syncthreads();
+    if (sl == 0 && c < CP) {
+        for (int k = 1; k < 8; ++k) { a1 += s1[k][cl]; a2 += s2[k][cl]; }
+        if (c < C) {
+            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)a1;
+            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)a2;
+            coef[c] = gamma[c] * invstd[c];
+            coef[CP + c] = (float)(a1 / count);
+            coef[2 * CP + c] = (float)(a2 / count);
+        } else {
+            coef[c] = 0.f; coef[CP + c] = 0.f; coef[2 * CP + c] = 0.f;
+        }
+    }
+}
+
+// out[c] (+)= sum_p partials[p*ldp + c]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partials, int nparts, int C, int ldp,
+                                                     float* out, int accumulate, float mul, size_t in_bstride,
+                                                     size_t out_bstride) {
+    partials += (size_t)blockIdx.y * in_bstride;
+    out += (size_t)blockIdx.y * out_bstride;
+    __shared__ double s1[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a1 = 0.0;
+    if (c < C)
+        for (int p = sl; p < nparts; p += 8) a1 += (double)partials[(size_t)p * ldp + c];
+    s1[sl][cl] = a1;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) a1 += s1[k][cl];
+        out[c] = (accumulate ? out[c] : 0.f) + (float)(a1 * (double)mul);
+    }
+}
+
+// ------------------------------------------------------------------ avg pool of relu(scale*y+shift)
+// grid (S slices, B).  ws [B][S][CP]
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void avgpool_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, float* __restrict__ ws,
+                                                              size_t hw, int CP) {
+    constexpr int VE = vec16<T>::N;
+    const int VPP = CP / VE, PPB = RED_THREADS / VPP;
+    const int vv = threadIdx.x % VPP, ps = threadIdx.x / VPP;
+    const int c0 = vv * VE;
+    const int b = blockIdx.y, S = gridDim.x;
+    float sc[VE], sh[VE], a1[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; a1[e] = 0.f; }
+    if (ps < PPB) {
+        for (size_t p = (size_t)blockIdx.x * PPB + ps; p < hw; p += (size_t)S * PPB) {
+            const vec16<T> yv = *reinterpret_cast<const vec16<T>*>(y + ((size_t)b * hw + p) * ldy + c0);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) a1[e] += fmaxf(sc[e] * yv.get(e) + sh[e], 0.f);
+        }
+    }
+    __shared__ float red[RED_THREADS][vec16<T>::N + 1];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) red[threadIdx.x][e] = a1[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < CP; c += RED_THREADS) {
+        const int v2 = c / VE, e = c - v2 * VE;
+        float s = 0.f;
+        for (int q = 0; q < PPB; ++q) s += red[q * VPP + v2][e];
+        ws[((size_t)b * S + blockIdx.x) * CP + c] = s;
+    }
+}
+
+// ------------------------------------------------------------------ channel-slice copy with fused BN+ReLU
+template <typename T>
+__global__ __launch_bounds__(256) void bnrelu_copy_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, T* __restrict__ y, int ldy, int c0,
+                                                          size_t npix, int C) {
+    constexpr int VE = vec16<T>::N;
+    const int VPP = C / VE;
+    const size_t total = npix * VPP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / VPP;
+        const int c = (int)(i - p * VPP) * VE;
+        vec16<T> v = *reinterpret_cast<const vec16<T>*>(x + p * ldx + c);
+        if (scale) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v.set(e, fmaxf(scale[c + e] * v.get(e) + shift[c + e], 0.f));
+        }
+        *reinterpret_cast<vec16<T>*>(y + p * ldy + c0 + c) = v;
+    }
+}
+
+bool cp_ok(int CP, int dtype) {
+    const int ve = dtype == WM_BF16 ? 8 : 4;
+    if (CP <= 0 || CP % ve) return false;
+    const int vpp = CP / ve;
+    return vpp <= 256 && (256 % vpp) == 0;
+}
+
+}  // namespace
+
+extern "C" int wm_bn_finalize(const float* partials, int nparts, int C, int CP, double count, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                              float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    WM_REQUIRE(partials && gamma && beta && scale && shift && mean && invstd, WM_E_BADARG, "wm_bn_finalize: null pointer");
+    WM_REQUIRE(nparts > 0 && C > 0 && CP >= C && count > 0, WM_E_BADARG, "wm_bn_finalize: bad sizes");
+    WM_REQUIRE((running_mean == nullptr) == (running_var == nullptr), WM_E_BADARG, "wm_bn_finalize: running stats must come together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(wm_cdiv(CP, 32)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C, CP,
+                       count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
+    WM_LAUNCH_CHECK("wm_bn_finalize");
+    return WM_OK;
+}
+
+extern "C" int wm_bn_bwd_nparts(size_t npix) {
+    const size_t n = (npix + 255) / 256;
+    return (int)(n < 1 ? 1 : (n > 2048 ? 2048 : n));
+}
+
+extern "C" int wm_bn_bwd_reduce(const void* g, int ldg, const float* gvec, const void* y, int ldy, const float* scale,
+                                const float* shift, const float* mean, const float* invstd, float* partials, int B,
+                                size_t hw, int CP, int dtype, void* stream) {
+    WM_REQUIRE((g != nullptr) != (gvec != nullptr), WM_E_BADARG, "wm_bn_bwd_reduce: exactly one of g / gvec");
+    WM_REQUIRE(y && scale && shift && mean && invstd && partials, WM_E_BADARG, "wm_bn_bwd_reduce: null pointer");
+    WM_REQUIRE(cp_ok(CP, dtype), WM_E_SHAPE, "wm_bn_bwd_reduce: unsupported channel count CP=%d", CP);
+    const size_t npix = (size_t)B * hw;
+    const int nparts = wm_bn_bwd_nparts(npix);
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_bn_bwd_reduce",
+        hipLaunchKernelGGL((bn_bwd_kernel<T, false>), dim3(nparts), dim3(RED_THREADS), 0, s, (const T*)g, ldg, gvec,
+                           (const T*)y, ldy, scale, shift, mean, invstd, (const float*)nullptr, (T*)nullptr, 0, partials,
+                           npix, hw, CP));
+    WM_LAUNCH_CHECK("wm_bn_bwd_reduce");
+    return WM_OK;
+}
+
+extern "C" int wm_bn_bwd_finalize(const float* partials, int nparts, int C, int CP, double count, const float* gamma,
+                                  const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef,
+                                  void* stream) {
+    WM_REQUIRE(partials && gamma && invstd && coef, WM_E_BADARG, "wm_bn_bwd_finalize: null pointer");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(wm_cdiv(CP, 32)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C,
+                       CP, count, gamma, invstd, dgamma, dbeta, accumulate, coef);
+    WM_LAUNCH_CHECK("wm_bn_bwd_finalize");
+    return WM_OK;
+}
+
+extern "C" int wm_bn_bwd_apply(const void* g, int ldg, const float* gvec, const void* y, int ldy, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, const float* coef, void* dy,
+                               int lddy, float* dbias_partials, int B, size_t hw, int CP, int dtype, void* stream) {
+    WM_REQUIRE((g != nullptr) != (gvec != nullptr), WM_E_BADARG, "wm_bn_bwd_apply: exactly one of g / gvec");
+    WM_REQUIRE(y && scale && shift && mean && invstd && coef && dy, WM_E_BADARG, "wm_bn_bwd_apply: null pointer");
+    WM_REQUIRE(cp_ok(CP, dtype), WM_E_SHAPE, "wm_bn_bwd_apply: unsupported channel count CP=%d", CP);
+    const size_t npix = (size_t)B * hw;
+    const int nparts = wm_bn_bwd_nparts(npix);
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_bn_bwd_apply",
+        hipLaunchKernelGGL((bn_bwd_kernel<T, true>), dim3(nparts), dim3(RED_THREADS), 0, s, (const T*)g, ldg, gvec,
+                           (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, dbias_partials, npix, hw, CP));
+    WM_LAUNCH_CHECK("wm_bn_bwd_apply");
+    return WM_OK;
+}
+
+extern "C" int wm_colsum_finalize(const float* partials, int nparts, int C, int ldp, float* out, int accumulate,
+                                  void* stream) {
+    WM_REQUIRE(partials && out && nparts > 0 && C > 0 && ldp >= C, WM_E_BADARG, "wm_colsum_finalize: bad arguments");
+    hipLaunchKernelGGL(colsum_kernel, dim3(wm_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C, ldp, out,
+                       accumulate, 1.0f, (size_t)0, (size_t)0);
+    WM_LAUNCH_CHECK("wm_colsum_finalize");
+    return WM_OK;
+}
+
+extern "C" int wm_avgpool_slices(size_t hw) {
+    const size_t n = (hw + 1023) / 1024;
+    return (int)(n < 1 ? 1 : (n > 64 ? 64 : n));
+}
+
+extern "C" int wm_bnrelu_avgpool(const void* y, int ldy, const float* scale, const float* shift, float* out, float* ws,
+                                 int B, size_t hw, int CP, int dtype, void* stream) {
+    WM_REQUIRE(y && scale && shift && out && ws, WM_E_BADARG, "wm_bnrelu_avgpool: null pointer");
+    WM_REQUIRE(cp_ok(CP, dtype), WM_E_SHAPE, "wm_bnrelu_avgpool: unsupported channel count CP=%d", CP);
+    const int S = wm_avgpool_slices(hw);
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_bnrelu_avgpool",
+        hipLaunchKernelGGL((avgpool_kernel<T>), dim3(S, B), dim3(RED_THREADS), 0, s, (const T*)y, ldy, scale, shift, ws, hw, CP));
+    WM_LAUNCH_CHECK("wm_bnrelu_avgpool");
+    // ws viewed as [B][S*CP]: per sample reduce S rows of CP -> out[b][CP], scaled by 1/hw
+    hipLaunchKernelGGL(colsum_kernel, dim3(wm_cdiv(CP, 32), B), dim3(256), 0, s, ws, S, CP, CP, out, 0,
+                       (float)(1.0 / (double)hw), (size_t)S * CP, (size_t)CP);
+    WM_LAUNCH_CHECK("wm_bnrelu_avgpool(finalize)");
+    return WM_OK;
+}
+
+extern "C" int wm_bnrelu_copy(const void* x, int ldx, const float* scale, const float* shift, void* y, int ldy, int c0,
+                              size_t npix, int C, int dtype, void* stream) {
+    WM_REQUIRE(x && y, WM_E_BADARG, "wm_bnrelu_copy: null pointer");
+    WM_REQUIRE((scale == nullptr) == (shift == nullptr), WM_E_BADARG, "wm_bnrelu_copy: scale/shift must come together");
+    const int ve = dtype == WM_BF16 ? 8 : 4;
+    WM_REQUIRE(C > 0 && C % ve == 0 && c0 % ve == 0 && ldx % ve == 0 && ldy % ve == 0, WM_E_SHAPE,
+               "wm_bnrelu_copy: C=%d c0=%d ldx=%d ldy=%d must be multiples of %d", C, c0, ldx, ldy, ve);
+    const size_t total = npix * (C / ve);
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_bnrelu_copy",
+        hipLaunchKernelGGL((bnrelu_copy_kernel<T>), dim3(blocks), dim3(256), 0, s, (const T*)x, ldx, scale, shift, (T*)y, ldy, c0, npix, C));
+    WM_LAUNCH_CHECK("wm_bnrelu_copy");
+    return WM_OK;
+}

@@ -1,0 +1,328 @@
+// 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on MFMA (gfx950), forward + dgrad.
+//
+// Reference op: nn.Conv2d(cin, cout, 3, 1, padding=1) in hidden_models/conv_bn_relu.py:11 and
+// network/UNet.py:67-97 (followed there by BatchNorm2d + ReLU, which this kernel helps fuse:
+// the *consumer* applies relu(scale*x+shift) of the producer while staging its input tile, and
+// the *producer* emits the per-channel sum / sum-of-squares of its f32 accumulators).
+//
+// GEMM view: M = B*H*W output pixels, N = Cout, K = 9*Cin.  NHWC activations.
+//   workgroup  = 256 threads (4 waves) -> 16x16 output pixels x BN output channels
+//   wave       = 4 tile rows (64 pixels) x BN channels = 2 x (BN/32) MFMA 32x32 accumulators
+//   K loop     = Cin chunks of CK channels; per chunk the 18x18xCK input halo tile and the
+//                [9][BN][CK] weight slab are staged into LDS once and reused by all 9 taps
+//                (each input element is fetched from HBM once per Cout tile, +27% halo).
+//   bf16 path  : v_mfma_f32_32x32x16_bf16, CK = 32, f32 accumulate
+//   f32 path   : v_mfma_f32_32x32x2_f32 (exact f32 FMA chain), CK = 16 -- the parity path
+// LDS rows (one pixel's CK channels / one filter row) are padded by 16 B to an 80-byte stride:
+// 16 consecutive pixels then hit 16 distinct 16-byte bank slots for ds_read_b128.
+// The epilogue restages the accumulators through LDS so the global stores are 16 B per lane
+// and contiguous over a pixel's channels (128 B for 64 bf16 channels).
+#include "wm_common.h"
+
+namespace {
+
+constexpr int TH = 16, TW = 16;
+constexpr int HH = TH + 2, HW = TW + 2;
+
+template <typename T> struct Cfg;
+template <> struct Cfg<bf16_t> {
+    static constexpr int CK = 32;   // channels per K chunk
+    static constexpr int VE = 8;    // elements per 16-byte vector
+    static constexpr int PS = 40;   // LDS row stride in elements (80 B)
+};
+template <> struct Cfg<float> {
+    static constexpr int CK = 16;
+    static constexpr int VE = 4;
+    static constexpr int PS = 20;   // 80 B
+};
+
+template <typename T>
+struct ConvArgs {
+    const T* x;
+    int ldx;
+    const T* wp;          // [9][CoutP][Cin]
+    const float* bias;    // [nbias] or null
+    int nbias;
+    const float* in_scale;
+    const float* in_shift;
+    T* y;
+    int ldy;
+    float* stat;          // [gridDim.x][2][CoutP] or null
+    int B, H, W, Cin, CoutP;
+    int tilesX, tilesY;
+};
+
+template <typename T> __device__ __forceinline__ void zero_vec(vec16<T>& v) {
+#pragma unroll
+    for (int i = 0; i < vec16<T>::N; ++i) v.set(i, 0.f);
+}
+
+template <typename T, int BN, bool XFORM>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs<T> a) {
+    constexpr int CK = Cfg<T>::CK, VE = Cfg<T>::VE, PS = Cfg<T>::PS;
+    constexpr int NF = BN / 32;
+    constexpr int A_ELEMS = HH * HW * PS;
+    constexpr int B_ELEMS = 9 * BN * PS;
+    constexpr int OPS = BN + 16 / (int)sizeof(T);          // output staging row stride (elements)
+    constexpr int MAIN_BYTES = (A_ELEMS + B_ELEMS) * (int)sizeof(T);
+    constexpr int OUT_BYTES = TH * TW * OPS * (int)sizeof(T);
+    constexpr int LDS_BYTES = MAIN_BYTES > OUT_BYTES ? MAIN_BYTES : OUT_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + 4 * 2 * BN * 4];
+    T* sA = reinterpret_cast<T*>(smem);
+    T* sB = sA + A_ELEMS;
+    T* sOut = reinterpret_cast<T*>(smem);
+    float* sRed = reinterpret_cast<float*>(smem + LDS_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    int t = blockIdx.x;
+    const int txi = t % a.tilesX; t /= a.tilesX;
+    const int tyi = t % a.tilesY; t /= a.tilesY;
+    const int b = t;
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    const int n0 = blockIdx.y * BN;
+
+    f32x16 acc[2][NF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+    const int vec = tid & 3;  // this thread's 16-byte group inside a CK chunk (stride 256 keeps it fixed)
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        const int kvalid = min(CK, a.Cin - c0);
+        const int cbase = c0 + vec * VE;
+        const bool cok = vec * VE < kvalid;
+        float sc[VE], sh[VE];
+        if (XFORM && cok) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) { sc[i] = a.in_scale[cbase + i]; sh[i] = a.in_shift[cbase + i]; }
+        }
+        __syncthreads();  // previous chunk fully consumed
+        // ---- stage the input halo tile: 18x18 pixels x CK channels
+        for (int i = tid; i < HH * HW * 4; i += 256) {
+            const int pix = i >> 2;
+            const int py = pix / HW, px = pix - py * HW;
+            const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+            vec16<T> v;
+            const bool inb = cok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            if (inb) {
+                v = *reinterpret_cast<const vec16<T>*>(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldx + cbase);
+                if (XFORM) {
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) v.set(e, fmaxf(sc[e] * v.get(e) + sh[e], 0.f));
+                }
+            } else {
+                zero_vec(v);  // zero padding is applied AFTER the fused BN+ReLU, as the reference pads the activated map
+            }
+            *reinterpret_cast<vec16<T>*>(sA + pix * PS + vec * VE) = v;
+        }
+        // ---- stage the weight slab [9][BN][CK]
+        for (int i = tid; i < 9 * BN * 4; i += 256) {
+            const int row = i >> 2;  // tap*BN + n
+            const int tap = row / BN, n = row - tap * BN;
+            vec16<T> v;
+            if (cok) v = *reinterpret_cast<const vec16<T>*>(a.wp + ((size_t)tap * a.CoutP + n0 + n) * a.Cin + cbase);
+            else zero_vec(v);
+            *reinterpret_cast<vec16<T>*>(sB + row * PS + vec * VE) = v;
+        }
+        __syncthreads();
+        // ---- 9 taps x K steps of MFMA
+        if constexpr (sizeof(T) == 2) {
+            const int ksteps = (kvalid + 15) >> 4;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap % 3;
+                for (int ks = 0; ks < ksteps; ++ks) {
+                    bf16x8 af[2], bfr[NF];
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf) {
+                        const int py = wave * 4 + mf * 2 + (r >> 4), px = r & 15;
+                        af[mf] = *reinterpret_cast<const bf16x8*>(sA + ((py + kh) * HW + px + kw) * PS + ks * 16 + h * 8);
+                    }
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf)
+                        bfr[nf] = *reinterpret_cast<const bf16x8*>(sB + (tap * BN + nf * 32 + r) * PS + ks * 16 + h * 8);
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                        for (int nf = 0; nf < NF; ++nf)
+                            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mf], bfr[nf], acc[mf][nf], 0, 0, 0);
+                }
+            }
+        } else {
+            const int ksteps = kvalid >> 1;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap % 3;
+                for (int ks = 0; ks < ksteps; ++ks) {
+                    float af[2], bfr[NF];
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf) {
+                        const int py = wave * 4 + mf * 2 + (r >> 4), px = r & 15;
+                        af[mf] = sA[((py + kh) * HW + px + kw) * PS + ks * 2 + h];
+                    }
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf) bfr[nf] = sB[(tap * BN + nf * 32 + r) * PS + ks * 2 + h];
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                        for (int nf = 0; nf < NF; ++nf)
+                            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mf], bfr[nf], acc[mf][nf], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();  // all waves done with sA/sB before the output tile overwrites them
+
+    // ---- epilogue: bias, batch statistics, restage through LDS, coalesced store
+    // accumulator element i of lane (r,h): pixel row-in-fragment = (i&3) + 8*(i>>2) + 4*h, column n = r
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        const float bv = (a.bias && n0 + nf * 32 + r < a.nbias) ? a.bias[n0 + nf * 32 + r] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int prow = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int py = wave * 4 + mf * 2 + (prow >> 4), px = prow & 15;
+                const float v = acc[mf][nf][i] + bv;
+                const bool ok = (ty0 + py < a.H) && (tx0 + px < a.W);
+                if (ok) { s1 += v; s2 += v * v; }
+                sOut[(py * TW + px) * OPS + nf * 32 + r] = from_f32<T>(v);
+            }
+        }
+        if (a.stat) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (h == 0) {
+                sRed[(wave * 2 + 0) * BN + nf * 32 + r] = s1;
+                sRed[(wave * 2 + 1) * BN + nf * 32 + r] = s2;
+            }
+        }
+    }
+    __syncthreads();
+    if (a.stat && tid < 2 * BN) {
+        const int which = tid / BN, n = tid - which * BN;
+        const float s = sRed[(0 * 2 + which) * BN + n] + sRed[(1 * 2 + which) * BN + n] +
+                        sRed[(2 * 2 + which) * BN + n] + sRed[(3 * 2 + which) * BN + n];
+        a.stat[((size_t)blockIdx.x * 2 + which) * a.CoutP + n0 + n] = s;
+    }
+    constexpr int VPP = BN / VE;  // 16-byte vectors per pixel
+    for (int i = tid; i < TH * TW * VPP; i += 256) {
+        const int pix = i / VPP, vv = i - pix * VPP;
+        const int py = pix / TW, px = pix - py * TW;
+        const int gy = ty0 + py, gx = tx0 + px;
+        if (gy < a.H && gx < a.W) {
+            const vec16<T> v = *reinterpret_cast<const vec16<T>*>(sOut + pix * OPS + vv * VE);
+            *reinterpret_cast<vec16<T>*>(a.y + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldy + n0 + vv * VE) = v;
+        }
+    }
+}
+
+// ---- weight packing: PyTorch [Cout][Cin][3][3] f32 -> [9][RowsP][ColsP] T
+//   transpose == 0: rows = Cout, cols = packed Cin (perm applied), tap = kh*3+kw        (forward)
+//   transpose == 1: rows = packed Cin, cols = Cout, tap = (2-kh)*3+(2-kw)               (dgrad)
+struct PermArg { int p[128]; };
+template <typename T>
+__global__ void pack_w3x3_kernel(const float* __restrict__ w, T* __restrict__ wp, int Cout, int Cin, int CoutP,
+                                 int CinP, int transpose, PermArg perm, int has_perm) {
+    const int rowsP = transpose ? CinP : CoutP, colsP = transpose ? CoutP : CinP;
+    const size_t total = (size_t)9 * rowsP * colsP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % colsP);
+        const int row = (int)((i / colsP) % rowsP);
+        const int tap = (int)(i / ((size_t)colsP * rowsP));
+        const int co = transpose ? col : row;
+        const int cip = transpose ? row : col;  // packed input-channel index
+        int kh = tap / 3, kw = tap % 3;
+        if (transpose) { kh = 2 - kh; kw = 2 - kw; }
+        float v = 0.f;
+        if (co < Cout) {
+            // find the reference input channel stored at packed position cip
+            int ci = -1;
+            if (!has_perm) ci = cip < Cin ? cip : -1;
+            else {
+                for (int q = 0; q < Cin; ++q) if (perm.p[q] == cip) { ci = q; break; }
+            }
+            if (ci >= 0) v = w[(((size_t)co * Cin + ci) * 3 + kh) * 3 + kw];
+        }
+        wp[i] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+int launch_conv(const void* x, int ldx, const void* wp, const float* bias, int nbias, const float* in_scale,
+                const float* in_shift, void* y, int ldy, float* stat, int B, int H, int W, int Cin, int CoutP,
+                hipStream_t s) {
+    ConvArgs<T> a;
+    a.x = (const T*)x; a.ldx = ldx; a.wp = (const T*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale; a.in_shift = in_shift;
+    a.y = (T*)y; a.ldy = ldy; a.stat = stat; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.CoutP = CoutP;
+    a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH);
+    const bool xf = in_scale != nullptr;
+    const int BN = (CoutP % 64 == 0) ? 64 : 32;
+    dim3 grid((unsigned)(B * a.tilesX * a.tilesY), (unsigned)(CoutP / BN)), block(256);
+    if (BN == 64) {
+        if (xf) hipLaunchKernelGGL((conv3x3_kernel<T, 64, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_kernel<T, 64, false>), grid, block, 0, s, a);
+    } else {
+        if (xf) hipLaunchKernelGGL((conv3x3_kernel<T, 32, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_kernel<T, 32, false>), grid, block, 0, s, a);
+    }
+    return WM_OK;
+}
+
+}  // namespace
+
+extern "C" int wm_conv3x3_nparts(int B, int H, int W) { return B * wm_cdiv(H, TH) * wm_cdiv(W, TW); }
+
+extern "C" int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const float* bias, int nbias, const float* in_scale,
+                              const float* in_shift, void* y, int ldy, float* stat_partials, int B, int H, int W,
+                              int Cin, int CoutP, int dtype, void* stream) {
+    WM_REQUIRE(x && wp && y, WM_E_BADARG, "wm_conv3x3_fwd: null pointer");
+    WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && CoutP > 0, WM_E_BADARG, "wm_conv3x3_fwd: bad shape");
+    WM_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), WM_E_BADARG, "wm_conv3x3_fwd: in_scale/in_shift must come together");
+    WM_REQUIRE(dtype == WM_F32 || dtype == WM_BF16, WM_E_BADARG, "wm_conv3x3_fwd: unsupported dtype %d", dtype);
+    const int esz = dtype == WM_BF16 ? 2 : 4;
+    const int cmul = dtype == WM_BF16 ? 16 : 4;
+    WM_REQUIRE(Cin % cmul == 0, WM_E_SHAPE, "wm_conv3x3_fwd: Cin=%d must be a multiple of %d (pad the channels)", Cin, cmul);
+    WM_REQUIRE(CoutP % 32 == 0, WM_E_SHAPE, "wm_conv3x3_fwd: CoutP=%d must be a multiple of 32", CoutP);
+    WM_REQUIRE(ldx >= Cin && ldy >= CoutP && (ldx * esz) % 16 == 0 && (ldy * esz) % 16 == 0, WM_E_SHAPE,
+               "wm_conv3x3_fwd: pixel strides ldx=%d ldy=%d must cover the channels and be 16-byte multiples", ldx, ldy);
+    WM_REQUIRE((((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y) & 15) == 0, WM_E_SHAPE, "wm_conv3x3_fwd: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == WM_BF16) launch_conv<bf16_t>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s);
+    else launch_conv<float>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s);
+    WM_LAUNCH_CHECK("wm_conv3x3_fwd");
+    return WM_OK;
+}
+
+extern "C" int wm_pack_w3x3(const float* w, void* wp, int Cout, int Cin, int CoutP, int CinP, const int* perm,
+                            int transpose, int dtype, void* stream) {
+    WM_REQUIRE(w && wp, WM_E_BADARG, "wm_pack_w3x3: null pointer");
+    WM_REQUIRE(Cout > 0 && Cin > 0 && CoutP >= Cout && (perm || CinP >= Cin), WM_E_BADARG, "wm_pack_w3x3: bad shape");
+    WM_REQUIRE(!perm || Cin <= 128, WM_E_SHAPE, "wm_pack_w3x3: channel permutation supports Cin <= 128");
+    PermArg pa;
+    for (int i = 0; i < 128; ++i) pa.p[i] = -1;
+    if (perm)
+        for (int i = 0; i < Cin; ++i) {
+            // a packed position >= CinP means "this input channel is dropped" (dgrad of a channel slice)
+            WM_REQUIRE(perm[i] >= 0, WM_E_BADARG, "wm_pack_w3x3: perm[%d]=%d out of range", i, perm[i]);
+            pa.p[i] = perm[i];
+        }
+    const size_t total = (size_t)9 * CoutP * CinP;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == WM_BF16)
+        hipLaunchKernelGGL(pack_w3x3_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, (bf16_t*)wp, Cout, Cin, CoutP, CinP, transpose, pa, perm ? 1 : 0);
+    else if (dtype == WM_F32)
+        hipLaunchKernelGGL(pack_w3x3_kernel<float>, dim3(blocks), dim3(256), 0, s, w, (float*)wp, Cout, Cin, CoutP, CinP, transpose, pa, perm ? 1 : 0);
+    else { wm_set_error("wm_pack_w3x3: unsupported dtype %d", dtype); return WM_E_BADARG; }
+    WM_LAUNCH_CHECK("wm_pack_w3x3");
+    return WM_OK;
+}

@@ -1,0 +1,171 @@
+// 1x1 convolution heads on the fused relu(scale*y+shift) of the last ConvBNRelu block:
+//   hidden_models/encoder.py:28,42  final_layer = nn.Conv2d(64, 3, kernel_size=1)  -> encoded image (NCHW f32)
+//   network/UNet.py:41-43,65        conv = nn.Conv2d(32, 1, 1) + sigmoid           -> tamper mask   (NCHW f32)
+// Cout <= 4, so this is a bandwidth-bound reduction, not a GEMM: VPP = Cin/VE lanes share one pixel,
+// each lane loads one 16-byte channel vector (a wave reads 64/VPP whole pixels, fully contiguous),
+// forms its partial dot products and the lanes of a pixel combine with wave shuffles.
+#include "wm_common.h"
+
+namespace {
+
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out, size_t npix,
+                                                       size_t hw, int Cin, int act) {
+    constexpr int VE = vec16<T>::N;
+    const int VPP = Cin / VE, PPB = 256 / VPP;
+    const int vv = threadIdx.x % VPP, ps = threadIdx.x / VPP;
+    const int c0 = vv * VE;
+    float sc[VE], sh[VE], wr[COUT][VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        sc[e] = scale ? scale[c0 + e] : 1.f;
+        sh[e] = scale ? shift[c0 + e] : 0.f;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) wr[co][e] = w[co * Cin + c0 + e];
+    }
+    for (size_t base = (size_t)blockIdx.x * PPB; base < npix; base += (size_t)gridDim.x * PPB) {
+        const size_t p = base + ps;
+        const bool valid = p < npix;
+        float part[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) part[co] = 0.f;
+        if (valid) {
+            const vec16<T> yv = *reinterpret_cast<const vec16<T>*>(y + p * ldy + c0);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                float a = sc[e] * yv.get(e) + sh[e];
+                if (scale) a = fmaxf(a, 0.f);
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) part[co] += wr[co][e] * a;
+            }
+        }
+        for (int o = VPP >> 1; o > 0; o >>= 1) {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) part[co] += __shfl_xor(part[co], o, 64);
+        }
+        if (valid && vv < COUT) {
+            float v = 0.f;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) v = (vv == co) ? part[co] + bias[co] : v;
+            if (act == 1) v = 1.f / (1.f + __expf(-v));
+            const size_t b = p / hw, q = p - b * hw;
+            out[(b * COUT + vv) * hw + q] = v;
+        }
+    }
+}
+
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ w,
+                                                       const float* __restrict__ gout, T* __restrict__ g, int ldg,
+                                                       float* __restrict__ partials, size_t npix, size_t hw, int Cin) {
+    constexpr int VE = vec16<T>::N;
+    const int VPP = Cin / VE, PPB = 256 / VPP;
+    const int vv = threadIdx.x % VPP, ps = threadIdx.x / VPP;
+    const int c0 = vv * VE;
+    float sc[VE], sh[VE], wr[COUT][VE], dw[COUT][VE], db[COUT];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        sc[e] = scale ? scale[c0 + e] : 1.f;
+        sh[e] = scale ? shift[c0 + e] : 0.f;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) { wr[co][e] = w[co * Cin + c0 + e]; dw[co][e] = 0.f; }
+    }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) db[co] = 0.f;
+    for (size_t p = (size_t)blockIdx.x * PPB + ps; p < npix; p += (size_t)gridDim.x * PPB) {
+        const size_t b = p / hw, q = p - b * hw;
+        float go[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) go[co] = gout[(b * COUT + co) * hw + q];
+        const vec16<T> yv = *reinterpret_cast<const vec16<T>*>(y + p * ldy + c0);
+        vec16<T> gv;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            float a = sc[e] * yv.get(e) + sh[e];
+            if (scale) a = fmaxf(a, 0.f);
+            float gg = 0.f;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) { gg += go[co] * wr[co][e]; dw[co][e] += go[co] * a; }
+            gv.set(e, gg);
+        }
+        if (vv == 0) {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) db[co] += go[co];
+        }
+        *reinterpret_cast<vec16<T>*>(g + p * ldg + c0) = gv;
+    }
+    __shared__ float red[256][COUT * vec16<T>::N + COUT + 1];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) red[threadIdx.x][co * VE + e] = dw[co][e];
+        red[threadIdx.x][COUT * VE + co] = db[co];
+    }
+    __syncthreads();
+    float* prow = partials + (size_t)blockIdx.x * COUT * (Cin + 1);
+    for (int i = threadIdx.x; i < COUT * Cin; i += 256) {
+        const int co = i / Cin, c = i - co * Cin;
+        const int v2 = c / VE, e = c - v2 * VE;
+        float s = 0.f;
+        for (int qq = 0; qq < PPB; ++qq) s += red[qq * VPP + v2][co * VE + e];
+        prow[i] = s;
+    }
+    if (threadIdx.x < COUT) {
+        float s = 0.f;
+        for (int qq = 0; qq < PPB; ++qq) s += red[qq * VPP][COUT * VE + threadIdx.x];
+        prow[COUT * Cin + threadIdx.x] = s;
+    }
+}
+
+bool cin_ok(int Cin, int dtype) {
+    const int ve = dtype == WM_BF16 ? 8 : 4;
+    if (Cin <= 0 || Cin % ve) return false;
+    const int vpp = Cin / ve;
+    return vpp <= 64 && (vpp & (vpp - 1)) == 0;
+}
+
+inline int head_parts(size_t npix) {
+    const size_t n = (npix + 511) / 512;
+    return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
+}
+
+}  // namespace
+
+extern "C" int wm_conv1x1_head_fwd(const void* y, int ldy, const float* scale, const float* shift, const float* w,
+                                   const float* bias, float* out, int B, size_t hw, int Cin, int Cout, int act, int dtype,
+                                   void* stream) {
+    WM_REQUIRE(y && w && bias && out, WM_E_BADARG, "wm_conv1x1_head_fwd: null pointer");
+    WM_REQUIRE((scale == nullptr) == (shift == nullptr), WM_E_BADARG, "wm_conv1x1_head_fwd: scale/shift must come together");
+    WM_REQUIRE(cin_ok(Cin, dtype), WM_E_SHAPE, "wm_conv1x1_head_fwd: unsupported Cin=%d", Cin);
+    WM_REQUIRE(Cout == 1 || Cout == 3, WM_E_SHAPE, "wm_conv1x1_head_fwd: Cout must be 1 or 3 (got %d)", Cout);
+    const size_t npix = (size_t)B * hw;
+    const int grid = (int)((npix + 31) / 32 > 4096 ? 4096 : (npix + 31) / 32);
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_conv1x1_head_fwd",
+        if (Cout == 3) hipLaunchKernelGGL((head_fwd_kernel<T, 3>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, scale, shift, w, bias, out, npix, hw, Cin, act);
+        else hipLaunchKernelGGL((head_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, scale, shift, w, bias, out, npix, hw, Cin, act));
+    WM_LAUNCH_CHECK("wm_conv1x1_head_fwd");
+    return WM_OK;
+}
+
+extern "C" int wm_conv1x1_head_nparts(size_t npix) { return head_parts(npix); }
+
+extern "C" int wm_conv1x1_head_bwd(const void* y, int ldy, const float* scale, const float* shift, const float* w,
+                                   const float* gout, void* g, int ldg, float* partials, int B, size_t hw, int Cin,
+                                   int Cout, int dtype, void* stream) {
+    WM_REQUIRE(y && w && gout && g && partials, WM_E_BADARG, "wm_conv1x1_head_bwd: null pointer");
+    WM_REQUIRE((scale == nullptr) == (shift == nullptr), WM_E_BADARG, "wm_conv1x1_head_bwd: scale/shift must come together");
+    WM_REQUIRE(cin_ok(Cin, dtype), WM_E_SHAPE, "wm_conv1x1_head_bwd: unsupported Cin=%d", Cin);
+    WM_REQUIRE(Cout == 1 || Cout == 3, WM_E_SHAPE, "wm_conv1x1_head_bwd: Cout must be 1 or 3 (got %d)", Cout);
+    const size_t npix = (size_t)B * hw;
+    const int grid = head_parts(npix);
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_conv1x1_head_bwd",
+        if (Cout == 3) hipLaunchKernelGGL((head_bwd_kernel<T, 3>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, scale, shift, w, gout, (T*)g, ldg, partials, npix, hw, Cin);
+        else hipLaunchKernelGGL((head_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, scale, shift, w, gout, (T*)g, ldg, partials, npix, hw, Cin));
+    WM_LAUNCH_CHECK("wm_conv1x1_head_bwd");
+    return WM_OK;
+}

@@ -1,0 +1,110 @@
+// Layout conversions between the reference's NCHW f32 image planes (attack / loss boundary) and the
+// NHWC bf16|f32 activation layout of the conv path; message broadcast (hidden_models/encoder.py:34-37).
+// Pure data movement, HBM-bound: a thread owns one pixel, plane reads are coalesced across the wave,
+// NHWC writes are 16-byte vectors when the destination slice is aligned.
+#include "wm_common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C,
+                                                           size_t hw, int ld, int c0, int zero_tail) {
+    const size_t total = (size_t)B * hw;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = p / hw, q = p - b * hw;
+        T* o = y + p * ld + c0;
+        for (int c = 0; c < C; ++c) o[c] = from_f32<T>(x[(b * C + c) * hw + q]);
+        for (int c = C; c < C + zero_tail; ++c) o[c] = from_f32<T>(0.f);
+    }
+}
+
+// specialisation used for image inputs: C = 3 -> 16-channel zero padded pixel (32 B bf16 / 64 B f32), c0 = 0
+template <typename T>
+__global__ __launch_bounds__(256) void nchw3_to_nhwc16_kernel(const float* __restrict__ x, T* __restrict__ y, int B,
+                                                              size_t hw, int ld) {
+    constexpr int VE = vec16<T>::N;
+    const size_t total = (size_t)B * hw;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = p / hw, q = p - b * hw;
+        vec16<T> v;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v.set(e, 0.f);
+        vec16<T> z = v;
+        v.set(0, x[(b * 3 + 0) * hw + q]);
+        v.set(1, x[(b * 3 + 1) * hw + q]);
+        v.set(2, x[(b * 3 + 2) * hw + q]);
+        vec16<T>* o = reinterpret_cast<vec16<T>*>(y + p * ld);
+        o[0] = v;
+#pragma unroll
+        for (int k = 1; k < 16 / VE; ++k) o[k] = z;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int C,
+                                                           size_t hw, int ld, int c0) {
+    const size_t total = (size_t)B * hw;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = p / hw, q = p - b * hw;
+        const T* i = x + p * ld + c0;
+        for (int c = 0; c < C; ++c) y[(b * C + c) * hw + q] = to_f32(i[c]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void broadcast_kernel(const float* __restrict__ v, T* __restrict__ y, int B, int L,
+                                                        size_t hw, int ld, int c0) {
+    const size_t total = (size_t)B * hw;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = p / hw;
+        T* o = y + p * ld + c0;
+        for (int c = 0; c < L; ++c) o[c] = from_f32<T>(v[b * L + c]);
+    }
+}
+
+inline int grid_for(size_t n) {
+    const size_t g = (n + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int wm_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int ld, int c0, int zero_tail,
+                               int dtype, void* stream) {
+    WM_REQUIRE(x && y, WM_E_BADARG, "wm_nchw_to_nhwc: null pointer");
+    WM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && c0 >= 0 && zero_tail >= 0 && ld >= c0 + C + zero_tail, WM_E_BADARG,
+               "wm_nchw_to_nhwc: bad shape (ld=%d c0=%d C=%d tail=%d)", ld, c0, C, zero_tail);
+    const size_t hw = (size_t)H * W;
+    hipStream_t s = (hipStream_t)stream;
+    const int esz = dtype == WM_BF16 ? 2 : 4;
+    const bool fast = C == 3 && c0 == 0 && zero_tail == 13 && (ld * esz) % 16 == 0 && ((uintptr_t)y & 15) == 0;
+    WM_DISPATCH_DTYPE(dtype, "wm_nchw_to_nhwc",
+        if (fast) hipLaunchKernelGGL((nchw3_to_nhwc16_kernel<T>), dim3(grid_for(B * hw)), dim3(256), 0, s, x, (T*)y, B, hw, ld);
+        else hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(B * hw)), dim3(256), 0, s, x, (T*)y, B, C, hw, ld, c0, zero_tail));
+    WM_LAUNCH_CHECK("wm_nchw_to_nhwc");
+    return WM_OK;
+}
+
+extern "C" int wm_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int ld, int c0, int dtype,
+                               void* stream) {
+    WM_REQUIRE(x && y, WM_E_BADARG, "wm_nhwc_to_nchw: null pointer");
+    WM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && c0 >= 0 && ld >= c0 + C, WM_E_BADARG, "wm_nhwc_to_nchw: bad shape");
+    const size_t hw = (size_t)H * W;
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_nhwc_to_nchw",
+        hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid_for(B * hw)), dim3(256), 0, s, (const T*)x, y, B, C, hw, ld, c0));
+    WM_LAUNCH_CHECK("wm_nhwc_to_nchw");
+    return WM_OK;
+}
+
+extern "C" int wm_broadcast_to_nhwc(const float* v, void* y, int B, int L, int H, int W, int ld, int c0, int dtype,
+                                    void* stream) {
+    WM_REQUIRE(v && y, WM_E_BADARG, "wm_broadcast_to_nhwc: null pointer");
+    WM_REQUIRE(B > 0 && L > 0 && H > 0 && W > 0 && c0 >= 0 && ld >= c0 + L, WM_E_BADARG, "wm_broadcast_to_nhwc: bad shape");
+    const size_t hw = (size_t)H * W;
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_broadcast_to_nhwc",
+        hipLaunchKernelGGL((broadcast_kernel<T>), dim3(grid_for(B * hw)), dim3(256), 0, s, v, (T*)y, B, L, hw, ld, c0));
+    WM_LAUNCH_CHECK("wm_broadcast_to_nhwc");
+    return WM_OK;
+}

@@ -1,0 +1,106 @@
+// Loss / optimiser streaming kernels (f32, flat buffers):
+//   nn.MSELoss forward+backward           hidden_models/hidden.py:37,90,97
+//   torch.optim.Adam / AdamW step         hidden_models/hidden.py:24-25, models/IRNrhi_model.py:270-272
+//   sum of squares (clip_grad_norm_)      models/IRNrhi_model.py:459-460
+// All parameters of a network live in ONE flat f32 buffer (grads, exp_avg, exp_avg_sq likewise), so an
+// optimiser step is one launch and the gradient all-reduce is one RCCL bucket.
+#include "wm_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ grad_a, float gscale, float* __restrict__ partials,
+                                                  size_t n) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i];
+        acc += d * d;
+        if (grad_a) grad_a[i] = gscale * d;
+    }
+    acc = wave_sum(acc);
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, float* __restrict__ partials, size_t n) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += x[i] * x[i];
+    acc = wave_sum(acc);
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ a, const float* __restrict__ b, float s, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] += s * b[i];
+}
+
+// torch.optim.Adam (single-tensor, non-amsgrad, non-capturable) arithmetic:
+//   g += wd*p (coupled)  |  p *= 1 - lr*wd (decoupled)
+//   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
+//   denom = sqrt(v)/sqrt(1-b2^t) + eps ; p -= (lr/(1-b1^t)) * m/denom
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                   float wd, int decoupled, float step_size, float bc2_sqrt,
+                                                   float grad_scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float gg = g[i] * grad_scale;
+        float pp = p[i];
+        if (wd != 0.f) {
+            if (decoupled) pp *= 1.f - lr * wd;
+            else gg += wd * pp;
+        }
+        const float mm = b1 * m[i] + (1.f - b1) * gg;
+        const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+        m[i] = mm;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[i] = pp - step_size * (mm / denom);
+    }
+}
+
+inline int grid_for(size_t n, int cap = 2048) {
+    const size_t g = (n + 255) / 256;
+    return (int)(g > (size_t)cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int wm_mse_fwd_bwd(const float* a, const float* b, float* grad_a, float gscale, float* loss_partials,
+                              int nparts, size_t n, void* stream) {
+    WM_REQUIRE(a && b && n > 0, WM_E_BADARG, "wm_mse_fwd_bwd: bad arguments");
+    WM_REQUIRE(nparts > 0 && nparts <= 2048, WM_E_BADARG, "wm_mse_fwd_bwd: nparts must be in 1..2048");
+    hipLaunchKernelGGL(mse_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, a, b, grad_a, gscale, loss_partials, n);
+    WM_LAUNCH_CHECK("wm_mse_fwd_bwd");
+    return WM_OK;
+}
+
+extern "C" int wm_sumsq(const float* x, size_t n, float* partials, int nparts, void* stream) {
+    WM_REQUIRE(x && partials && n > 0 && nparts > 0 && nparts <= 2048, WM_E_BADARG, "wm_sumsq: bad arguments");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, partials, n);
+    WM_LAUNCH_CHECK("wm_sumsq");
+    return WM_OK;
+}
+
+extern "C" int wm_axpy(float* a, const float* b, float s, size_t n, void* stream) {
+    WM_REQUIRE(a && b && n > 0, WM_E_BADARG, "wm_axpy: bad arguments");
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, s, n);
+    WM_LAUNCH_CHECK("wm_axpy");
+    return WM_OK;
+}
+
+extern "C" int wm_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int decoupled, int step, float grad_scale, void* stream) {
+    WM_REQUIRE(p && g && m && v && n > 0 && step >= 1, WM_E_BADARG, "wm_adam_step: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, decoupled, step_size, bc2_sqrt, grad_scale);
+    WM_LAUNCH_CHECK("wm_adam_step");
+    return WM_OK;
+}

@@ -1,0 +1,242 @@
+// Weight gradient of the 3x3 / stride 1 / pad 1 convolution on MFMA (gfx950).
+//
+//   dW[co][ci][kh][kw] = sum_{b,h,w} a[b, h+kh-1, w+kw-1, ci] * dy[b, h, w, co]
+//
+// (what autograd computes for nn.Conv2d in hidden_models/conv_bn_relu.py:11 and
+// network/UNet.py:67-97), with a = x or the fused relu(in_scale*x+in_shift) of the producer.
+//
+// GEMM view per tap: M = Cin, N = Cout, K = B*H*W pixels -- the reduction runs over pixels, the
+// slow index of both NHWC operands, so both MFMA operands need an [k = pixel][row/col = channel]
+// -> k-contiguous transpose.  On gfx950 that is free: ds_read_b64_tr_b16 reads a 4 pixel x 16
+// channel LDS block and hands each lane 4 consecutive pixels of one channel, which is exactly
+// the v_mfma_f32_32x32x16_bf16 operand layout (two reads per 8-deep fragment).
+//
+//   workgroup  = 256 threads, loops over 16x16-pixel tiles (grid-stride), one (64 ci x 64 co)
+//                channel block per blockIdx.y; stages the 18x18x64 input halo tile and the
+//                16x16x64 dy tile in LDS per tile
+//   wave (mi,ni) owns the 32 ci x 32 co block for all 9 taps: 9 accumulators (144 VGPRs) that
+//                live across the whole tile loop; per K step (16 pixels of a tile row) it reads
+//                the dy fragment once and 9 shifted x fragments
+//   epilogue   = f32 slab [9][CinP][CoutP] per workgroup; a second kernel sums the slabs in a
+//                fixed order (deterministic, no float atomics) into the PyTorch-layout gradient.
+//   f32 path   : v_mfma_f32_32x32x2_f32 on 8x16 tiles (parity path; plain ds_read_b32 operands).
+#include "wm_common.h"
+
+namespace {
+
+constexpr int TW = 16;
+constexpr int HW_ = TW + 2;
+constexpr int CB = 64;  // channel block (both ci and co)
+
+template <typename T> struct WCfg;
+template <> struct WCfg<bf16_t> { static constexpr int TH = 16, VE = 8, PS = 72; };   // 144-byte pixel rows
+template <> struct WCfg<float>  { static constexpr int TH = 8,  VE = 4, PS = 68; };   // 272-byte pixel rows
+
+template <typename T>
+struct WgArgs {
+    const T* x; int ldx; int CinX;
+    const float* in_scale; const float* in_shift;
+    const T* dy; int lddy; int CoutY;
+    float* ws;           // [gridDim.x][9][CinP][CoutP]
+    int B, H, W;
+    int tilesX, tilesY, ntiles;
+    int ciBlocks, coBlocks;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* p0, const bf16_t* p1) {
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p0));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p1));
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <typename T, bool XFORM>
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(WgArgs<T> a) {
+    constexpr int TH = WCfg<T>::TH, VE = WCfg<T>::VE, PS = WCfg<T>::PS;
+    constexpr int HH = TH + 2;
+    constexpr int VPP = CB / VE;
+    constexpr int X_ELEMS = HH * HW_ * PS;
+    constexpr int D_ELEMS = TH * TW * PS;
+    __shared__ __attribute__((aligned(16))) T smem[X_ELEMS + D_ELEMS];
+    T* sX = smem;
+    T* sD = smem + X_ELEMS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mi = wave >> 1, ni = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int cc = blockIdx.y / a.coBlocks, oc = blockIdx.y % a.coBlocks;
+    const int ci0 = cc * CB, co0 = oc * CB;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int vv = tid % VPP;
+    const int cx = ci0 + vv * VE;      // this thread's x channel group (fixed: 256 % VPP == 0)
+    const int cd = co0 + vv * VE;
+    const bool cxok = cx < a.CinX, cdok = cd < a.CoutY;
+    float sc[VE], sh[VE];
+    if (XFORM && cxok) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { sc[e] = a.in_scale[cx + e]; sh[e] = a.in_shift[cx + e]; }
+    }
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int txi = t % a.tilesX; t /= a.tilesX;
+        const int tyi = t % a.tilesY; t /= a.tilesY;
+        const int b = t;
+        const int ty0 = tyi * TH, tx0 = txi * TW;
+        __syncthreads();  // previous tile consumed
+        for (int i = tid; i < HH * HW_ * VPP; i += 256) {
+            const int pix = i / VPP;
+            const int py = pix / HW_, px = pix - py * HW_;
+            const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+            vec16<T> v;
+            if (cxok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                v = *reinterpret_cast<const vec16<T>*>(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldx + cx);
+                if (XFORM) {
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) v.set(e, fmaxf(sc[e] * v.get(e) + sh[e], 0.f));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VE; ++e) v.set(e, 0.f);
+            }
+            *reinterpret_cast<vec16<T>*>(sX + pix * PS + vv * VE) = v;
+        }
+        for (int i = tid; i < TH * TW * VPP; i += 256) {
+            const int pix = i / VPP;
+            const int py = pix / TW, px = pix - py * TW;
+            const int gy = ty0 + py, gx = tx0 + px;
+            vec16<T> v;
+            if (cdok && gy < a.H && gx < a.W)
+                v = *reinterpret_cast<const vec16<T>*>(a.dy + ((size_t)(b * a.H + gy) * a.W + gx) * a.lddy + cd);
+            else {
+#pragma unroll
+                for (int e = 0; e < VE; ++e) v.set(e, 0.f);
+            }
+            *reinterpret_cast<vec16<T>*>(sD + pix * PS + vv * VE) = v;
+        }
+        __syncthreads();
+
+        if constexpr (sizeof(T) == 2) {
+            // transposing-read lane geometry: 16-lane group g = lane>>4; lane i = 4q+p of the group
+            const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+            const int chan = 16 * (g & 1) + 4 * p;  // channel offset inside the 32-channel block
+            const int pk = 8 * (g >> 1) + q;        // pixel offset inside the 16-pixel K step (+4 for the 2nd read)
+            for (int kr = 0; kr < TH; ++kr) {
+                const bf16_t* pd = sD + (kr * TW + pk) * PS + ni * 32 + chan;
+                const bf16x8 bfrag = tr_frag(pd, pd + 4 * PS);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int kh = tap / 3, kw = tap % 3;
+                    const bf16_t* px_ = sX + ((kr + kh) * HW_ + pk + kw) * PS + mi * 32 + chan;
+                    const bf16x8 afrag = tr_frag(px_, px_ + 4 * PS);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[tap], 0, 0, 0);
+                }
+            }
+        } else {
+            for (int kr = 0; kr < TH; ++kr) {
+                for (int kp = 0; kp < TW / 2; ++kp) {
+                    const int px = 2 * kp + h;
+                    const float bfrag = sD[(kr * TW + px) * PS + ni * 32 + r];
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int kh = tap / 3, kw = tap % 3;
+                        const float afrag = sX[((kr + kh) * HW_ + px + kw) * PS + mi * 32 + r];
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag, acc[tap], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // slab write: acc[tap][i] -> row (ci) = (i&3)+8*(i>>2)+4h, col (co) = r
+    const int CinP = a.ciBlocks * CB, CoutP = a.coBlocks * CB;
+    float* slab = a.ws + (size_t)blockIdx.x * 9 * CinP * CoutP;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            slab[((size_t)tap * CinP + ci0 + mi * 32 + row) * CoutP + co0 + ni * 32 + r] = acc[tap][i];
+        }
+}
+
+// dw[co][ci][kh][kw] (+)= sum_slab ws[slab][tap][perm(ci)][co]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nslabs, int CinP, int CoutP,
+                                                           float* __restrict__ dw, int Cin, int Cout,
+                                                           const int* __restrict__ perm, int accumulate) {
+    const size_t slab_elems = (size_t)9 * CinP * CoutP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slab_elems; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % CoutP);
+        const int cip = (int)((i / CoutP) % CinP);
+        const int tap = (int)(i / ((size_t)CoutP * CinP));
+        if (co >= Cout) continue;
+        int ci = -1;
+        if (!perm) ci = cip < Cin ? cip : -1;
+        else
+            for (int qq = 0; qq < Cin; ++qq)
+                if (perm[qq] == cip) { ci = qq; break; }
+        if (ci < 0) continue;
+        double s = 0.0;
+        for (int k = 0; k < nslabs; ++k) s += (double)ws[(size_t)k * slab_elems + i];
+        float* o = dw + (((size_t)co * Cin + ci) * 9 + tap);
+        *o = (accumulate ? *o : 0.f) + (float)s;
+    }
+}
+
+inline int nslabs_for(int B, int H, int W) {
+    const long n = (long)B * wm_cdiv(H, 16) * wm_cdiv(W, 16);
+    return (int)(n < 256 ? n : 256);
+}
+
+template <typename T>
+void launch_wgrad(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy, int lddy,
+                  int CoutY, float* ws, int B, int H, int W, hipStream_t s) {
+    WgArgs<T> a;
+    a.x = (const T*)x; a.ldx = ldx; a.CinX = CinX; a.in_scale = in_scale; a.in_shift = in_shift;
+    a.dy = (const T*)dy; a.lddy = lddy; a.CoutY = CoutY; a.ws = ws; a.B = B; a.H = H; a.W = W;
+    a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, WCfg<T>::TH); a.ntiles = B * a.tilesX * a.tilesY;
+    a.ciBlocks = wm_cdiv(CinX, CB); a.coBlocks = wm_cdiv(CoutY, CB);
+    dim3 grid((unsigned)nslabs_for(B, H, W), (unsigned)(a.ciBlocks * a.coBlocks)), block(256);
+    if (in_scale) hipLaunchKernelGGL((wgrad_kernel<T, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wgrad_kernel<T, false>), grid, block, 0, s, a);
+}
+
+}  // namespace
+
+extern "C" int wm_conv3x3_wgrad_nslabs(int B, int H, int W) { return nslabs_for(B, H, W); }
+
+extern "C" size_t wm_conv3x3_wgrad_ws_bytes(int B, int H, int W, int CinX, int CoutY) {
+    return (size_t)nslabs_for(B, H, W) * 9 * (wm_cdiv(CinX, CB) * CB) * (wm_cdiv(CoutY, CB) * CB) * sizeof(float);
+}
+
+extern "C" int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift,
+                                const void* dy, int lddy, int CoutY, float* ws, float* dw, int accumulate, int B, int H,
+                                int W, int Cin, int Cout, const int* perm_dev, int dtype, void* stream) {
+    WM_REQUIRE(x && dy && ws && dw, WM_E_BADARG, "wm_conv3x3_wgrad: null pointer");
+    WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && CinX > 0 && CoutY >= Cout, WM_E_BADARG, "wm_conv3x3_wgrad: bad shape");
+    WM_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), WM_E_BADARG, "wm_conv3x3_wgrad: in_scale/in_shift must come together");
+    WM_REQUIRE(dtype == WM_F32 || dtype == WM_BF16, WM_E_BADARG, "wm_conv3x3_wgrad: unsupported dtype %d", dtype);
+    const int ve = dtype == WM_BF16 ? 8 : 4, esz = dtype == WM_BF16 ? 2 : 4;
+    WM_REQUIRE(CinX % ve == 0 && CoutY % ve == 0, WM_E_SHAPE, "wm_conv3x3_wgrad: channel counts %d/%d must be multiples of %d", CinX, CoutY, ve);
+    WM_REQUIRE(ldx >= CinX && lddy >= CoutY && (ldx * esz) % 16 == 0 && (lddy * esz) % 16 == 0, WM_E_SHAPE,
+               "wm_conv3x3_wgrad: bad pixel strides ldx=%d lddy=%d", ldx, lddy);
+    WM_REQUIRE(perm_dev || CinX >= Cin, WM_E_BADARG, "wm_conv3x3_wgrad: x has fewer channels than the weight");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == WM_BF16) launch_wgrad<bf16_t>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
+    else launch_wgrad<float>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
+    WM_LAUNCH_CHECK("wm_conv3x3_wgrad");
+    const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
+    const size_t slab_elems = (size_t)9 * CinP * CoutP;
+    const int blocks = (int)((slab_elems + 255) / 256 > 2048 ? 2048 : (slab_elems + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout,
+                       perm_dev, accumulate);
+    WM_LAUNCH_CHECK("wm_conv3x3_wgrad(reduce)");
+    return WM_OK;
+}

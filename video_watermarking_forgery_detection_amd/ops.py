@@ -69,3 +69,218 @@ def jpeg_bwd(x, gy, mode, tables, subsample=0):
     rc = _lib.lib().wm_jpeg_bwd(_p(xx), _p(gy), _p(gx), c_int(B), c_int(H), c_int(W), c_int(mode), tb, c_int(subsample), _stream())
     _lib.check(rc, "wm_jpeg_bwd")
     return gx
+
+
+# ----------------------------------------------------------------------------- layout
+def _host_ints(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def nchw_to_nhwc(x, out, C_off=0, zero_tail=0):
+    """x [B,C,H,W] f32 -> out[B,H,W,ld] (bf16|f32) channels [C_off, C_off+C), zero tail after."""
+    _need_cuda(x, out)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    rc = _lib.lib().wm_nchw_to_nhwc(_p(x), _p(out), c_int(B), c_int(C), c_int(H), c_int(W), c_int(out.shape[-1]),
+                                    c_int(C_off), c_int(zero_tail), c_int(dtype_id(out)), _stream())
+    _lib.check(rc, "wm_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, C, C_off=0):
+    _need_cuda(x)
+    B, H, W, ld = x.shape
+    y = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().wm_nhwc_to_nchw(_p(x), _p(y), c_int(B), c_int(C), c_int(H), c_int(W), c_int(ld), c_int(C_off),
+                                    c_int(dtype_id(x)), _stream())
+    _lib.check(rc, "wm_nhwc_to_nchw")
+    return y
+
+
+def broadcast_to_nhwc(v, out, C_off):
+    _need_cuda(v, out)
+    v = v.contiguous().float()
+    B, H, W, ld = out.shape
+    rc = _lib.lib().wm_broadcast_to_nhwc(_p(v), _p(out), c_int(B), c_int(v.shape[1]), c_int(H), c_int(W), c_int(ld),
+                                         c_int(C_off), c_int(dtype_id(out)), _stream())
+    _lib.check(rc, "wm_broadcast_to_nhwc")
+    return out
+
+
+def bnrelu_copy(x, scale, shift, out, C_off, C):
+    B, H, W, ldx = x.shape
+    rc = _lib.lib().wm_bnrelu_copy(_p(x), c_int(ldx), _p(scale), _p(shift), _p(out), c_int(out.shape[-1]), c_int(C_off),
+                                   c_size_t(B * H * W), c_int(C), c_int(dtype_id(x)), _stream())
+    _lib.check(rc, "wm_bnrelu_copy")
+    return out
+
+
+def pack_w3x3(w, CoutP, CinP, dtype, perm=None, transpose=False):
+    """w [Cout,Cin,3,3] f32 -> [9,CoutP,CinP] (or [9,CinP,CoutP] transposed/flipped for dgrad)."""
+    _need_cuda(w)
+    Cout, Cin = w.shape[0], w.shape[1]
+    shape = (9, CinP, CoutP) if transpose else (9, CoutP, CinP)
+    wp = torch.empty(shape, device=w.device, dtype=dtype)
+    pa = _host_ints(perm) if perm is not None else None
+    rc = _lib.lib().wm_pack_w3x3(_p(w), _p(wp), c_int(Cout), c_int(Cin), c_int(CoutP), c_int(CinP), pa,
+                                 c_int(1 if transpose else 0), c_int(dtype_id(wp)), _stream())
+    _lib.check(rc, "wm_pack_w3x3")
+    return wp
+
+
+# ----------------------------------------------------------------------------- conv / bn
+def conv3x3_nparts(B, H, W):
+    return _lib.lib().wm_conv3x3_nparts(c_int(B), c_int(H), c_int(W))
+
+
+def conv3x3_fwd(x, wp, bias, in_scale, in_shift, want_stats, Cin=None):
+    """x [B,H,W,ld]; wp [9,CoutP,Cin]; returns y [B,H,W,CoutP] and stat partials (or None)."""
+    _need_cuda(x, wp)
+    B, H, W, ldx = x.shape
+    CoutP, CinW = wp.shape[1], wp.shape[2]
+    Cin = CinW if Cin is None else Cin
+    assert Cin == CinW and Cin <= ldx
+    y = torch.empty(B, H, W, CoutP, device=x.device, dtype=x.dtype)
+    st = torch.empty(conv3x3_nparts(B, H, W), 2, CoutP, device=x.device, dtype=torch.float32) if want_stats else None
+    rc = _lib.lib().wm_conv3x3_fwd(_p(x), c_int(ldx), _p(wp), _p(bias), c_int(0 if bias is None else bias.numel()),
+                                   _p(in_scale), _p(in_shift), _p(y), c_int(CoutP), _p(st), c_int(B), c_int(H), c_int(W),
+                                   c_int(Cin), c_int(CoutP), c_int(dtype_id(x)), _stream())
+    _lib.check(rc, "wm_conv3x3_fwd")
+    return y, st
+
+
+def bn_finalize(partials, C, CP, count, gamma, beta, running_mean, running_var, momentum, eps):
+    dev = partials.device
+    out = torch.empty(4, CP, device=dev, dtype=torch.float32)  # scale, shift, mean, invstd
+    rc = _lib.lib().wm_bn_finalize(_p(partials), c_int(partials.shape[0]), c_int(C), c_int(CP), c_double(count), _p(gamma),
+                                   _p(beta), _p(running_mean), _p(running_var), c_float(momentum), c_float(eps),
+                                   _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _stream())
+    _lib.check(rc, "wm_bn_finalize")
+    return out
+
+
+def bn_bwd(g, gvec, y, stats, C, gamma, dgamma, dbeta, accumulate, dbias):
+    """ReLU+BN backward.  g [B,H,W,ld] or None with gvec [B,CP]; y raw conv output [B,H,W,CP];
+    stats = [4,CP] (scale, shift, mean, invstd).  Returns dy [B,H,W,CP]; writes dgamma/dbeta/dbias."""
+    B, H, W, CP = y.shape
+    hw = H * W
+    L = _lib.lib()
+    nparts = L.wm_bn_bwd_nparts(c_size_t(B * hw))
+    dev = y.device
+    part = torch.empty(nparts, 2, CP, device=dev, dtype=torch.float32)
+    did = c_int(dtype_id(y))
+    ldg = c_int(0 if g is None else g.shape[-1])
+    rc = L.wm_bn_bwd_reduce(_p(g), ldg, _p(gvec), _p(y), c_int(CP), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
+                            _p(part), c_int(B), c_size_t(hw), c_int(CP), did, _stream())
+    _lib.check(rc, "wm_bn_bwd_reduce")
+    coef = torch.empty(3, CP, device=dev, dtype=torch.float32)
+    rc = L.wm_bn_bwd_finalize(_p(part), c_int(nparts), c_int(C), c_int(CP), c_double(B * hw), _p(gamma), _p(stats[3]),
+                              _p(dgamma), _p(dbeta), c_int(1 if accumulate else 0), _p(coef), _stream())
+    _lib.check(rc, "wm_bn_bwd_finalize")
+    dy = torch.empty_like(y)
+    bpart = torch.empty(nparts, CP, device=dev, dtype=torch.float32) if dbias is not None else None
+    rc = L.wm_bn_bwd_apply(_p(g), ldg, _p(gvec), _p(y), c_int(CP), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
+                           _p(coef), _p(dy), c_int(CP), _p(bpart), c_int(B), c_size_t(hw), c_int(CP), did, _stream())
+    _lib.check(rc, "wm_bn_bwd_apply")
+    if dbias is not None:
+        colsum(bpart, dbias.numel(), CP, dbias, accumulate)
+    return dy
+
+
+def colsum(partials, C, ldp, out, accumulate):
+    rc = _lib.lib().wm_colsum_finalize(_p(partials), c_int(partials.shape[0]), c_int(C), c_int(ldp), _p(out),
+                                       c_int(1 if accumulate else 0), _stream())
+    _lib.check(rc, "wm_colsum_finalize")
+
+
+def conv3x3_wgrad(x, CinX, in_scale, in_shift, dy, dw, accumulate, perm_dev=None):
+    """dw [Cout,Cin,3,3] f32 view (written in place)."""
+    B, H, W, ldx = x.shape
+    CoutY = dy.shape[-1]
+    L = _lib.lib()
+    L.wm_conv3x3_wgrad_ws_bytes.restype = c_size_t
+    nbytes = L.wm_conv3x3_wgrad_ws_bytes(c_int(B), c_int(H), c_int(W), c_int(CinX), c_int(CoutY))
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    Cout, Cin = dw.shape[0], dw.shape[1]
+    assert dw.is_contiguous()
+    rc = L.wm_conv3x3_wgrad(_p(x), c_int(ldx), c_int(CinX), _p(in_scale), _p(in_shift), _p(dy), c_int(CoutY), c_int(CoutY),
+                            _p(ws), _p(dw), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W), c_int(Cin),
+                            c_int(Cout), _p(perm_dev), c_int(dtype_id(x)), _stream())
+    _lib.check(rc, "wm_conv3x3_wgrad")
+
+
+# ----------------------------------------------------------------------------- heads
+def bnrelu_avgpool(y, scale, shift):
+    B, H, W, CP = y.shape
+    L = _lib.lib()
+    S = L.wm_avgpool_slices(c_size_t(H * W))
+    ws = torch.empty(B * S * CP, device=y.device, dtype=torch.float32)
+    out = torch.empty(B, CP, device=y.device, dtype=torch.float32)
+    rc = L.wm_bnrelu_avgpool(_p(y), c_int(CP), _p(scale), _p(shift), _p(out), _p(ws), c_int(B), c_size_t(H * W), c_int(CP),
+                             c_int(dtype_id(y)), _stream())
+    _lib.check(rc, "wm_bnrelu_avgpool")
+    return out
+
+
+def conv1x1_head_fwd(y, scale, shift, w, bias, act=0):
+    """y [B,H,W,Cin]; w [Cout,Cin(,1,1)] f32; -> out [B,Cout,H,W] f32"""
+    B, H, W, Cin = y.shape
+    Cout = w.shape[0]
+    out = torch.empty(B, Cout, H, W, device=y.device, dtype=torch.float32)
+    rc = _lib.lib().wm_conv1x1_head_fwd(_p(y), c_int(Cin), _p(scale), _p(shift), _p(w), _p(bias), _p(out), c_int(B),
+                                        c_size_t(H * W), c_int(Cin), c_int(Cout), c_int(act), c_int(dtype_id(y)), _stream())
+    _lib.check(rc, "wm_conv1x1_head_fwd")
+    return out
+
+
+def conv1x1_head_bwd(y, scale, shift, w, gout, dw, dbias, accumulate):
+    B, H, W, Cin = y.shape
+    Cout = w.shape[0]
+    L = _lib.lib()
+    nparts = L.wm_conv1x1_head_nparts(c_size_t(B * H * W))
+    part = torch.empty(nparts, Cout * (Cin + 1), device=y.device, dtype=torch.float32)
+    g = torch.empty_like(y)
+    gout = gout.contiguous()
+    rc = L.wm_conv1x1_head_bwd(_p(y), c_int(Cin), _p(scale), _p(shift), _p(w), _p(gout), _p(g), c_int(Cin), _p(part), c_int(B),
+                               c_size_t(H * W), c_int(Cin), c_int(Cout), c_int(dtype_id(y)), _stream())
+    _lib.check(rc, "wm_conv1x1_head_bwd")
+    ldp = Cout * (Cin + 1)
+    colsum(part, Cout * Cin, ldp, dw, accumulate)
+    colsum(part[:, Cout * Cin:], Cout, ldp, dbias, accumulate)
+    return g
+
+
+# ----------------------------------------------------------------------------- losses / optimiser
+def mse_fwd_bwd(a, b, gscale, want_grad=True):
+    """returns (sum of squared differences partials [nparts], grad = gscale*(a-b))"""
+    a = a.contiguous(); b = b.contiguous()
+    n = a.numel()
+    nparts = max(1, min(1024, (n + 4095) // 4096))
+    part = torch.empty(nparts, device=a.device, dtype=torch.float32)
+    grad = torch.empty_like(a) if want_grad else None
+    rc = _lib.lib().wm_mse_fwd_bwd(_p(a), _p(b), _p(grad), c_float(gscale), _p(part), c_int(nparts), c_size_t(n), _stream())
+    _lib.check(rc, "wm_mse_fwd_bwd")
+    return part, grad
+
+
+def axpy_(a, b, s=1.0):
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    rc = _lib.lib().wm_axpy(_p(a), _p(b), c_float(s), c_size_t(a.numel()), _stream())
+    _lib.check(rc, "wm_axpy")
+    return a
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, decoupled=False, grad_scale=1.0):
+    rc = _lib.lib().wm_adam_step(_p(p), _p(g), _p(m), _p(v), c_size_t(p.numel()), c_float(lr), c_float(beta1), c_float(beta2),
+                                 c_float(eps), c_float(weight_decay), c_int(1 if decoupled else 0), c_int(step),
+                                 c_float(grad_scale), _stream())
+    _lib.check(rc, "wm_adam_step")
+
+
+def sumsq(x):
+    n = x.numel()
+    nparts = max(1, min(1024, (n + 4095) // 4096))
+    part = torch.empty(nparts, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().wm_sumsq(_p(x), c_size_t(n), _p(part), c_int(nparts), _stream())
+    _lib.check(rc, "wm_sumsq")
+    return part
