@@ -1,0 +1,76 @@
+"""CPU: host-side surface checks that need no GPU -- state_dict keys equal the reference's
+(through the oracle restatement, itself pinned to the reference by test_oracle_golden), the C-ABI
+library loads and exports every symbol include/wm_hip.h declares, and the product path refuses to
+run without a GPU instead of falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import hidden_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_keys_match_reference_names():
+    from video_watermarking_forgery_detection_amd.hidden_models import Encoder, Decoder, Discriminator
+    from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
+    cfg = HiDDenConfiguration(H=32, W=32)
+    rc = hidden_ref.HiDDenConfiguration(H=32, W=32)
+    for mine, ref in ((Encoder(cfg), hidden_ref.Encoder(rc)), (Decoder(cfg), hidden_ref.Decoder(rc)),
+                      (Discriminator(cfg), hidden_ref.Discriminator(rc))):
+        a, b = mine.state_dict(), ref.state_dict()
+        assert list(a.keys()) == list(b.keys())
+        assert all(a[k].shape == b[k].shape for k in a)
+        ref.load_state_dict(a)  # checkpoints interchange
+
+
+def test_library_exports_every_declared_symbol():
+    from video_watermarking_forgery_detection_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "wm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(wm_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 20
+    if not os.path.exists(_lib.LIB_PATH):
+        from video_watermarking_forgery_detection_amd import build
+        build.build(verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.wm_abi_version() >= 1
+
+
+def test_no_cpu_fallback():
+    from video_watermarking_forgery_detection_amd.hidden_models import Encoder, Hidden
+    from video_watermarking_forgery_detection_amd.noise_layers import Jpeg, Identity
+    from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
+    cfg = HiDDenConfiguration(H=16, W=16)
+    with pytest.raises(RuntimeError, match="HIP path only"):
+        Encoder(cfg)(torch.zeros(1, 3, 16, 16), torch.zeros(1, 30))
+    with pytest.raises(RuntimeError, match="HIP path only"):
+        Jpeg(50)(torch.zeros(1, 3, 16, 16))
+    with pytest.raises(RuntimeError, match="HIP path only"):
+        Hidden(cfg, torch.device("cpu"), Identity(), None)
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "video_watermarking_forgery_detection_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_jpeg_layer_names_and_scale():
+    from video_watermarking_forgery_detection_amd.noise_layers import Jpeg, JpegSS, JpegMask, Combined, Identity
+    assert Jpeg(50).name == "Jpeg50" and JpegSS(70).name == "JpegSS70" and JpegMask(90).name == "JpegMask90"
+    assert Jpeg(50).scale_factor == 1.0 and abs(Jpeg(90).scale_factor - 0.2) < 1e-12 and Jpeg(10).scale_factor == 5.0
+    c = Combined([JpegMask(80), Jpeg(80), Identity()])
+    assert c.name == "NotChosenYet"
+    c._pick(1)
+    assert c.name == "Jpeg80"
+    c._pick(7)
+    assert c.name in ("JpegMask80", "Jpeg80", "Identity")

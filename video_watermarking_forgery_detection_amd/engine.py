@@ -1,0 +1,163 @@
+"""Explicit forward / backward of the ConvBNRelu stacks on the HIP kernels.
+
+This is the host side of the hot path: it sequences the C-ABI kernels (ops.py)
+for HiDDeN's encoder / decoder / discriminator (hidden_models/*.py of the
+reference) without autograd -- the backward order is written out, so the step
+can be captured, overlapped with RCCL and profiled kernel by kernel.
+
+Data layout in HBM
+  * activations: NHWC, bf16 (production) or f32 (parity), one tensor per conv
+    output holding the RAW convolution result y; the BatchNorm+ReLU that follows
+    is never materialised -- an `Act` carries (y, scale, shift) and every consumer
+    kernel applies relu(scale*y+shift) while it stages its input;
+  * image inputs: 3 channels zero-padded to 16 (one 32-byte bf16 pixel);
+  * parameters / gradients / Adam moments: f32, one flat buffer per network.
+"""
+import torch
+
+from . import ops
+
+
+class Act:
+    """NHWC activation: logical value = t (if scale is None) or relu(scale*t+shift)."""
+    __slots__ = ("t", "C", "scale", "shift")
+
+    def __init__(self, t, C, scale=None, shift=None):
+        self.t, self.C, self.scale, self.shift = t, C, scale, shift
+
+
+def round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+def image_to_act(img, dtype):
+    """[B,3,H,W] f32 (NCHW) -> Act over a [B,H,W,16] zero-padded NHWC tensor."""
+    B, C, H, W = img.shape
+    assert C == 3
+    t = torch.empty(B, H, W, 16, device=img.device, dtype=dtype)
+    ops.nchw_to_nhwc(img, t, 0, 13)
+    return Act(t, 3)
+
+
+class CBRCtx:
+    __slots__ = ("x", "y", "stats", "perm", "training")
+
+
+def cbr_forward(conv, bn, x, dtype, perm=None, training=True, momentum=0.1):
+    """ConvBNRelu forward (conv_bn_relu.py:11-15).  conv.weight [Cout,Cin,3,3], conv.bias or None,
+    bn: BatchNorm2d parameters/buffers.  x: Act whose physical channel count (x.t.shape[-1]) is the
+    K extent.  Returns (Act(y, scale, shift), ctx)."""
+    Cout = conv.weight.shape[0]
+    CoutP = round_up(Cout, 32)
+    CinX = x.t.shape[-1]
+    wp = ops.pack_w3x3(conv.weight.data, CoutP, CinX, dtype, perm=perm)
+    bias = conv.bias.data if conv.bias is not None else None
+    B, H, W, _ = x.t.shape
+    y, st = ops.conv3x3_fwd(x.t, wp, bias, x.scale, x.shift, want_stats=training)
+    if training:
+        stats = ops.bn_finalize(st, Cout, CoutP, B * H * W, bn.weight.data, bn.bias.data, bn.running_mean,
+                                bn.running_var, momentum if bn.momentum is None else bn.momentum, bn.eps)
+    else:
+        invstd = torch.rsqrt(bn.running_var + bn.eps)
+        scale = bn.weight.data * invstd
+        stats = torch.zeros(4, CoutP, device=y.device, dtype=torch.float32)
+        stats[0, :Cout] = scale
+        stats[1, :Cout] = bn.bias.data - bn.running_mean * scale
+        stats[2, :Cout] = bn.running_mean
+        stats[3, :Cout] = invstd
+    ctx = CBRCtx()
+    ctx.x, ctx.y, ctx.stats, ctx.perm, ctx.training = x, y, stats, perm, training
+    return Act(y, Cout, stats[0], stats[1]), ctx
+
+
+def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, accumulate=False,
+                 dgrad_channels=None, perm_dev=None):
+    """Backward of ConvBNRelu.  g: NHWC gradient wrt the ReLU output ([B,H,W,>=CoutP]) or gvec [B,CoutP]
+    (global-average-pool gradient, already / (H*W)).  grads: dict param -> f32 grad view.
+    Returns the NHWC gradient wrt the (activated) input, `dgrad_channels` wide (default: the input's
+    physical channels rounded up to 32), or None."""
+    if not ctx.training:
+        raise RuntimeError("backward through eval-mode BatchNorm is not supported by the HIP path")
+    y, x = ctx.y, ctx.x
+    Cout = conv.weight.shape[0]
+    dtype = y.dtype
+    dbias = grads[conv.bias] if conv.bias is not None else None
+    dy = ops.bn_bwd(g, gvec, y, ctx.stats, Cout, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate, dbias)
+    ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, perm_dev=perm_dev)
+    if not need_input_grad:
+        return None
+    rows = dgrad_channels or round_up(x.t.shape[-1], 32)
+    wpt = ops.pack_w3x3(conv.weight.data, y.shape[-1], rows, dtype, perm=ctx.perm, transpose=True)
+    gx, _ = ops.conv3x3_fwd(dy, wpt, None, None, None, want_stats=False)
+    return gx
+
+
+def grad_dict(module, flat_grad=None):
+    """param -> gradient view.  With flat_grad None, uses/creates p.grad."""
+    out = {}
+    off = 0
+    for p in module.parameters():
+        if flat_grad is None:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p.data)
+            out[p] = p.grad
+        else:
+            n = p.numel()
+            out[p] = flat_grad[off:off + n].view_as(p)
+            off += n
+    return out
+
+
+class FlatModule:
+    """Mixin: keeps all parameters of an nn.Module in one flat f32 buffer (and the gradients in
+    another) so the optimiser step is one kernel and the gradient all-reduce one RCCL bucket."""
+
+    def flatten_parameters_(self):
+        params = list(self.parameters())
+        if not params:
+            return
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        flat = getattr(self, "_flat", None)
+        ok = flat is not None and flat.device == dev and flat.numel() == n
+        if ok:
+            off = 0
+            for p in params:
+                if p.data_ptr() != flat.data_ptr() + 4 * off:
+                    ok = False
+                    break
+                off += p.numel()
+        if ok:
+            return
+        flat = torch.empty(n, device=dev, dtype=torch.float32)
+        gflat = torch.zeros(n, device=dev, dtype=torch.float32)
+        off = 0
+        for p in params:
+            k = p.numel()
+            v = flat[off:off + k].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            p.grad = gflat[off:off + k].view_as(p)
+            off += k
+        object.__setattr__(self, "_flat", flat)
+        object.__setattr__(self, "_gflat", gflat)
+
+    @property
+    def flat_params(self):
+        self.flatten_parameters_()
+        return self._flat
+
+    @property
+    def flat_grads(self):
+        self.flatten_parameters_()
+        return self._gflat
+
+
+def set_compute_dtype(module, dtype):
+    """torch.bfloat16 (production) or torch.float32 (parity path) for every HIP-backed submodule."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("compute dtype must be torch.float32 or torch.bfloat16")
+    for m in module.modules():
+        if hasattr(m, "compute_dtype"):
+            m.compute_dtype = dtype
+    return module

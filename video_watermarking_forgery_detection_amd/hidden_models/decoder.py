@@ -1,0 +1,114 @@
+"""Decoder and Discriminator share one shape: a ConvBNRelu stack on an image, a global average
+pool, a Linear.  This file mirrors the reference's hidden_models/decoder.py:6-35
+(`Decoder(config)`, keys `layers.{i}.layers.{0,1}.*`, `linear.*`)."""
+import torch
+import torch.nn as nn
+
+from .. import engine, ops
+from ..options import HiDDenConfiguration
+from .conv_bn_relu import ConvBNRelu
+
+
+class StackCtx:
+    __slots__ = ("layers", "pooled", "HW", "x_is_leaf_image")
+
+
+def stack_fwd(blocks, image, dt, training):
+    """image [B,3,H,W] f32 -> (pooled [B,CP] f32 of the last block's ReLU output, ctx)"""
+    ctx = StackCtx()
+    ctx.layers = []
+    a = engine.image_to_act(image, dt)
+    for blk in blocks:
+        a, cx = engine.cbr_forward(blk.layers[0], blk.layers[1], a, dt, training=training)
+        ctx.layers.append(cx)
+    ctx.pooled = ops.bnrelu_avgpool(a.t, a.scale, a.shift)
+    ctx.HW = image.shape[2] * image.shape[3]
+    return ctx.pooled, ctx
+
+
+def stack_bwd(blocks, ctx, g_pooled, grads, accumulate, need_input_grad):
+    """g_pooled [B,C] f32 (gradient wrt the pooled features) -> gradient wrt the image [B,3,H,W] or None"""
+    CP = ctx.layers[-1].y.shape[-1]
+    B, C = g_pooled.shape
+    gvec = torch.zeros(B, CP, device=g_pooled.device, dtype=torch.float32)
+    gvec[:, :C] = g_pooled / ctx.HW
+    g = None
+    n = len(blocks)
+    for i in range(n - 1, -1, -1):
+        blk = blocks[i]
+        g = engine.cbr_backward(blk.layers[0], blk.layers[1], ctx.layers[i], grads, g=g, gvec=gvec if i == n - 1 else None,
+                                accumulate=accumulate, need_input_grad=(i > 0 or need_input_grad))
+    if not need_input_grad:
+        return None
+    return ops.nhwc_to_nchw(g, 3, 0)
+
+
+def bump_bn_counters(mod):
+    for m in mod.modules():
+        if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None:
+            m.num_batches_tracked += 1
+
+
+class _StackLinearFn(torch.autograd.Function):
+    """reference-style autograd entry for Decoder / Discriminator"""
+
+    @staticmethod
+    def forward(ctx, image, mod, *params):
+        out, c = mod.fwd(image.float().contiguous(), training=mod.training)
+        ctx.c, ctx.mod = c, mod
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mod = ctx.mod
+        n = sum(p.numel() for p in mod.parameters())
+        flat = torch.zeros(n, device=g.device, dtype=torch.float32)
+        grads = engine.grad_dict(mod, flat)
+        gin = mod.bwd(ctx.c, g.float().contiguous(), grads, accumulate=False, need_input_grad=ctx.needs_input_grad[0])
+        return (gin, None) + tuple(grads[p] for p in mod.parameters())
+
+
+class Decoder(nn.Module, engine.FlatModule):
+    """Receives a (noised) watermarked image and extracts the message."""
+
+    def __init__(self, config: HiDDenConfiguration):
+        super(Decoder, self).__init__()
+        self.channels = config.decoder_channels
+        self.message_length = config.message_length
+        layers = [ConvBNRelu(3, self.channels)]
+        for _ in range(config.decoder_blocks - 1):
+            layers.append(ConvBNRelu(self.channels, self.channels))
+        layers.append(ConvBNRelu(self.channels, config.message_length))
+        layers.append(nn.AdaptiveAvgPool2d(output_size=(1, 1)))
+        self.layers = nn.Sequential(*layers)
+        self.linear = nn.Linear(config.message_length, config.message_length)
+        self.compute_dtype = torch.bfloat16
+
+    def _blocks(self):
+        return [m for m in self.layers if isinstance(m, ConvBNRelu)]
+
+    def fwd(self, image, training=True):
+        pooled, ctx = stack_fwd(self._blocks(), image, self.compute_dtype, training)
+        L = self.message_length
+        out = torch.addmm(self.linear.bias.data, pooled[:, :L], self.linear.weight.data.t())  # [B,L]x[L,L]: plumbing-sized
+        if training:
+            bump_bn_counters(self)
+        return out, ctx
+
+    def bwd(self, ctx, g_out, grads, accumulate=False, need_input_grad=True):
+        L = self.message_length
+        pooled = ctx.pooled[:, :L]
+        gw, gb = g_out.t() @ pooled, g_out.sum(0)
+        if accumulate:
+            grads[self.linear.weight] += gw
+            grads[self.linear.bias] += gb
+        else:
+            grads[self.linear.weight].copy_(gw)
+            grads[self.linear.bias].copy_(gb)
+        g_pooled = g_out @ self.linear.weight.data
+        return stack_bwd(self._blocks(), ctx, g_pooled, grads, accumulate, need_input_grad)
+
+    def forward(self, image_with_wm):
+        if not image_with_wm.is_cuda:
+            raise RuntimeError("Decoder runs on the HIP path only: move the module and input to cuda")
+        return _StackLinearFn.apply(image_with_wm, self, *self.parameters())

@@ -1,0 +1,53 @@
+"""Discriminator -- mirror of the reference's hidden_models/discriminator.py:5-27
+(`Discriminator(config)`, keys `before_linear.{i}.layers.{0,1}.*`, `linear.*`; returns logits,
+the sigmoid is commented out in the reference at :26)."""
+import torch
+import torch.nn as nn
+
+from .. import engine
+from ..options import HiDDenConfiguration
+from .conv_bn_relu import ConvBNRelu
+from .decoder import _StackLinearFn, bump_bn_counters, stack_bwd, stack_fwd
+
+
+class Discriminator(nn.Module, engine.FlatModule):
+    """Receives an image and decides whether it carries a watermark."""
+
+    def __init__(self, config: HiDDenConfiguration):
+        super(Discriminator, self).__init__()
+        c = config.discriminator_channels
+        self.channels = c
+        layers = [ConvBNRelu(3, c)]
+        for _ in range(config.discriminator_blocks - 1):
+            layers.append(ConvBNRelu(c, c))
+        layers.append(nn.AdaptiveAvgPool2d(output_size=(1, 1)))
+        self.before_linear = nn.Sequential(*layers)
+        self.linear = nn.Linear(c, 1)
+        self.compute_dtype = torch.bfloat16
+
+    def _blocks(self):
+        return [m for m in self.before_linear if isinstance(m, ConvBNRelu)]
+
+    def fwd(self, image, training=True):
+        pooled, ctx = stack_fwd(self._blocks(), image, self.compute_dtype, training)
+        out = torch.addmm(self.linear.bias.data, pooled[:, :self.channels], self.linear.weight.data.t())
+        if training:
+            bump_bn_counters(self)
+        return out, ctx
+
+    def bwd(self, ctx, g_out, grads, accumulate=False, need_input_grad=False):
+        pooled = ctx.pooled[:, :self.channels]
+        gw, gb = g_out.t() @ pooled, g_out.sum(0)
+        if accumulate:
+            grads[self.linear.weight] += gw
+            grads[self.linear.bias] += gb
+        else:
+            grads[self.linear.weight].copy_(gw)
+            grads[self.linear.bias].copy_(gb)
+        g_pooled = g_out @ self.linear.weight.data
+        return stack_bwd(self._blocks(), ctx, g_pooled, grads, accumulate, need_input_grad)
+
+    def forward(self, image):
+        if not image.is_cuda:
+            raise RuntimeError("Discriminator runs on the HIP path only: move the module and input to cuda")
+        return _StackLinearFn.apply(image, self, *self.parameters())

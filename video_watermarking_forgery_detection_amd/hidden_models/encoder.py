@@ -1,0 +1,119 @@
+"""Encoder -- mirror of the reference's hidden_models/encoder.py:7-43 on the HIP kernels.
+
+Same ctor (`Encoder(config)`), attributes and state_dict keys (`conv_layers.{i}.layers.{0,1}.*`,
+`after_concat_layer.layers.*`, `final_layer.*`).  The concat of encoder.py:40 is
+cat([message, features, image]); in HBM it is laid out as [features(64) | message(L) | image(3) | 0-pad]
+so the feature slice stays 16-byte aligned, and the after-concat weights are permuted to match when
+they are packed -- the arithmetic is the reference's.
+"""
+import torch
+import torch.nn as nn
+
+from .. import engine, ops
+from ..options import HiDDenConfiguration
+from .conv_bn_relu import ConvBNRelu
+
+
+class EncCtx:
+    __slots__ = ("layers", "cat_ctx", "final_in", "B", "H", "W")
+
+
+class Encoder(nn.Module, engine.FlatModule):
+    """Inserts a watermark into an image."""
+
+    def __init__(self, config: HiDDenConfiguration):
+        super(Encoder, self).__init__()
+        self.H = config.H
+        self.W = config.W
+        self.conv_channels = config.encoder_channels
+        self.num_blocks = config.encoder_blocks
+        self.message_length = config.message_length
+        layers = [ConvBNRelu(3, self.conv_channels)]
+        for _ in range(config.encoder_blocks - 1):
+            layers.append(ConvBNRelu(self.conv_channels, self.conv_channels))
+        self.conv_layers = nn.Sequential(*layers)
+        self.after_concat_layer = ConvBNRelu(self.conv_channels + 3 + config.message_length, self.conv_channels)
+        self.final_layer = nn.Conv2d(self.conv_channels, 3, kernel_size=1)
+        self.compute_dtype = torch.bfloat16
+        c, L = self.conv_channels, config.message_length
+        assert c % 8 == 0
+        # packed position of reference concat channel ci (reference order: message, features, image)
+        self._cat_ld = engine.round_up(c + L + 3, 16)
+        self._perm = [c + i for i in range(L)] + list(range(c)) + [c + L + i for i in range(3)]
+        self._perm_dev = None
+
+    # -- explicit engine path ------------------------------------------------------------------
+    def fwd(self, image, message, training=True):
+        """image [B,3,H,W] f32 cuda, message [B,L] -> (encoded [B,3,H,W] f32, ctx)"""
+        if image.shape[2] != self.H or image.shape[3] != self.W:
+            raise RuntimeError(f"Encoder configured for {self.H}x{self.W}, got {tuple(image.shape[2:])}")  # encoder.py:37
+        dt = self.compute_dtype
+        B = image.shape[0]
+        c, L = self.conv_channels, self.message_length
+        ctx = EncCtx()
+        ctx.layers = []
+        a = engine.image_to_act(image, dt)
+        for blk in self.conv_layers:
+            a, cx = engine.cbr_forward(blk.layers[0], blk.layers[1], a, dt, training=training)
+            ctx.layers.append(cx)
+        cat = torch.empty(B, self.H, self.W, self._cat_ld, device=image.device, dtype=dt)
+        ops.bnrelu_copy(a.t, a.scale, a.shift, cat, 0, c)
+        ops.broadcast_to_nhwc(message, cat, c)
+        ops.nchw_to_nhwc(image, cat, c + L, self._cat_ld - (c + L + 3))
+        blk = self.after_concat_layer
+        a5, ctx.cat_ctx = engine.cbr_forward(blk.layers[0], blk.layers[1], engine.Act(cat, c + L + 3), dt,
+                                             perm=self._perm, training=training)
+        ctx.final_in = a5
+        fl = self.final_layer
+        enc = ops.conv1x1_head_fwd(a5.t, a5.scale, a5.shift, fl.weight.data.view(3, c), fl.bias.data, act=0)
+        if training:
+            self._bump_bn_counters()
+        return enc, ctx
+
+    def bwd(self, ctx, g_enc, grads, accumulate=False):
+        """g_enc [B,3,H,W] f32: gradient wrt the encoded image.  Parameter gradients go to `grads`.
+        (No gradient wrt image/message: the reference's inputs do not require grad.)"""
+        c = self.conv_channels
+        if self._perm_dev is None or self._perm_dev.device != g_enc.device:
+            self._perm_dev = torch.tensor(self._perm, dtype=torch.int32, device=g_enc.device)
+        fl = self.final_layer
+        a5 = ctx.final_in
+        g = ops.conv1x1_head_bwd(a5.t, a5.scale, a5.shift, fl.weight.data.view(3, c), g_enc,
+                                 grads[fl.weight].view(3, c), grads[fl.bias], accumulate)
+        blk = self.after_concat_layer
+        g = engine.cbr_backward(blk.layers[0], blk.layers[1], ctx.cat_ctx, grads, g=g, accumulate=accumulate,
+                                dgrad_channels=c, perm_dev=self._perm_dev)
+        n = len(self.conv_layers)
+        for i in range(n - 1, -1, -1):
+            blk = self.conv_layers[i]
+            g = engine.cbr_backward(blk.layers[0], blk.layers[1], ctx.layers[i], grads, g=g, accumulate=accumulate,
+                                    need_input_grad=(i > 0))
+        return None
+
+    def _bump_bn_counters(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None:
+                m.num_batches_tracked += 1
+
+    # -- reference-style call (autograd) -------------------------------------------------------
+    def forward(self, image, message):
+        if not image.is_cuda:
+            raise RuntimeError("Encoder runs on the HIP path only: move the module and inputs to cuda")
+        return _EncoderFn.apply(image, message, self, *self.parameters())
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, message, mod, *params):
+        enc, c = mod.fwd(image.float().contiguous(), message.float().reshape(message.shape[0], -1), training=mod.training)
+        ctx.c, ctx.mod = c, mod
+        return enc
+
+    @staticmethod
+    def backward(ctx, g):
+        mod = ctx.mod
+        n = sum(p.numel() for p in mod.parameters())
+        flat = torch.zeros(n, device=g.device, dtype=torch.float32)
+        grads = engine.grad_dict(mod, flat)
+        mod.bwd(ctx.c, g.float().contiguous(), grads, accumulate=False)
+        return (None, None, None) + tuple(grads[p] for p in mod.parameters())

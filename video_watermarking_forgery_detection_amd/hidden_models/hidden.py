@@ -1,0 +1,252 @@
+"""Hidden -- the GAN training step of the reference's hidden_models/hidden.py:12-118 on the MI355X
+kernels: same constructor, `train_on_batch([images, messages])` / `validate_on_batch(...)` returning
+(losses dict with the reference's keys, (encoded, noised, decoded)), same order of operations:
+
+    D(cover) -> BCE(1) -> bwd | enc -> noise -> dec | D(enc.detach()) -> BCE(0) -> bwd | Adam(D)
+    | D(enc) -> adv*BCE(1) + enc*MSE(enc, img) + dec*MSE(dec, msg) -> bwd | Adam(enc+dec)
+
+The backward is written out (engine.py) instead of traced by autograd, every heavy op is a HIP kernel
+behind the C ABI, parameters/gradients/moments of each optimiser live in flat f32 buffers (one fused
+Adam launch, one RCCL bucket for data parallel), and the seven logged scalars are fetched with a
+single host sync.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import engine, ops
+from ..options import HiDDenConfiguration
+from .discriminator import Discriminator
+from .encoder_decoder import EncoderDecoder
+
+
+class _FlatAdam:
+    """torch.optim.Adam defaults (hidden.py:24-25) over flat parameter buffers, one kernel per buffer.
+    Exposes `param_groups` / `state_dict` enough for BaseModel-style lr handling and checkpoints."""
+
+    def __init__(self, modules, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False):
+        self.modules = list(modules)
+        self.param_groups = [{"lr": lr, "initial_lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
+        self.decoupled = decoupled
+        self.step_count = 0
+        self._m = None
+        self._v = None
+
+    def _ensure(self):
+        if self._m is None:
+            self._m = [torch.zeros_like(m.flat_params) for m in self.modules]
+            self._v = [torch.zeros_like(m.flat_params) for m in self.modules]
+
+    def zero_grad(self):
+        for m in self.modules:
+            m.flat_grads.zero_()
+
+    def step(self, grad_scale=1.0):
+        self._ensure()
+        self.step_count += 1
+        g = self.param_groups[0]
+        for mod, m, v in zip(self.modules, self._m, self._v):
+            ops.adam_step(mod.flat_params, mod.flat_grads, m, v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                          g["weight_decay"], self.step_count, decoupled=self.decoupled, grad_scale=grad_scale)
+
+    def state_dict(self):
+        self._ensure()
+        return {"step": self.step_count, "param_groups": self.param_groups,
+                "exp_avg": [t.cpu() for t in self._m], "exp_avg_sq": [t.cpu() for t in self._v]}
+
+    def load_state_dict(self, sd):
+        self._ensure()
+        self.step_count = sd["step"]
+        self.param_groups = sd["param_groups"]
+        for t, s in zip(self._m, sd["exp_avg"]):
+            t.copy_(s)
+        for t, s in zip(self._v, sd["exp_avg_sq"]):
+            t.copy_(s)
+
+
+def _noise_fwd(noiser, enc, cover):
+    """explicit fwd/bwd if the noise layer offers it, autograd otherwise (any nn.Module works)."""
+    if hasattr(noiser, "fwd") and hasattr(noiser, "bwd"):
+        y, c = noiser.fwd(enc)
+        return y, ("explicit", c)
+    x = enc.detach().requires_grad_(True)
+    with torch.enable_grad():
+        out = noiser([x, cover])
+        y = out[0] if isinstance(out, (list, tuple)) else out
+    return y.detach(), ("autograd", (x, y))
+
+
+def _noise_bwd(noiser, ctx, g):
+    kind, c = ctx
+    if kind == "explicit":
+        return noiser.bwd(c, g)
+    x, y = c
+    if not y.requires_grad:
+        return torch.zeros_like(g)
+    (gx,) = torch.autograd.grad(y, x, g, allow_unused=True)
+    return gx if gx is not None else torch.zeros_like(g)
+
+
+class Hidden:
+    def __init__(self, configuration: HiDDenConfiguration, device: torch.device, noiser, tb_logger=None,
+                 compute_dtype=torch.bfloat16, grad_sync=None):
+        """
+        :param configuration: sizes / loss weights (options.HiDDenConfiguration)
+        :param device: must be a cuda (ROCm) device -- the step has no CPU path
+        :param noiser: attack layer(s): an object with forward([encoded, cover]) -> [noised, cover]
+                       (noise_layers.Noiser) or any module of noise_layers
+        :param tb_logger: accepted for signature compatibility; unused
+        :param compute_dtype: torch.bfloat16 (production) or torch.float32 (parity path)
+        :param grad_sync: optional callable(flat_grad_tensor) run before each optimiser step
+                          (data-parallel all-reduce, see parallel.py)
+        """
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("Hidden runs on the MI355X HIP path only (device must be cuda)")
+        self.encoder_decoder = EncoderDecoder(configuration, noiser).to(device)
+        self.discriminator = Discriminator(configuration).to(device)
+        engine.set_compute_dtype(self.encoder_decoder, compute_dtype)
+        engine.set_compute_dtype(self.discriminator, compute_dtype)
+        enc, dec = self.encoder_decoder.encoder, self.encoder_decoder.decoder
+        for m in (enc, dec, self.discriminator):
+            m.flatten_parameters_()
+        self.optimizer_enc_dec = _FlatAdam([enc, dec])
+        self.optimizer_discrim = _FlatAdam([self.discriminator])
+        if configuration.use_vgg:
+            raise NotImplementedError("use_vgg: the reference's vgg_loss module is absent from its tree")
+        self.vgg_loss = None
+        self.config = configuration
+        self.device = device
+        self.cover_label = 1
+        self.encoded_label = 0
+        self.tb_logger = tb_logger
+        self.grad_sync = grad_sync
+        self.noise_id = None  # optional deterministic choice for Combined/Noiser layers
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _bce_logits(logits, target):
+        """nn.BCEWithLogitsLoss (mean) value and gradient wrt logits, on a [B,1] tensor."""
+        t = torch.full_like(logits, float(target))
+        loss = F.binary_cross_entropy_with_logits(logits, t)
+        grad = (torch.sigmoid(logits) - t) / logits.numel()
+        return loss, grad
+
+    def _run_noiser(self, enc, cover):
+        n = self.encoder_decoder.noiser
+        if hasattr(n, "fwd") and hasattr(n, "bwd"):
+            try:
+                y, c = n.fwd(enc, id=self.noise_id)
+            except TypeError:
+                y, c = n.fwd(enc)
+            return y, ("explicit", c)
+        return _noise_fwd(n, enc, cover)
+
+    # ------------------------------------------------------------------ the step
+    def train_on_batch(self, batch: list):
+        images, messages = batch
+        images = images.to(self.device, torch.float32).contiguous()
+        messages = messages.to(self.device, torch.float32).contiguous()
+        B = images.shape[0]
+        cfg = self.config
+        ed = self.encoder_decoder
+        enc_net, dec_net, D = ed.encoder, ed.decoder, self.discriminator
+        ed.train()
+        D.train()
+        gD = engine.grad_dict(D)
+        gE = engine.grad_dict(enc_net)
+        gDec = engine.grad_dict(dec_net)
+
+        # ---------------- train the discriminator (hidden.py:68-83)
+        d_on_cover, c = D.fwd(images)
+        d_loss_on_cover, g = self._bce_logits(d_on_cover, self.cover_label)
+        D.bwd(c, g, gD, accumulate=False, need_input_grad=False)          # zero_grad + backward
+
+        encoded, cE = enc_net.fwd(images, messages)
+        noised, cN = self._run_noiser(encoded, images)
+        decoded, cDec = dec_net.fwd(noised)
+
+        d_on_encoded, c = D.fwd(encoded)                                  # encoded.detach()
+        d_loss_on_encoded, g = self._bce_logits(d_on_encoded, self.encoded_label)
+        D.bwd(c, g, gD, accumulate=True, need_input_grad=False)
+        if self.grad_sync is not None:
+            self.grad_sync(D.flat_grads)
+        self.optimizer_discrim.step()
+
+        # ---------------- train the generator (hidden.py:85-103)
+        d_on_encoded_for_enc, c = D.fwd(encoded)
+        g_loss_adv, g = self._bce_logits(d_on_encoded_for_enc, self.cover_label)
+        # the reference's g_loss.backward() also accumulates into the discriminator's .grad (zeroed at
+        # the start of the next step); kept, so .grad state matches
+        g_enc = D.bwd(c, g * cfg.adversarial_loss, gD, accumulate=True, need_input_grad=True)
+
+        n_img = encoded.numel()
+        enc_part, g_mse = ops.mse_fwd_bwd(encoded, images, 2.0 * cfg.encoder_loss / n_img)
+        ops.axpy_(g_enc, g_mse)
+        diff = decoded - messages
+        g_loss_dec = (diff * diff).mean()
+        g_dec = diff * (2.0 * cfg.decoder_loss / diff.numel())
+        g_noised = dec_net.bwd(cDec, g_dec, gDec, accumulate=False, need_input_grad=True)
+        g_from_noise = _noise_bwd(ed.noiser, cN, g_noised)
+        ops.axpy_(g_enc, g_from_noise.contiguous())
+        enc_net.bwd(cE, g_enc, gE, accumulate=False)
+        if self.grad_sync is not None:
+            self.grad_sync(enc_net.flat_grads)
+            self.grad_sync(dec_net.flat_grads)
+        self.optimizer_enc_dec.step()
+
+        # ---------------- metrics: one host sync for all seven scalars (hidden.py:105-117)
+        g_loss_enc = enc_part.sum() / n_img
+        g_loss = cfg.adversarial_loss * g_loss_adv + cfg.encoder_loss * g_loss_enc + cfg.decoder_loss * g_loss_dec
+        rounded = decoded.round().clamp(0, 1)
+        bit_err = (rounded - messages).abs().sum() / (B * messages.shape[1])
+        vals = torch.stack([g_loss, g_loss_enc, g_loss_dec, bit_err, g_loss_adv, d_loss_on_cover,
+                            d_loss_on_encoded]).tolist()
+        losses = {
+            'loss           ': vals[0],
+            'encoder_mse    ': vals[1],
+            'dec_mse        ': vals[2],
+            'bitwise-error  ': vals[3],
+            'adversarial_bce': vals[4],
+            'discr_cover_bce': vals[5],
+            'discr_encod_bce': vals[6],
+        }
+        return losses, (encoded, noised, decoded)
+
+    def validate_on_batch(self, batch: list):
+        """hidden.py:120-182: eval-mode BatchNorm (running statistics), no parameter update."""
+        images, messages = batch
+        images = images.to(self.device, torch.float32).contiguous()
+        messages = messages.to(self.device, torch.float32).contiguous()
+        B = images.shape[0]
+        cfg = self.config
+        ed = self.encoder_decoder
+        enc_net, dec_net, D = ed.encoder, ed.decoder, self.discriminator
+        ed.eval()
+        D.eval()
+        with torch.no_grad():
+            d_on_cover, _ = D.fwd(images, training=False)
+            d_loss_on_cover, _ = self._bce_logits(d_on_cover, self.cover_label)
+            encoded, _ = enc_net.fwd(images, messages, training=False)
+            noised, _ = self._run_noiser(encoded, images)
+            decoded, _ = dec_net.fwd(noised, training=False)
+            d_on_encoded, _ = D.fwd(encoded, training=False)
+            d_loss_on_encoded, _ = self._bce_logits(d_on_encoded, self.encoded_label)
+            g_loss_adv, _ = self._bce_logits(d_on_encoded, self.cover_label)
+            g_loss_enc = F.mse_loss(encoded, images)
+            g_loss_dec = F.mse_loss(decoded, messages)
+            g_loss = cfg.adversarial_loss * g_loss_adv + cfg.encoder_loss * g_loss_enc + cfg.decoder_loss * g_loss_dec
+            rounded = decoded.round().clamp(0, 1)
+            bit_err = (rounded - messages).abs().sum() / (B * messages.shape[1])
+            vals = torch.stack([g_loss, g_loss_enc, g_loss_dec, bit_err, g_loss_adv, d_loss_on_cover,
+                                d_loss_on_encoded]).tolist()
+        losses = {
+            'loss           ': vals[0], 'encoder_mse    ': vals[1], 'dec_mse        ': vals[2],
+            'bitwise-error  ': vals[3], 'adversarial_bce': vals[4], 'discr_cover_bce': vals[5],
+            'discr_encod_bce': vals[6],
+        }
+        return losses, (encoded, noised, decoded)
+
+    def to_stirng(self):
+        return '{}\n{}'.format(str(self.encoder_decoder), str(self.discriminator))
