@@ -142,9 +142,10 @@ def conv3x3_fwd(x, wp, bias, in_scale, in_shift, want_stats, Cin=None):
     assert Cin == CinW and Cin <= ldx
     y = torch.empty(B, H, W, CoutP, device=x.device, dtype=x.dtype)
     st = torch.empty(conv3x3_nparts(B, H, W), 2, CoutP, device=x.device, dtype=torch.float32) if want_stats else None
-    rc = _lib.lib().wm_conv3x3_fwd(_p(x), c_int(ldx), _p(wp), _p(bias), c_int(0 if bias is None else bias.numel()),
-                                   _p(in_scale), _p(in_shift), _p(y), c_int(CoutP), _p(st), c_int(B), c_int(H), c_int(W),
-                                   c_int(Cin), c_int(CoutP), c_int(dtype_id(x)), _stream())
+    info = {"B": B, "H": H, "W": W, "Cin": Cin, "CoutP": CoutP, "xform": in_scale is not None, "dtype": x.dtype}
+    rc = _timed("conv3x3_fwd", info, lambda: _lib.lib().wm_conv3x3_fwd(
+        _p(x), c_int(ldx), _p(wp), _p(bias), c_int(0 if bias is None else bias.numel()), _p(in_scale), _p(in_shift),
+        _p(y), c_int(CoutP), _p(st), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(CoutP), c_int(dtype_id(x)), _stream()))
     _lib.check(rc, "wm_conv3x3_fwd")
     return y, st
 
@@ -284,3 +285,37 @@ def sumsq(x):
     rc = _lib.lib().wm_sumsq(_p(x), c_size_t(n), _p(part), c_int(nparts), _stream())
     _lib.check(rc, "wm_sumsq")
     return part
+
+
+# ----------------------------------------------------------------------------- per-kernel timing hook
+# bench.py brackets launches of one named kernel family with events on the launch stream
+# (torch's current stream == the hipStream_t handed to the C ABI).
+_TIMER = None
+
+
+class KernelTimer:
+    def __init__(self, match):
+        self.match = match  # callable(name, info) -> bool
+        self.pairs = []
+
+    def elapsed_ms(self):
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in self.pairs]
+
+
+def set_kernel_timer(timer):
+    global _TIMER
+    _TIMER = timer
+
+
+def _timed(name, info, launch):
+    t = _TIMER
+    if t is None or not t.match(name, info):
+        return launch()
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    r = launch()
+    b.record()
+    t.pairs.append((a, b))
+    return r
