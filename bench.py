@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--noise", default="Jpeg50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--cpu-frames", type=int, default=2)
     return ap.parse_args()
 
 
@@ -49,7 +49,7 @@ def cpu_baseline(size, frames):
     """oracle step (torch CPU fp32) on `frames` frames: the reported CPU baseline ("port")."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from oracle import hidden_ref, jpeg_ref
-    cores = os.cpu_count() or 1
+    cores = min(32, os.cpu_count() or 1)  # torch CPU conv does not scale past a few dozen threads (256 threads: 20x slower)
     torch.set_num_threads(cores)
     torch.manual_seed(10)
     cfg = hidden_ref.HiDDenConfiguration(H=size, W=size)
