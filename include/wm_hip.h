@@ -151,6 +151,8 @@ int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* in_scale, co
 /* ------------------------------------------------------------------ BatchNorm2d (training)
  * replaces nn.BatchNorm2d + nn.ReLU of conv_bn_relu.py:12-14 / UNet.py:67-97.
  * finalize: partial sums -> batch mean / biased var; scale = gamma*invstd,
+ * (every *_finalize / colsum call treats its `partials` buffer as scratch: with more than 64 rows
+ * it first folds them in place to 64 rows, so the pointer is const only in name),
  * shift = beta - mean*scale; running stats updated with `momentum` and the unbiased var
  * (count/(count-1)), as torch does.  C real channels, CP padded (scale=shift=0 there). */
 int wm_bn_finalize(const float* partials, int nparts, int C, int CP, double count, const float* gamma,

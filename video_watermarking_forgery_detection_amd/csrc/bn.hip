@@ -14,6 +14,33 @@ namespace {
 
 constexpr int RED_THREADS = 256;
 
+// ------------------------------------------------------------------ partial-row reduction helpers
+// rows[n][W] -> rows[0..R)[W] in place: output row j = sum of rows j, j+R, j+2R, ...  (block j only ever
+// touches rows congruent to j, so reading and writing the same buffer is race-free).  Keeps the
+// finalisation kernels short: they then walk at most R = 64 rows.
+constexpr int TREE_ROWS = 64;
+__global__ __launch_bounds__(256) void tree_reduce_rows_kernel(float* __restrict__ rows, int n, int W) {
+    const int j = blockIdx.x;
+    for (int c = threadIdx.x; c < W; c += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int r = j;
+        for (; r + 3 * TREE_ROWS < n; r += 4 * TREE_ROWS) {
+            a0 += rows[(size_t)r * W + c];
+            a1 += rows[(size_t)(r + TREE_ROWS) * W + c];
+            a2 += rows[(size_t)(r + 2 * TREE_ROWS) * W + c];
+            a3 += rows[(size_t)(r + 3 * TREE_ROWS) * W + c];
+        }
+        for (; r < n; r += TREE_ROWS) a0 += rows[(size_t)r * W + c];
+        rows[(size_t)j * W + c] = (a0 + a1) + (a2 + a3);
+    }
+}
+// returns the number of rows left
+inline int tree_reduce_rows(float* rows, int n, int W, hipStream_t s) {
+    if (n <= TREE_ROWS) return n;
+    hipLaunchKernelGGL(tree_reduce_rows_kernel, dim3(TREE_ROWS), dim3(256), 0, s, rows, n, W);
+    return TREE_ROWS;
+}
+
 // ------------------------------------------------------------------ forward statistics
 // partials: [nparts][2][CP] (sum, sum of squares).  One workgroup per 32 channels, 8 slices of parts.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nparts, int C, int CP,
@@ -242,6 +269,7 @@ extern "C" int wm_bn_finalize(const float* partials, int nparts, int C, int CP, 
     WM_REQUIRE(partials && gamma && beta && scale && shift && mean && invstd, WM_E_BADARG, "wm_bn_finalize: null pointer");
     WM_REQUIRE(nparts > 0 && C > 0 && CP >= C && count > 0, WM_E_BADARG, "wm_bn_finalize: bad sizes");
     WM_REQUIRE((running_mean == nullptr) == (running_var == nullptr), WM_E_BADARG, "wm_bn_finalize: running stats must come together");
+    nparts = tree_reduce_rows(const_cast<float*>(partials), nparts, 2 * CP, (hipStream_t)stream);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(wm_cdiv(CP, 32)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C, CP,
                        count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
     WM_LAUNCH_CHECK("wm_bn_finalize");
@@ -274,6 +302,7 @@ extern "C" int wm_bn_bwd_finalize(const float* partials, int nparts, int C, int 
                                   const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef,
                                   void* stream) {
     WM_REQUIRE(partials && gamma && invstd && coef, WM_E_BADARG, "wm_bn_bwd_finalize: null pointer");
+    nparts = tree_reduce_rows(const_cast<float*>(partials), nparts, 2 * CP, (hipStream_t)stream);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(wm_cdiv(CP, 32)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C,
                        CP, count, gamma, invstd, dgamma, dbeta, accumulate, coef);
     WM_LAUNCH_CHECK("wm_bn_bwd_finalize");
@@ -299,6 +328,7 @@ extern "C" int wm_bn_bwd_apply(const void* g, int ldg, const float* gvec, const 
 extern "C" int wm_colsum_finalize(const float* partials, int nparts, int C, int ldp, float* out, int accumulate,
                                   void* stream) {
     WM_REQUIRE(partials && out && nparts > 0 && C > 0 && ldp >= C, WM_E_BADARG, "wm_colsum_finalize: bad arguments");
+    nparts = tree_reduce_rows(const_cast<float*>(partials), nparts, ldp, (hipStream_t)stream);
     hipLaunchKernelGGL(colsum_kernel, dim3(wm_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C, ldp, out,
                        accumulate, 1.0f, (size_t)0, (size_t)0);
     WM_LAUNCH_CHECK("wm_colsum_finalize");

@@ -183,8 +183,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             for (int qq = 0; qq < Cin; ++qq)
                 if (perm[qq] == cip) { ci = qq; break; }
         if (ci < 0) continue;
-        double s = 0.0;
-        for (int k = 0; k < nslabs; ++k) s += (double)ws[(size_t)k * slab_elems + i];
+        // independent partial sums keep 8 loads in flight (the loop is latency-bound otherwise)
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p5 = 0.f, p6 = 0.f, p7 = 0.f;
+        int k = 0;
+        for (; k + 8 <= nslabs; k += 8) {
+            const float* q = ws + (size_t)k * slab_elems + i;
+            p0 += q[0]; p1 += q[slab_elems]; p2 += q[2 * slab_elems]; p3 += q[3 * slab_elems];
+            p4 += q[4 * slab_elems]; p5 += q[5 * slab_elems]; p6 += q[6 * slab_elems]; p7 += q[7 * slab_elems];
+        }
+        for (; k < nslabs; ++k) p0 += ws[(size_t)k * slab_elems + i];
+        const double s = ((double)p0 + (double)p1) + ((double)p2 + (double)p3) + ((double)p4 + (double)p5) + ((double)p6 + (double)p7);
         float* o = dw + (((size_t)co * Cin + ci) * 9 + tap);
         *o = (accumulate ? *o : 0.f) + (float)s;
     }

@@ -247,7 +247,8 @@ def conv1x1_head_bwd(y, scale, shift, w, gout, dw, dbias, accumulate):
     _lib.check(rc, "wm_conv1x1_head_bwd")
     ldp = Cout * (Cin + 1)
     colsum(part, Cout * Cin, ldp, dw, accumulate)
-    colsum(part[:, Cout * Cin:], Cout, ldp, dbias, accumulate)
+    # the first call folded the rows in place to <= 64 (wm_colsum_finalize treats partials as scratch)
+    colsum(part[:min(nparts, 64), Cout * Cin:], Cout, ldp, dbias, accumulate)
     return g
 
 
