@@ -84,16 +84,16 @@ int wm_median_bwd(const float* gy, const int8_t* idx, float* gx, int N, int H, i
 /* bicubic (A=-0.75, align_corners=False, no antialias) and bilinear resampling of the
  * sub-rectangle [h0,h0+hs) x [w0,w0+ws) of x[N,H,W] to y[N,OH,OW]; replaces
  * F.interpolate in noise_layers/resize.py:42-51 and noise_layers/crop.py:48-53.
- * clamp01 != 0 clamps the output to [0,1] (resize.py:53).  The backward is the transpose
- * (gather form, deterministic); gy_mask_src (may be NULL) is the un-clamped forward output,
- * used to zero the gradient where the clamp was active. */
+ * clamp01 != 0 clamps the output to [0,1] (resize.py:53).  The backward is the transpose in
+ * gather form (deterministic, no atomics): gx[N,H,W] gets zero outside the rectangle;
+ * y_clamped (may be NULL) is the clamped forward output: where it is not strictly inside (0,1)
+ * the clamp was active and the incoming gradient is dropped. */
 #define WM_BILINEAR 0
 #define WM_BICUBIC 1
 int wm_resample_fwd(const float* x, float* y, int N, int H, int W, int h0, int hs, int w0, int ws,
                     int OH, int OW, int kind, int clamp01, void* stream);
-int wm_resample_bwd(const float* gy, const float* y_unclamped, float* gx, int N, int H, int W,
-                    int h0, int hs, int w0, int ws, int OH, int OW, int kind, int clamp01,
-                    void* stream);
+int wm_resample_bwd(const float* gy, const float* y_clamped, float* gx, int N, int H, int W,
+                    int h0, int hs, int w0, int ws, int OH, int OW, int kind, void* stream);
 /* Quantization: round(255 x)/255; replaces models/modules/Quantization.py:7-14 (the backward
  * is the identity and needs no kernel). */
 int wm_quant_fwd(const float* x, float* y, size_t n, void* stream);

@@ -14,4 +14,8 @@ def get_random_int(int_range):
 from .identity import Identity  # noqa: E402
 from .jpeg import Jpeg, JpegSS, JpegMask, JpegBasic  # noqa: E402
 from .combined import Combined  # noqa: E402
+from .gaussian_blur import GaussianBlur  # noqa: E402
+from .middle_filter import MiddleBlur  # noqa: E402
+from .resize import Resize  # noqa: E402
+from .crop import Crop  # noqa: E402
 from .noiser import Noiser  # noqa: E402

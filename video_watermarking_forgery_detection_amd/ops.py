@@ -320,3 +320,73 @@ def _timed(name, info, launch):
     b.record()
     t.pairs.append((a, b))
     return r
+
+
+# ----------------------------------------------------------------------------- stencil / resample attacks
+BILINEAR, BICUBIC = 0, 1
+
+
+def _planes(x):
+    _need_cuda(x)
+    assert x.dim() == 4 and x.dtype == torch.float32
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    return x, B * C, H, W
+
+
+def stencil3(x, w9):
+    x, N, H, W = _planes(x)
+    y = torch.empty_like(x)
+    rc = _lib.lib().wm_stencil3_fwd(_p(x), _p(y), c_int(N), c_int(H), c_int(W), _host_floats(w9), _stream())
+    _lib.check(rc, "wm_stencil3_fwd")
+    return y
+
+
+def median_fwd(x, k, want_idx=True):
+    x, N, H, W = _planes(x)
+    y = torch.empty_like(x)
+    idx = torch.empty(x.shape, device=x.device, dtype=torch.int8) if want_idx else None
+    rc = _lib.lib().wm_median_fwd(_p(x), _p(y), _p(idx), c_int(N), c_int(H), c_int(W), c_int(k), _stream())
+    _lib.check(rc, "wm_median_fwd")
+    return y, idx
+
+
+def median_bwd(gy, idx, k):
+    gy, N, H, W = _planes(gy)
+    gx = torch.empty_like(gy)
+    rc = _lib.lib().wm_median_bwd(_p(gy), _p(idx), _p(gx), c_int(N), c_int(H), c_int(W), c_int(k), _stream())
+    _lib.check(rc, "wm_median_bwd")
+    return gx
+
+
+def resample_fwd(x, rect, out_hw, kind, clamp01=False):
+    """rect = (h0, hs, w0, ws) sub-rectangle of x resampled to out_hw."""
+    x, N, H, W = _planes(x)
+    h0, hs, w0, ws = rect
+    OH, OW = out_hw
+    y = torch.empty(x.shape[0], x.shape[1], OH, OW, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().wm_resample_fwd(_p(x), _p(y), c_int(N), c_int(H), c_int(W), c_int(h0), c_int(hs), c_int(w0), c_int(ws),
+                                    c_int(OH), c_int(OW), c_int(kind), c_int(1 if clamp01 else 0), _stream())
+    _lib.check(rc, "wm_resample_fwd")
+    return y
+
+
+def resample_bwd(gy, y_clamped, in_hw, rect, kind):
+    gy, N, OH, OW = _planes(gy)
+    H, W = in_hw
+    h0, hs, w0, ws = rect
+    gx = torch.empty(gy.shape[0], gy.shape[1], H, W, device=gy.device, dtype=torch.float32)
+    yc = y_clamped.contiguous() if y_clamped is not None else None
+    rc = _lib.lib().wm_resample_bwd(_p(gy), _p(yc), _p(gx), c_int(N), c_int(H), c_int(W), c_int(h0), c_int(hs), c_int(w0),
+                                    c_int(ws), c_int(OH), c_int(OW), c_int(kind), _stream())
+    _lib.check(rc, "wm_resample_bwd")
+    return gx
+
+
+def quant(x):
+    _need_cuda(x)
+    x = x.contiguous().float()
+    y = torch.empty_like(x)
+    rc = _lib.lib().wm_quant_fwd(_p(x), _p(y), c_size_t(x.numel()), _stream())
+    _lib.check(rc, "wm_quant_fwd")
+    return y
