@@ -216,7 +216,13 @@ int wm_maxpool2_bwd(const void* y, int ldy, const float* scale, const float* shi
 int wm_upconv2x2_fwd(const void* x, int ldx, const float* scale, const float* shift, const float* w,
                      const float* bias, void* y, int ldy, int c0, int B, int H, int W, int Cin, int Cout,
                      int dtype, void* stream);
-int wm_upconv2x2_bwd(const void* x, int ldx, const float* scale, const float* shift, const float* w,
+/* backward: gx = gradient wrt the (activated) input, NHWC [B,H,W,Cin]; w_t = the weight
+ * rearranged to [(i,j,co)][Cin] f32 (weight.permute(2,3,1,0)); dw_partials f32
+ * [wm_upconv2x2_dw_chunks(B,H,W)][Cin+1][4*Cout]: per-chunk partial sums of the weight gradient in
+ * PyTorch order (row ci, column co*4+i*2+j) with the per-column sums of gy in the extra row Cin
+ * (bias gradient = sum over the 4 taps); reduce with wm_colsum_finalize. */
+int wm_upconv2x2_dw_chunks(int B, int H, int W);
+int wm_upconv2x2_bwd(const void* x, int ldx, const float* scale, const float* shift, const float* w_t,
                      const void* gy, int ldgy, int c0, void* gx, int ldgx, float* dw_partials,
                      int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
 

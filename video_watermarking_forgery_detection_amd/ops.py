@@ -390,3 +390,68 @@ def quant(x):
     rc = _lib.lib().wm_quant_fwd(_p(x), _p(y), c_size_t(x.numel()), _stream())
     _lib.check(rc, "wm_quant_fwd")
     return y
+
+
+# ----------------------------------------------------------------------------- UNet pieces
+def bnrelu_maxpool2(y, scale, shift, C, act_out=None, act_c0=0):
+    """y [B,H,W,ld] raw conv output -> pooled activated [B,H/2,W/2,C]; optionally writes the activated
+    full-resolution map into act_out[..., act_c0:act_c0+C] (the skip half of a concat buffer)."""
+    B, H, W, ld = y.shape
+    pooled = torch.empty(B, H // 2, W // 2, C, device=y.device, dtype=y.dtype)
+    rc = _lib.lib().wm_bnrelu_maxpool2(_p(y), c_int(ld), _p(scale), _p(shift), _p(pooled), c_int(C), _p(act_out),
+                                       c_int(0 if act_out is None else act_out.shape[-1]), c_int(act_c0), c_int(B), c_int(H),
+                                       c_int(W), c_int(C), c_int(dtype_id(y)), _stream())
+    _lib.check(rc, "wm_bnrelu_maxpool2")
+    return pooled
+
+
+def maxpool2_bwd(y, scale, shift, gpooled, g_skip, g_skip_c0, C):
+    """gradient wrt the activated full-resolution map: skip gradient (slice of a concat gradient) + pooled path."""
+    B, H, W, ld = y.shape
+    g = torch.empty(B, H, W, C, device=y.device, dtype=y.dtype)
+    gs_ptr = None
+    ldgs = 0
+    if g_skip is not None:
+        ldgs = g_skip.shape[-1]
+        gs_ptr = ctypes.c_void_p(g_skip.data_ptr() + g_skip_c0 * g_skip.element_size())
+    rc = _lib.lib().wm_maxpool2_bwd(_p(y), c_int(ld), _p(scale), _p(shift), _p(gpooled), c_int(gpooled.shape[-1]), gs_ptr,
+                                    c_int(ldgs), _p(g), c_int(C), c_int(B), c_int(H), c_int(W), c_int(C), c_int(dtype_id(y)),
+                                    _stream())
+    _lib.check(rc, "wm_maxpool2_bwd")
+    return g
+
+
+def upconv2x2_fwd(x, scale, shift, w, bias, out, c0):
+    """x [B,H,W,Cin] (raw + pending BN/ReLU) ; w [Cin,Cout,2,2] f32 -> writes out[B,2H,2W,ld] channels [c0,c0+Cout)."""
+    B, H, W, ldx = x.shape
+    Cin, Cout = w.shape[0], w.shape[1]
+    rc = _lib.lib().wm_upconv2x2_fwd(_p(x), c_int(ldx), _p(scale), _p(shift), _p(w), _p(bias), _p(out), c_int(out.shape[-1]),
+                                     c_int(c0), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(Cout), c_int(dtype_id(x)), _stream())
+    _lib.check(rc, "wm_upconv2x2_fwd")
+    return out
+
+
+def upconv2x2_bwd(x, scale, shift, w, gy, c0, dw, dbias, accumulate):
+    """returns gx [B,H,W,Cin]; writes dw [Cin,Cout,2,2], dbias [Cout]."""
+    B, H, W, ldx = x.shape
+    Cin, Cout = w.shape[0], w.shape[1]
+    L = _lib.lib()
+    chunks = L.wm_upconv2x2_dw_chunks(c_int(B), c_int(H), c_int(W))
+    N = 4 * Cout
+    part = torch.empty(chunks, (Cin + 1) * N, device=x.device, dtype=torch.float32)
+    w_t = w.permute(2, 3, 1, 0).reshape(N, Cin).contiguous()
+    gx = torch.empty(B, H, W, Cin, device=x.device, dtype=x.dtype)
+    rc = L.wm_upconv2x2_bwd(_p(x), c_int(ldx), _p(scale), _p(shift), _p(w_t), _p(gy), c_int(gy.shape[-1]), c_int(c0), _p(gx),
+                            c_int(Cin), _p(part), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(Cout), c_int(dtype_id(x)), _stream())
+    _lib.check(rc, "wm_upconv2x2_bwd")
+    red = torch.empty((Cin + 1) * N, device=x.device, dtype=torch.float32)
+    colsum(part, (Cin + 1) * N, (Cin + 1) * N, red, False)
+    gw = red[:Cin * N].view(Cin, Cout, 2, 2)
+    gb = red[Cin * N:].view(Cout, 4).sum(1)
+    if accumulate:
+        dw += gw
+        dbias += gb
+    else:
+        dw.copy_(gw)
+        dbias.copy_(gb)
+    return gx
