@@ -144,7 +144,10 @@ class Hidden:
         return _noise_fwd(n, enc, cover)
 
     # ------------------------------------------------------------------ the step
-    def train_on_batch(self, batch: list):
+    def train_on_batch(self, batch: list, extra_encoded_grad=None, clip=None):
+        """extra_encoded_grad: optional callable(encoded, images) -> (gradient wrt encoded, [(name, value)]), run
+        after the encoder forward (the tamper-localisation branch of models/IRNrhi_model.py);
+        clip: optional callable(flat_grad) applied before each optimiser step (clip_grad_norm_)."""
         images, messages = batch
         images = images.to(self.device, torch.float32).contiguous()
         messages = messages.to(self.device, torch.float32).contiguous()
@@ -172,6 +175,8 @@ class Hidden:
         D.bwd(c, g, gD, accumulate=True, need_input_grad=False)
         if self.grad_sync is not None:
             self.grad_sync(D.flat_grads)
+        if clip is not None:
+            clip(D.flat_grads)
         self.optimizer_discrim.step()
 
         # ---------------- train the generator (hidden.py:85-103)
@@ -190,10 +195,17 @@ class Hidden:
         g_noised = dec_net.bwd(cDec, g_dec, gDec, accumulate=False, need_input_grad=True)
         g_from_noise = _noise_bwd(ed.noiser, cN, g_noised)
         ops.axpy_(g_enc, g_from_noise.contiguous())
+        extra_logs = []
+        if extra_encoded_grad is not None:
+            g_extra, extra_logs = extra_encoded_grad(encoded, images)
+            ops.axpy_(g_enc, g_extra)
         enc_net.bwd(cE, g_enc, gE, accumulate=False)
         if self.grad_sync is not None:
             self.grad_sync(enc_net.flat_grads)
             self.grad_sync(dec_net.flat_grads)
+        if clip is not None:
+            clip(enc_net.flat_grads)
+            clip(dec_net.flat_grads)
         self.optimizer_enc_dec.step()
 
         # ---------------- metrics: one host sync for all seven scalars (hidden.py:105-117)
@@ -212,6 +224,8 @@ class Hidden:
             'discr_cover_bce': vals[5],
             'discr_encod_bce': vals[6],
         }
+        if extra_logs:
+            losses['_extra'] = extra_logs
         return losses, (encoded, noised, decoded)
 
     def validate_on_batch(self, batch: list):
