@@ -353,6 +353,254 @@ __global__ __launch_bounds__(256) void jpeg_bwd_kernel(const float* __restrict__
     store_rows(gx, t, H, W, g);
 }
 
+
+// =====================================================================================================
+// DiffJPEG (utils/JPEG.py:115-540 of the reference): JFIF colour matrices with +128 offsets, 2x2 average
+// chroma subsampling, 8x8 DCT on Y (full res) and Cb/Cr (half res), transposed tables * factor, selectable
+// rounding, nearest chroma up-sampling, clamp to [0,255].  H, W multiples of 16.
+//
+// One wave owns a 64 x 16 pixel strip = 4 MCUs.  The (row r, block blk) lane layout of the block-JPEG
+// kernel is reused with the three "channels" of dct2d3 re-purposed as
+//     v[0] = Y row r of block blk in the upper 8 rows,  v[1] = same in the lower 8 rows,
+//     v[2] = row r of a half-resolution chroma block: Cb of MCU blk (blk < 4) or Cr of MCU blk-4
+// so a single dct2d3 / idct2d3 call transforms all six blocks of every MCU.
+struct DiffTables { float t[128]; };  // y_table*factor [64], c_table*factor [64], row-major [u][v]
+
+template <int RND> __device__ __forceinline__ float dj_round(float q) {
+    if (RND == 0) return rintf(q);
+    if (RND == 1) return (fabsf(q) < 0.5f) ? q * q * q : q;       // round_only_at_0, JPEG.py:482-484
+    const float r = rintf(q);                                      // diff_round, JPEG.py:472-479
+    return r + (q - r) * (q - r) * (q - r);
+}
+template <int RND> __device__ __forceinline__ float dj_round_grad(float q) {
+    if (RND == 0) return 0.f;
+    if (RND == 1) return (fabsf(q) < 0.5f) ? 3.f * q * q : 1.f;
+    const float d = q - rintf(q);
+    return 3.f * d * d;
+}
+
+struct DjTask { int b, y0, x0; bool valid; };
+__device__ __forceinline__ DjTask dj_task(int B, int H, int W) {
+    const int Hs = H >> 4, Ws = (W + 63) >> 6;
+    const long total = (long)B * Hs * Ws;
+    const long wid = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    DjTask t;
+    t.valid = wid < total;
+    const long w = t.valid ? wid : 0;
+    t.x0 = (int)(w % Ws) * 64;
+    t.y0 = (int)((w / Ws) % Hs) * 16;
+    t.b = (int)(w / ((long)Ws * Hs));
+    return t;
+}
+
+// JPEG.py:121-130 on x*255
+__device__ __forceinline__ void dj_ycc(float R, float G, float B, float& Y, float& Cb, float& Cr) {
+    Y = 0.299f * R + 0.587f * G + 0.114f * B;
+    Cb = -0.168736f * R - 0.331264f * G + 0.5f * B + 128.f;
+    Cr = 0.5f * R - 0.418688f * G - 0.081312f * B + 128.f;
+}
+
+// loads the strip into v[0], v[1] (Y - 128) and v[2] (avg-pooled chroma - 128) for lane (r, blk)
+__device__ __forceinline__ void dj_load(const float* __restrict__ x, const DjTask& t, int H, int W, int r, int blk,
+                                        float (&v)[3][8]) {
+    const size_t plane = (size_t)H * W;
+    const float* base = x + (size_t)t.b * 3 * plane;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int yy = t.y0 + 8 * s + r, xx = t.x0 + 8 * blk;
+        const bool ok = t.valid && xx < W;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float Y = 128.f, Cb, Cr;
+            if (ok) {
+                const size_t o = (size_t)yy * W + xx + j;
+                dj_ycc(base[o] * 255.f, base[plane + o] * 255.f, base[2 * plane + o] * 255.f, Y, Cb, Cr);
+            }
+            v[s][j] = Y - 128.f;
+        }
+    }
+    const int m = blk & 3;
+    const bool cr_lane = blk >= 4;
+    const int xx = t.x0 + 16 * m, yy = t.y0 + 2 * r;
+    const bool ok = t.valid && xx < W;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float acc = 0.f;
+        if (ok) {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const size_t o = (size_t)(yy + dy) * W + xx + 2 * j + dx;
+                    float Y, Cb, Cr;
+                    dj_ycc(base[o] * 255.f, base[plane + o] * 255.f, base[2 * plane + o] * 255.f, Y, Cb, Cr);
+                    acc += cr_lane ? Cr : Cb;
+                }
+            acc *= 0.25f;
+        } else acc = 128.f;
+        v[2][j] = acc - 128.f;
+    }
+}
+
+// chroma exchange: lanes publish their chroma row, every lane picks the (nearest-upsampled) Cb/Cr of its two Y rows
+__device__ __forceinline__ void dj_chroma_to_y(const float (&c)[8], float* lds, int r, int blk, float (&cb)[2][8],
+                                               float (&cr)[2][8]) {
+    float* p = lds + blk * 64 + r * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = c[j];
+    wave_lds_sync();
+    const int m = blk >> 1, half = (blk & 1) * 4;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int crow = 4 * s + (r >> 1);
+        const float* pb = lds + m * 64 + crow * 8 + half;
+        const float* pr = lds + (m + 4) * 64 + crow * 8 + half;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { cb[s][j] = pb[j >> 1]; cr[s][j] = pr[j >> 1]; }
+    }
+    wave_lds_sync();
+}
+
+// forward core shared by both kernels: leaves q (pre-rounding coefficients, column layout) in `q` and the
+// unclamped 0..255 RGB of the lane's two rows in rgb[s][c][j]
+template <int RND>
+__device__ __forceinline__ void dj_forward(const float* __restrict__ x, const DjTask& t, int H, int W, int r, int blk,
+                                           float* lds, const float* s_tbl, float (&q)[3][8], float (&rgb)[2][3][8]) {
+    float v[3][8];
+    dj_load(x, t, H, W, r, blk, v);
+    dct2d3(v, lds, r, blk);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float tq = s_tbl[(c == 2 ? 64 : 0) + u * 8 + r];
+            q[c][u] = v[c][u] / tq;
+            v[c][u] = dj_round<RND>(q[c][u]) * tq;
+        }
+    idct2d3(v, lds, r, blk);
+    float cbv[2][8], crv[2][8];
+    float chroma[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) chroma[j] = v[2][j] + 128.f;
+    dj_chroma_to_y(chroma, lds, r, blk, cbv, crv);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float Y = v[s][j] + 128.f, Cb = cbv[s][j] - 128.f, Cr = crv[s][j] - 128.f;  // JPEG.py:419-426
+            rgb[s][0][j] = Y + 1.402f * Cr;
+            rgb[s][1][j] = Y - 0.344136f * Cb - 0.714136f * Cr;
+            rgb[s][2][j] = Y + 1.772f * Cb;
+        }
+}
+
+template <int RND>
+__global__ __launch_bounds__(256) void diffjpeg_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H,
+                                                            int W, DiffTables tb) {
+    __shared__ __attribute__((aligned(16))) float s_lds[4 * LDS_WAVE];
+    __shared__ float s_tbl[128];
+    if (threadIdx.x < 128) s_tbl[threadIdx.x] = tb.t[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane >> 3, blk = lane & 7;
+    float* lds = s_lds + (threadIdx.x >> 6) * LDS_WAVE;
+    const DjTask t = dj_task(B, H, W);
+    float q[3][8], rgb[2][3][8];
+    dj_forward<RND>(x, t, H, W, r, blk, lds, s_tbl, q, rgb);
+    const size_t plane = (size_t)H * W;
+    const int xx = t.x0 + 8 * blk;
+    if (t.valid && xx < W) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float* p = y + ((size_t)t.b * 3 + c) * plane + (size_t)(t.y0 + 8 * s + r) * W + xx;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p[j] = fminf(255.f, fmaxf(0.f, rgb[s][c][j])) / 255.f;  // JPEG.py:467-469
+            }
+    }
+}
+
+template <int RND>
+__global__ __launch_bounds__(256) void diffjpeg_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                            float* __restrict__ gx, int B, int H, int W, DiffTables tb) {
+    __shared__ __attribute__((aligned(16))) float s_lds[4 * LDS_WAVE];
+    __shared__ float s_tbl[128];
+    if (threadIdx.x < 128) s_tbl[threadIdx.x] = tb.t[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane >> 3, blk = lane & 7;
+    float* lds = s_lds + (threadIdx.x >> 6) * LDS_WAVE;
+    const DjTask t = dj_task(B, H, W);
+    const size_t plane = (size_t)H * W;
+    const int xx = t.x0 + 8 * blk;
+    const bool ok = t.valid && xx < W;
+    float q[3][8], rgb[2][3][8];
+    dj_forward<RND>(x, t, H, W, r, blk, lds, s_tbl, q, rgb);
+    // ---- d rgb (clamp mask, /255) -> dY per pixel, dCb/dCr per pixel
+    float g[3][8];
+    float dcb[2][8], dcr[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float d[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float gv = 0.f;
+                if (ok) gv = gy[((size_t)t.b * 3 + c) * plane + (size_t)(t.y0 + 8 * s + r) * W + xx + j];
+                const float o = rgb[s][c][j];
+                d[c] = (o >= 0.f && o <= 255.f) ? gv / 255.f : 0.f;   // torch.min/max pass the gradient inside the range
+            }
+            g[s][j] = d[0] + d[1] + d[2];
+            dcb[s][j] = -0.344136f * d[1] + 1.772f * d[2];
+            dcr[s][j] = 1.402f * d[0] - 0.714136f * d[1];
+        }
+    // ---- nearest up-sampling^T: every chroma sample collects its 2x2 pixels.  Layout [kind][s][r][blk][4]
+    {
+        float* pb = lds + ((0 * 2 + 0) * 8 + r) * 32 + blk * 4;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pb[((0 * 2 + s) * 8) * 32 + k] = dcb[s][2 * k] + dcb[s][2 * k + 1];
+                pb[((1 * 2 + s) * 8) * 32 + k] = dcr[s][2 * k] + dcr[s][2 * k + 1];
+            }
+        wave_lds_sync();
+        const int kind = blk >> 2, m = blk & 3, s = r >> 2, r0 = 2 * (r & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int yb = 2 * m + (j >> 2), k = j & 3;
+            const float* pq = lds + (((kind * 2 + s) * 8 + r0) * 8 + yb) * 4 + k;
+            g[2][j] = pq[0] + pq[32];  // rows r0 and r0+1
+        }
+        wave_lds_sync();
+    }
+    // ---- IDCT^T = DCT, rounding derivative, DCT^T = IDCT
+    dct2d3(g, lds, r, blk);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g[c][u] *= dj_round_grad<RND>(q[c][u]);
+    idct2d3(g, lds, r, blk);
+    // ---- avg-pool^T (x 1/4) + chroma exchange, colour transform^T, x255
+    float chroma[8], gcb[2][8], gcr[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) chroma[j] = 0.25f * g[2][j];
+    dj_chroma_to_y(chroma, lds, r, blk, gcb, gcr);
+    if (ok) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float* p = gx + (size_t)t.b * 3 * plane + (size_t)(t.y0 + 8 * s + r) * W + xx;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dY = g[s][j], dCb = gcb[s][j], dCr = gcr[s][j];
+                p[j] = (0.299f * dY - 0.168736f * dCb + 0.5f * dCr) * 255.f;
+                p[plane + j] = (0.587f * dY - 0.331264f * dCb - 0.418688f * dCr) * 255.f;
+                p[2 * plane + j] = (0.114f * dY + 0.5f * dCb - 0.081312f * dCr) * 255.f;
+            }
+        }
+    }
+}
+
 int check_args(const char* name, const void* a, const void* b, int B, int H, int W, int mode, const float* tables,
                int subsample) {
     WM_REQUIRE(a && b, WM_E_BADARG, "%s: null tensor pointer", name);
@@ -407,5 +655,60 @@ extern "C" int wm_jpeg_bwd(const float* x, const float* gy, float* gx, int B, in
     }
 #undef L
     WM_LAUNCH_CHECK("wm_jpeg_bwd");
+    return WM_OK;
+}
+
+
+static int dj_check(const char* name, const void* a, const void* b, int B, int H, int W, int rounding, float factor) {
+    WM_REQUIRE(a && b, WM_E_BADARG, "%s: null tensor pointer", name);
+    WM_REQUIRE(B > 0 && H > 0 && W > 0, WM_E_BADARG, "%s: bad shape", name);
+    WM_REQUIRE(H % 16 == 0 && W % 16 == 0, WM_E_SHAPE, "%s: H, W must be multiples of 16 (got %dx%d), like the reference's block split", name, H, W);
+    WM_REQUIRE(rounding >= 0 && rounding <= 2, WM_E_BADARG, "%s: rounding must be 0 (round), 1 (round_only_at_0) or 2 (diff_round)", name);
+    WM_REQUIRE(factor > 0.f, WM_E_BADARG, "%s: factor must be positive", name);
+    return WM_OK;
+}
+
+static void dj_tables(float factor, DiffTables& tb) {
+    // utils/JPEG.py:96-108: the standard tables, TRANSPOSED; chroma = 99 with a transposed 4x4 corner
+    static const float lum[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
+                                  14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+                                  49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+    static const float c4[16] = {17, 18, 24, 47, 18, 21, 26, 66, 24, 26, 56, 99, 47, 66, 99, 99};
+    for (int u = 0; u < 8; ++u)
+        for (int v = 0; v < 8; ++v) {
+            tb.t[u * 8 + v] = lum[v * 8 + u] * factor;
+            tb.t[64 + u * 8 + v] = ((u < 4 && v < 4) ? c4[v * 4 + u] : 99.f) * factor;
+        }
+}
+
+extern "C" int wm_diffjpeg_fwd(const float* x, float* y, int B, int H, int W, int rounding, float factor, void* stream) {
+    int rc = dj_check("wm_diffjpeg_fwd", x, y, B, H, W, rounding, factor);
+    if (rc) return rc;
+    DiffTables tb;
+    dj_tables(factor, tb);
+    const long waves = (long)B * (H / 16) * ((W + 63) / 64);
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (rounding == 0) hipLaunchKernelGGL(diffjpeg_fwd_kernel<0>, grid, block, 0, s, x, y, B, H, W, tb);
+    else if (rounding == 1) hipLaunchKernelGGL(diffjpeg_fwd_kernel<1>, grid, block, 0, s, x, y, B, H, W, tb);
+    else hipLaunchKernelGGL(diffjpeg_fwd_kernel<2>, grid, block, 0, s, x, y, B, H, W, tb);
+    WM_LAUNCH_CHECK("wm_diffjpeg_fwd");
+    return WM_OK;
+}
+
+extern "C" int wm_diffjpeg_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int rounding, float factor,
+                               void* stream) {
+    int rc = dj_check("wm_diffjpeg_bwd", gy, gx, B, H, W, rounding, factor);
+    if (rc) return rc;
+    WM_REQUIRE(x, WM_E_BADARG, "wm_diffjpeg_bwd: x required (coefficients and the clamp mask are recomputed)");
+    DiffTables tb;
+    dj_tables(factor, tb);
+    const long waves = (long)B * (H / 16) * ((W + 63) / 64);
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (rounding == 0) hipLaunchKernelGGL(diffjpeg_bwd_kernel<0>, grid, block, 0, s, x, gy, gx, B, H, W, tb);
+    else if (rounding == 1) hipLaunchKernelGGL(diffjpeg_bwd_kernel<1>, grid, block, 0, s, x, gy, gx, B, H, W, tb);
+    else hipLaunchKernelGGL(diffjpeg_bwd_kernel<2>, grid, block, 0, s, x, gy, gx, B, H, W, tb);
+    WM_LAUNCH_CHECK("wm_diffjpeg_bwd");
     return WM_OK;
 }

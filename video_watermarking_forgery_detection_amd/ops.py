@@ -455,3 +455,28 @@ def upconv2x2_bwd(x, scale, shift, w, gy, c0, dw, dbias, accumulate):
         dw.copy_(gw)
         dbias.copy_(gb)
     return gx
+
+
+# ----------------------------------------------------------------------------- DiffJPEG
+ROUND, ROUND_ONLY_AT_0, DIFF_ROUND = 0, 1, 2
+
+
+def diffjpeg_fwd(x, rounding, factor):
+    _need_cuda(x)
+    assert x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.float32
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    B, _, H, W = x.shape
+    rc = _lib.lib().wm_diffjpeg_fwd(_p(x), _p(y), c_int(B), c_int(H), c_int(W), c_int(rounding), c_float(factor), _stream())
+    _lib.check(rc, "wm_diffjpeg_fwd")
+    return y
+
+
+def diffjpeg_bwd(x, gy, rounding, factor):
+    _need_cuda(x, gy)
+    x = x.contiguous(); gy = gy.contiguous()
+    gx = torch.empty_like(gy)
+    B, _, H, W = x.shape
+    rc = _lib.lib().wm_diffjpeg_bwd(_p(x), _p(gy), _p(gx), c_int(B), c_int(H), c_int(W), c_int(rounding), c_float(factor), _stream())
+    _lib.check(rc, "wm_diffjpeg_bwd")
+    return gx
