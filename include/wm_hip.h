@@ -128,11 +128,11 @@ int wm_pack_w3x3(const float* w, void* wp, int Cout, int Cin, int CoutP, int Cin
  *        zero padding is applied after that transform, as the reference pads the activated map.
  *   wp : packed weights from wm_pack_w3x3 (transpose=0), [9][CoutP][CinP]; CinP == Cin here.
  *   bias: f32[nbias] (nbias <= CoutP, the real Cout) or NULL.   y: NHWC [B,H,W,CoutP] stride ldy (raw conv output).
- *   stat_partials: NULL, or f32[wm_conv3x3_nparts(B,H,W)][2][CoutP]: per-workgroup sums of y
+ *   stat_partials: NULL, or f32[wm_conv3x3_nparts(B,H,W,Cin,CoutP,dtype)][2][CoutP]: per-workgroup sums of y
  *        and y^2 (from the f32 accumulators) for the BatchNorm batch statistics.
  * Cin multiple of 16 (bf16) / 8 (f32); CoutP multiple of 32.  The same entry point computes
  * dgrad when given dy and the transposed pack. */
-int wm_conv3x3_nparts(int B, int H, int W);
+int wm_conv3x3_nparts(int B, int H, int W, int Cin, int CoutP, int dtype);
 int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const float* bias, int nbias,
                    const float* in_scale, const float* in_shift, void* y, int ldy, float* stat_partials, int B, int H,
                    int W, int Cin, int CoutP, int dtype, void* stream);

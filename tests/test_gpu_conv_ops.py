@@ -31,6 +31,8 @@ CASES = [  # B, H, W, Cin, Cout
     (2, 16, 16, 112, 64),
     (1, 33, 16, 64, 32),
     (1, 16, 48, 32, 128),
+    (3, 100, 90, 64, 64),     # persistent 64-channel kernel, ragged tiles
+    (2, 256, 256, 64, 64),    # persistent kernel, 2 tiles per workgroup
 ]
 
 
@@ -77,7 +79,7 @@ def test_conv3x3_fused_input_transform(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(2, 20, 37, 64, 64), (1, 16, 16, 16, 64), (1, 24, 16, 64, 32)])
+@pytest.mark.parametrize("case", [(2, 20, 37, 64, 64), (1, 16, 16, 16, 64), (1, 24, 16, 64, 32), (5, 80, 112, 64, 64)])
 def test_conv3x3_dgrad(dtype, case):
     from video_watermarking_forgery_detection_amd import ops
     B, H, W, Cin, Cout = case

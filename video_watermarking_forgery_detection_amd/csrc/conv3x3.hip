@@ -98,37 +98,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs<T> a) {
         const int cbase = c0 + vec * VE;
         const bool cok = vec * VE < kvalid;
         float sc[VE], sh[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) { sc[i] = 0.f; sh[i] = 0.f; }
         if (XFORM && cok) {
 #pragma unroll
             for (int i = 0; i < VE; ++i) { sc[i] = a.in_scale[cbase + i]; sh[i] = a.in_shift[cbase + i]; }
         }
         __syncthreads();  // previous chunk fully consumed
         // ---- stage the input halo tile: 18x18 pixels x CK channels
-        for (int i = tid; i < HH * HW * 4; i += 256) {
-            const int pix = i >> 2;
+        const int cload = cok ? cbase : 0;  // loads are unconditional (clamped address); validity is applied afterwards
+#pragma unroll
+        for (int it = 0; it < (HH * HW * 4 + 255) / 256; ++it) {
+            const int i = tid + it * 256;
+            const int pix = min(i >> 2, HH * HW - 1);
             const int py = pix / HW, px = pix - py * HW;
             const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
-            vec16<T> v;
-            const bool inb = cok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            if (inb) {
-                v = *reinterpret_cast<const vec16<T>*>(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldx + cbase);
-                if (XFORM) {
+            const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+            vec16<T> v = *reinterpret_cast<const vec16<T>*>(a.x + ((size_t)(b * a.H + gyc) * a.W + gxc) * a.ldx + cload);
+            const bool inb = cok && gy == gyc && gx == gxc;
 #pragma unroll
-                    for (int e = 0; e < VE; ++e) v.set(e, fmaxf(sc[e] * v.get(e) + sh[e], 0.f));
-                }
-            } else {
-                zero_vec(v);  // zero padding is applied AFTER the fused BN+ReLU, as the reference pads the activated map
+            for (int e = 0; e < VE; ++e) {
+                float f = v.get(e);
+                if (XFORM) f = fmaxf(sc[e] * f + sh[e], 0.f);
+                v.set(e, inb ? f : 0.f);  // zero padding is applied AFTER the fused BN+ReLU, as the reference pads the activated map
             }
-            *reinterpret_cast<vec16<T>*>(sA + pix * PS + vec * VE) = v;
+            if (i < HH * HW * 4) *reinterpret_cast<vec16<T>*>(sA + pix * PS + vec * VE) = v;
         }
         // ---- stage the weight slab [9][BN][CK]
-        for (int i = tid; i < 9 * BN * 4; i += 256) {
-            const int row = i >> 2;  // tap*BN + n
+#pragma unroll
+        for (int it = 0; it < (9 * BN * 4 + 255) / 256; ++it) {
+            const int i = tid + it * 256;
+            const int row = min(i >> 2, 9 * BN - 1);  // tap*BN + n
             const int tap = row / BN, n = row - tap * BN;
-            vec16<T> v;
-            if (cok) v = *reinterpret_cast<const vec16<T>*>(a.wp + ((size_t)tap * a.CoutP + n0 + n) * a.Cin + cbase);
-            else zero_vec(v);
-            *reinterpret_cast<vec16<T>*>(sB + row * PS + vec * VE) = v;
+            vec16<T> v = *reinterpret_cast<const vec16<T>*>(a.wp + ((size_t)tap * a.CoutP + n0 + n) * a.Cin + cload);
+            if (!cok) zero_vec(v);
+            if (i < 9 * BN * 4) *reinterpret_cast<vec16<T>*>(sB + row * PS + vec * VE) = v;
         }
         __syncthreads();
         // ---- 9 taps x K steps of MFMA
@@ -225,6 +229,218 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs<T> a) {
     }
 }
 
+// =====================================================================================================
+// Specialisation for the layers that dominate the step: bf16, Cin = Cout = 64 (all body layers of the
+// HiDDeN encoder / decoder / discriminator, forward and dgrad).  Differences from the generic kernel:
+//   * persistent workgroups (one per CU): the whole [9][64][64] filter (83 KB with row padding) is staged
+//     into LDS ONCE and stays resident while the workgroup walks a contiguous run of 16x16 tiles
+//     (one image row of tiles at 256x256, so consecutive tiles share their halo columns in L1/L2);
+//   * the 18x18x64 halo tile of the NEXT tile is prefetched into registers (11 x 16 B per lane) before the
+//     MFMA loop of the current tile, so HBM latency hides under 144 MFMAs per wave; BN+ReLU is applied when
+//     the registers are written to LDS;
+//   * all 64 input channels are one K chunk: 9 taps x 4 K-steps x (2 A + 2 B ds_read_b128, 4 MFMA 32x32x16);
+//   * BatchNorm partial sums are carried in registers across the workgroup's tiles: one partial row per
+//     workgroup (256 rows instead of one per tile).
+// LDS: filter 82,944 B + halo 46,656 B + 2 KB = 131.6 KB; two workgroup barriers per tile.
+constexpr int C64 = 64;
+constexpr int PS64 = 72;  // 144-byte rows: 16 consecutive pixels/filters hit 16 distinct 16-byte bank slots
+constexpr int XV = (HH * HW * 8 + 255) / 256;  // halo vectors per thread (11)
+
+template <bool XFORM>
+__global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(ConvArgs<bf16_t> a, const bf16_t* __restrict__ xin,
+                                                           bf16_t* __restrict__ yout, int ntiles, int tiles_per_wg) {
+    __shared__ __attribute__((aligned(16))) bf16_t sW[9 * C64 * PS64];
+    __shared__ __attribute__((aligned(16))) bf16_t sX[HH * HW * PS64];
+    __shared__ float sRed[4 * 2 * C64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int vec = tid & 7;  // this thread's 8-channel group (fixed: 256 % 8 == 0)
+
+    // ---- filter [9][64 co][64 ci] -> LDS, all loads in flight at once.  Output channel n is stored at row
+    // (n&1)*32 + (n>>1): MFMA column r of N-fragment nf is then channel 2r+nf, so a lane ends up holding two
+    // ADJACENT channels of a pixel and the epilogue can store 32-bit pairs, 128 contiguous bytes per pixel,
+    // straight from the accumulators (no LDS restage, no extra barriers).
+    {
+        constexpr int WV = 9 * C64 * 8 / 256;  // 18 vectors per thread
+        bf16x8 wv[WV];
+#pragma unroll
+        for (int k = 0; k < WV; ++k) {
+            const int i = tid + 256 * k;
+            wv[k] = *reinterpret_cast<const bf16x8*>(a.wp + (size_t)(i >> 3) * C64 + (i & 7) * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < WV; ++k) {
+            const int i = tid + 256 * k;
+            const int row = i >> 3, tap = row >> 6, n = row & 63;
+            *reinterpret_cast<bf16x8*>(sW + (tap * C64 + (n & 1) * 32 + (n >> 1)) * PS64 + (i & 7) * 8) = wv[k];
+        }
+    }
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+    if (XFORM) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = a.in_scale[vec * 8 + e]; sh[e] = a.in_shift[vec * 8 + e]; }
+    }
+    float bv[2];
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) bv[nf] = (a.bias && 2 * r + nf < a.nbias) ? a.bias[2 * r + nf] : 0.f;
+    float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};
+
+    const int t_begin = blockIdx.x * tiles_per_wg;
+    const int t_end = min(ntiles, t_begin + tiles_per_wg);
+
+    bf16x8 pre[XV];
+    unsigned pre_ok = 0;
+    auto prefetch = [&](int tile) {
+        int t = tile;
+        const int txi = t % a.tilesX; t /= a.tilesX;
+        const int tyi = t % a.tilesY; t /= a.tilesY;
+        const int b = t, ty0 = tyi * TH, tx0 = txi * TW;
+        pre_ok = 0;
+#pragma unroll
+        for (int k = 0; k < XV; ++k) {
+            // always load from a clamped (valid) address and keep validity as a bit: a load under a
+            // per-lane condition makes hipcc branch around it and wait for each one separately
+            const int v = tid + 256 * k;
+            const int pix = v >> 3;
+            const int pixc = min(pix, HH * HW - 1);
+            const int py = pixc / HW, px = pixc - py * HW;
+            const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+            const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+            pre[k] = *reinterpret_cast<const bf16x8*>(xin + ((size_t)(b * a.H + gyc) * a.W + gxc) * a.ldx + vec * 8);
+            if (pix < HH * HW && gy == gyc && gx == gxc) pre_ok |= 1u << k;
+        }
+    };
+    if (t_begin < t_end) prefetch(t_begin);
+
+    // The output of tile t is packed into 32 registers and STORED one iteration later, right after the
+    // prefetch of tile t+2 has been issued: loads and stores then both have a whole MFMA loop to complete, so
+    // the wait in front of the next halo write never stalls on store acknowledgements.
+    typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 outpk[32];
+    unsigned out_ok = 0;
+    bf16_t* out_base = nullptr;   // &y[b][ty0 + wave*4][tx0][2r] of the pending tile
+    bool pending = false;
+    auto flush = [&]() {
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int prow = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int dy = mf * 2 + (prow >> 4), dx = prow & 15;
+                if ((out_ok >> (mf * 16 + i)) & 1u)
+                    *reinterpret_cast<bf16x2*>(out_base + ((size_t)dy * a.W + dx) * a.ldy) = outpk[mf * 16 + i];
+            }
+    };
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        int t = tile;
+        const int txi = t % a.tilesX; t /= a.tilesX;
+        const int tyi = t % a.tilesY; t /= a.tilesY;
+        const int b = t, ty0 = tyi * TH, tx0 = txi * TW;
+        __syncthreads();  // every wave has finished the MFMA reads of the previous halo tile
+        // ---- registers -> LDS halo tile, fused BN+ReLU, zero padding AFTER the activation
+#pragma unroll
+        for (int k = 0; k < XV; ++k) {
+            const int v = tid + 256 * k;
+            const int pix = v >> 3;
+            bf16x8 o = pre[k];
+            const bool ok = (pre_ok >> k) & 1u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)o[e];
+                if (XFORM) f = fmaxf(sc[e] * f + sh[e], 0.f);
+                o[e] = (bf16_t)(ok ? f : 0.f);
+            }
+            if (pix < HH * HW) *reinterpret_cast<bf16x8*>(sX + pix * PS64 + vec * 8) = o;
+        }
+        __syncthreads();
+        if (tile + 1 < t_end) prefetch(tile + 1);  // in flight during the MFMA loop
+        if (pending) flush();                       // previous tile's output, also hidden under the MFMA loop
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+        const int apix0 = (wave * 4 + (r >> 4)) * HW + (r & 15);
+        // explicit software pipeline over the 36 (tap, k-step) pairs: the fragments of step s+1 are read from
+        // LDS before the four MFMAs of step s issue, so ds_read latency hides under the matrix pipe
+        bf16x8 af[2][2], bfr[2][2];
+        auto load_frags = [&](int sidx, int buf) {
+            const int tap = sidx >> 2, ks = sidx & 3;
+            const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf)
+                af[buf][mf] = *reinterpret_cast<const bf16x8*>(sX + (apix0 + (mf * 2 + kh) * HW + kw) * PS64 + ks * 16 + h * 8);
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+                bfr[buf][nf] = *reinterpret_cast<const bf16x8*>(sW + (tap * C64 + nf * 32 + r) * PS64 + ks * 16 + h * 8);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int sidx = 0; sidx < 36; ++sidx) {
+            const int cur = sidx & 1;
+            if (sidx + 1 < 36) load_frags(sidx + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads of step s+1 ahead of the MFMAs of step s
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf)
+                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][mf], bfr[cur][nf], acc[mf][nf], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- pack the outputs: lane (r,h) holds channels 2r, 2r+1 of 16 pixels per M fragment
+        out_ok = 0;
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int prow = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int gy = ty0 + wave * 4 + mf * 2 + (prow >> 4), gx = tx0 + (prow & 15);
+                const float v0 = acc[mf][0][i] + bv[0], v1 = acc[mf][1][i] + bv[1];
+                if (gy < a.H && gx < a.W) {
+                    st1[0] += v0; st2[0] += v0 * v0;
+                    st1[1] += v1; st2[1] += v1 * v1;
+                    out_ok |= 1u << (mf * 16 + i);
+                }
+                bf16x2 pk = {(bf16_t)v0, (bf16_t)v1};
+                outpk[mf * 16 + i] = pk;
+            }
+        }
+        out_base = yout + (((size_t)b * a.H + ty0 + wave * 4) * a.W + tx0) * a.ldy + 2 * r;
+        pending = true;
+    }
+    if (pending) flush();
+    if (a.stat) {
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+            float s1 = st1[nf] + __shfl_xor(st1[nf], 32, 64);
+            float s2 = st2[nf] + __shfl_xor(st2[nf], 32, 64);
+            if (h == 0) {
+                sRed[(wave * 2 + 0) * C64 + 2 * r + nf] = s1;
+                sRed[(wave * 2 + 1) * C64 + 2 * r + nf] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * C64) {
+            const int which = tid / C64, n = tid - which * C64;
+            a.stat[((size_t)blockIdx.x * 2 + which) * a.CoutP + n] =
+                sRed[(0 * 2 + which) * C64 + n] + sRed[(1 * 2 + which) * C64 + n] + sRed[(2 * 2 + which) * C64 + n] +
+                sRed[(3 * 2 + which) * C64 + n];
+        }
+    }
+}
+
+constexpr int C64_MAX_WGS = 256;  // one persistent workgroup per CU
+inline bool use_c64(int Cin, int CoutP, int dtype) { return dtype == WM_BF16 && Cin == 64 && CoutP == 64; }
+inline int c64_tiles_per_wg(int ntiles) { return (ntiles + C64_MAX_WGS - 1) / C64_MAX_WGS; }
+inline int c64_wgs(int ntiles) { const int per = c64_tiles_per_wg(ntiles); return (ntiles + per - 1) / per; }
+
 // ---- weight packing: PyTorch [Cout][Cin][3][3] f32 -> [9][RowsP][ColsP] T
 //   transpose == 0: rows = Cout, cols = packed Cin (perm applied), tap = kh*3+kw        (forward)
 //   transpose == 1: rows = packed Cin, cols = Cout, tap = (2-kh)*3+(2-kw)               (dgrad)
@@ -265,6 +481,16 @@ int launch_conv(const void* x, int ldx, const void* wp, const float* bias, int n
     a.y = (T*)y; a.ldy = ldy; a.stat = stat; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.CoutP = CoutP;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH);
     const bool xf = in_scale != nullptr;
+    if constexpr (sizeof(T) == 2) {
+        if (use_c64(Cin, CoutP, WM_BF16)) {
+            const int ntiles = B * a.tilesX * a.tilesY;
+            const int per = c64_tiles_per_wg(ntiles);
+            dim3 grid((unsigned)c64_wgs(ntiles)), block(256);
+            if (xf) hipLaunchKernelGGL((conv3x3_c64_kernel<true>), grid, block, 0, s, a, a.x, a.y, ntiles, per);
+            else hipLaunchKernelGGL((conv3x3_c64_kernel<false>), grid, block, 0, s, a, a.x, a.y, ntiles, per);
+            return WM_OK;
+        }
+    }
     const int BN = (CoutP % 64 == 0) ? 64 : 32;
     dim3 grid((unsigned)(B * a.tilesX * a.tilesY), (unsigned)(CoutP / BN)), block(256);
     if (BN == 64) {
@@ -279,7 +505,10 @@ int launch_conv(const void* x, int ldx, const void* wp, const float* bias, int n
 
 }  // namespace
 
-extern "C" int wm_conv3x3_nparts(int B, int H, int W) { return B * wm_cdiv(H, TH) * wm_cdiv(W, TW); }
+extern "C" int wm_conv3x3_nparts(int B, int H, int W, int Cin, int CoutP, int dtype) {
+    const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
+    return use_c64(Cin, CoutP, dtype) ? c64_wgs(ntiles) : ntiles;
+}
 
 extern "C" int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const float* bias, int nbias, const float* in_scale,
                               const float* in_shift, void* y, int ldy, float* stat_partials, int B, int H, int W,

@@ -80,55 +80,87 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgArgs<T> a) {
     const int cd = co0 + vv * VE;
     const bool cxok = cx < a.CinX, cdok = cd < a.CoutY;
     float sc[VE], sh[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { sc[e] = 0.f; sh[e] = 0.f; }
     if (XFORM && cxok) {
 #pragma unroll
         for (int e = 0; e < VE; ++e) { sc[e] = a.in_scale[cx + e]; sh[e] = a.in_shift[cx + e]; }
     }
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    // ---- software pipeline over tiles: the x halo tile and the dy tile of the NEXT tile are fetched into
+    // registers before the MFMA loop of the current one (HBM latency hides under 144 MFMAs per wave); the
+    // fused BN+ReLU is applied when the registers are written to LDS.  Loads are unconditional (clamped,
+    // always valid address) so the compiler batches them; validity travels as bit masks.
+    constexpr int NXV = (HH * HW_ * VPP + 255) / 256;
+    constexpr int NDV = TH * TW * VPP / 256;
+    const int cxl = cxok ? cx : 0, cdl = cdok ? cd : 0;
+    vec16<T> prex[NXV], pred[NDV];
+    unsigned okx = 0, okd = 0;
+    auto prefetch = [&](int tile) {
         int t = tile;
         const int txi = t % a.tilesX; t /= a.tilesX;
         const int tyi = t % a.tilesY; t /= a.tilesY;
-        const int b = t;
-        const int ty0 = tyi * TH, tx0 = txi * TW;
-        __syncthreads();  // previous tile consumed
-        for (int i = tid; i < HH * HW_ * VPP; i += 256) {
-            const int pix = i / VPP;
+        const int b = t, ty0 = tyi * TH, tx0 = txi * TW;
+        okx = 0; okd = 0;
+#pragma unroll
+        for (int it = 0; it < NXV; ++it) {
+            const int i = tid + it * 256;
+            const int pix = min(i / VPP, HH * HW_ - 1);
             const int py = pix / HW_, px = pix - py * HW_;
             const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
-            vec16<T> v;
-            if (cxok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                v = *reinterpret_cast<const vec16<T>*>(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldx + cx);
-                if (XFORM) {
-#pragma unroll
-                    for (int e = 0; e < VE; ++e) v.set(e, fmaxf(sc[e] * v.get(e) + sh[e], 0.f));
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < VE; ++e) v.set(e, 0.f);
-            }
-            *reinterpret_cast<vec16<T>*>(sX + pix * PS + vv * VE) = v;
+            const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+            prex[it] = *reinterpret_cast<const vec16<T>*>(a.x + ((size_t)(b * a.H + gyc) * a.W + gxc) * a.ldx + cxl);
+            if (cxok && gy == gyc && gx == gxc) okx |= 1u << it;
         }
-        for (int i = tid; i < TH * TW * VPP; i += 256) {
+#pragma unroll
+        for (int it = 0; it < NDV; ++it) {
+            const int i = tid + it * 256;
             const int pix = i / VPP;
             const int py = pix / TW, px = pix - py * TW;
             const int gy = ty0 + py, gx = tx0 + px;
-            vec16<T> v;
-            if (cdok && gy < a.H && gx < a.W)
-                v = *reinterpret_cast<const vec16<T>*>(a.dy + ((size_t)(b * a.H + gy) * a.W + gx) * a.lddy + cd);
-            else {
+            const int gyc = min(gy, a.H - 1), gxc = min(gx, a.W - 1);
+            pred[it] = *reinterpret_cast<const vec16<T>*>(a.dy + ((size_t)(b * a.H + gyc) * a.W + gxc) * a.lddy + cdl);
+            if (cdok && gy == gyc && gx == gxc) okd |= 1u << it;
+        }
+    };
+    if ((int)blockIdx.x < a.ntiles) prefetch(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        __syncthreads();  // previous tile consumed
+#pragma unroll
+        for (int it = 0; it < NXV; ++it) {
+            const int i = tid + it * 256;
+            const int pix = min(i / VPP, HH * HW_ - 1);
+            vec16<T> v = prex[it];
+            const bool inb = (okx >> it) & 1u;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                float f = v.get(e);
+                if (XFORM) f = fmaxf(sc[e] * f + sh[e], 0.f);
+                v.set(e, inb ? f : 0.f);
+            }
+            if (i < HH * HW_ * VPP) *reinterpret_cast<vec16<T>*>(sX + pix * PS + vv * VE) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NDV; ++it) {
+            const int i = tid + it * 256;
+            const int pix = i / VPP;
+            vec16<T> v = pred[it];
+            if (!((okd >> it) & 1u)) {
 #pragma unroll
                 for (int e = 0; e < VE; ++e) v.set(e, 0.f);
             }
             *reinterpret_cast<vec16<T>*>(sD + pix * PS + vv * VE) = v;
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
 
         if constexpr (sizeof(T) == 2) {
             // transposing-read lane geometry: 16-lane group g = lane>>4; lane i = 4q+p of the group
             const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
             const int chan = 16 * (g & 1) + 4 * p;  // channel offset inside the 32-channel block
             const int pk = 8 * (g >> 1) + q;        // pixel offset inside the 16-pixel K step (+4 for the 2nd read)
+#pragma unroll 2
             for (int kr = 0; kr < TH; ++kr) {
                 const bf16_t* pd = sD + (kr * TW + pk) * PS + ni * 32 + chan;
                 const bf16x8 bfrag = tr_frag(pd, pd + 4 * PS);

@@ -129,8 +129,8 @@ def pack_w3x3(w, CoutP, CinP, dtype, perm=None, transpose=False):
 
 
 # ----------------------------------------------------------------------------- conv / bn
-def conv3x3_nparts(B, H, W):
-    return _lib.lib().wm_conv3x3_nparts(c_int(B), c_int(H), c_int(W))
+def conv3x3_nparts(B, H, W, Cin, CoutP, dtype):
+    return _lib.lib().wm_conv3x3_nparts(c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(CoutP), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32))
 
 
 def conv3x3_fwd(x, wp, bias, in_scale, in_shift, want_stats, Cin=None):
@@ -141,7 +141,7 @@ def conv3x3_fwd(x, wp, bias, in_scale, in_shift, want_stats, Cin=None):
     Cin = CinW if Cin is None else Cin
     assert Cin == CinW and Cin <= ldx
     y = torch.empty(B, H, W, CoutP, device=x.device, dtype=x.dtype)
-    st = torch.empty(conv3x3_nparts(B, H, W), 2, CoutP, device=x.device, dtype=torch.float32) if want_stats else None
+    st = torch.empty(conv3x3_nparts(B, H, W, Cin, CoutP, x.dtype), 2, CoutP, device=x.device, dtype=torch.float32) if want_stats else None
     info = {"B": B, "H": H, "W": W, "Cin": Cin, "CoutP": CoutP, "xform": in_scale is not None, "dtype": x.dtype}
     rc = _timed("conv3x3_fwd", info, lambda: _lib.lib().wm_conv3x3_fwd(
         _p(x), c_int(ldx), _p(wp), _p(bias), c_int(0 if bias is None else bias.numel()), _p(in_scale), _p(in_shift),
