@@ -110,6 +110,11 @@ int wm_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int ld,
  * (the expanded message of hidden_models/encoder.py:34-37). */
 int wm_broadcast_to_nhwc(const float* v, void* y, int B, int L, int H, int W, int ld, int c0,
                          int dtype, void* stream);
+/* the tail of the encoder's concat tensor in one pass: channels [c0, c0+tail) of every pixel =
+ * [message v[b, 0..L) | image planes img[b, 0..3) | zeros]  (encoder.py:34-40).  c0, tail, ld multiples of
+ * the 16-byte vector width. */
+int wm_concat_tail(const float* msg, const float* img, void* y, int B, int L, int H, int W, int ld, int c0,
+                   int tail, int dtype, void* stream);
 /* relu(scale*x+shift) of an NHWC tensor copied into another NHWC tensor (channel slice):
  * materialises a BatchNorm+ReLU output where a consumer cannot fuse it (concat). */
 int wm_bnrelu_copy(const void* x, int ldx, const float* scale, const float* shift, void* y, int ldy,

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void tree_reduce_rows_kernel(float* __restrict
 }
 // returns the number of rows left
 inline int tree_reduce_rows(float* rows, int n, int W, hipStream_t s) {
-    if (n <= TREE_ROWS) return n;
+    if (n <= 4 * TREE_ROWS) return n;  // the finalisation kernels walk up to 256 rows (8 slices x 32) themselves
     hipLaunchKernelGGL(tree_reduce_rows_kernel, dim3(TREE_ROWS), dim3(256), 0, s, rows, n, W);
     return TREE_ROWS;
 }

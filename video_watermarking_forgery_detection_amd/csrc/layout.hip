@@ -62,6 +62,32 @@ __global__ __launch_bounds__(256) void broadcast_kernel(const float* __restrict_
     }
 }
 
+// encoder concat tail (hidden_models/encoder.py:34-40): [message(L) | image(3) | zero pad] written as whole
+// 16-byte vectors at channel offset c0 (c0 and the tail width are multiples of the vector width)
+template <typename T>
+__global__ __launch_bounds__(256) void concat_tail_kernel(const float* __restrict__ msg, const float* __restrict__ img,
+                                                          T* __restrict__ y, int B, int L, size_t hw, int ld, int c0,
+                                                          int tail) {
+    constexpr int VE = vec16<T>::N;
+    const int nv = tail / VE;
+    const size_t total = (size_t)B * hw * nv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % nv);
+        const size_t p = i / nv;
+        const size_t b = p / hw, q = p - b * hw;
+        vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            const int c = v * VE + e;
+            float f = 0.f;
+            if (c < L) f = msg[b * L + c];
+            else if (c < L + 3) f = img[(b * 3 + (c - L)) * hw + q];
+            o.set(e, f);
+        }
+        *reinterpret_cast<vec16<T>*>(y + p * ld + c0 + v * VE) = o;
+    }
+}
+
 inline int grid_for(size_t n) {
     const size_t g = (n + 255) / 256;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -106,5 +132,19 @@ extern "C" int wm_broadcast_to_nhwc(const float* v, void* y, int B, int L, int H
     WM_DISPATCH_DTYPE(dtype, "wm_broadcast_to_nhwc",
         hipLaunchKernelGGL((broadcast_kernel<T>), dim3(grid_for(B * hw)), dim3(256), 0, s, v, (T*)y, B, L, hw, ld, c0));
     WM_LAUNCH_CHECK("wm_broadcast_to_nhwc");
+    return WM_OK;
+}
+
+extern "C" int wm_concat_tail(const float* msg, const float* img, void* y, int B, int L, int H, int W, int ld, int c0,
+                              int tail, int dtype, void* stream) {
+    WM_REQUIRE(msg && img && y, WM_E_BADARG, "wm_concat_tail: null pointer");
+    const int ve = dtype == WM_BF16 ? 8 : 4;
+    WM_REQUIRE(B > 0 && L > 0 && H > 0 && W > 0 && tail >= L + 3 && ld >= c0 + tail, WM_E_BADARG, "wm_concat_tail: bad shape");
+    WM_REQUIRE(c0 % ve == 0 && tail % ve == 0 && ld % ve == 0, WM_E_SHAPE, "wm_concat_tail: c0=%d tail=%d ld=%d must be multiples of %d", c0, tail, ld, ve);
+    const size_t hw = (size_t)H * W;
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_concat_tail",
+        hipLaunchKernelGGL((concat_tail_kernel<T>), dim3(grid_for(B * hw * (tail / ve))), dim3(256), 0, s, msg, img, (T*)y, B, L, hw, ld, c0, tail));
+    WM_LAUNCH_CHECK("wm_concat_tail");
     return WM_OK;
 }

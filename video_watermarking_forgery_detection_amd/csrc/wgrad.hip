@@ -20,6 +20,7 @@
 //   epilogue   = f32 slab [9][CinP][CoutP] per workgroup; a second kernel sums the slabs in a
 //                fixed order (deterministic, no float atomics) into the PyTorch-layout gradient.
 //   f32 path   : v_mfma_f32_32x32x2_f32 on 8x16 tiles (parity path; plain ds_read_b32 operands).
+#include <type_traits>
 #include "wm_common.h"
 
 namespace {
@@ -87,105 +88,141 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgArgs<T> a) {
         for (int e = 0; e < VE; ++e) { sc[e] = a.in_scale[cx + e]; sh[e] = a.in_shift[cx + e]; }
     }
 
-    // ---- software pipeline over tiles: the x halo tile and the dy tile of the NEXT tile are fetched into
-    // registers before the MFMA loop of the current one (HBM latency hides under 144 MFMAs per wave); the
-    // fused BN+ReLU is applied when the registers are written to LDS.  Loads are unconditional (clamped,
-    // always valid address) so the compiler batches them; validity travels as bit masks.
+    // ---- software pipeline over this workgroup's contiguous run of tiles (same scheme as the persistent conv
+    // kernel, measured there with tools/phase_c64.py): the x halo tile and the dy tile travel two tiles ahead
+    // in registers; their global loads are issued from INSIDE the MFMA loop, one every few MFMAs, so the
+    // per-CU memory queue never backs up and the HBM time hides under the matrix pipe; the fused BN+ReLU of the
+    // next tile's registers is done in the same loop.  Loads are never under a per-lane branch (clamped, always
+    // valid address; validity travels as bits).
     constexpr int NXV = (HH * HW_ * VPP + 255) / 256;
     constexpr int NDV = TH * TW * VPP / 256;
     const int cxl = cxok ? cx : 0, cdl = cdok ? cd : 0;
-    vec16<T> prex[NXV], pred[NDV];
-    unsigned okx = 0, okd = 0;
-    auto prefetch = [&](int tile) {
+    struct TileGeo { int b, ty0, tx0; };
+    auto geo = [&](int tile) {
+        TileGeo g;
         int t = tile;
         const int txi = t % a.tilesX; t /= a.tilesX;
         const int tyi = t % a.tilesY; t /= a.tilesY;
-        const int b = t, ty0 = tyi * TH, tx0 = txi * TW;
-        okx = 0; okd = 0;
+        g.b = t; g.ty0 = tyi * TH; g.tx0 = txi * TW;
+        return g;
+    };
+    auto load_x = [&](const TileGeo& g, int it, vec16<T>& dst, unsigned& okbits) {
+        const int i = tid + it * 256;
+        const int pix = min(i / VPP, HH * HW_ - 1);
+        const int py = pix / HW_, px = pix - py * HW_;
+        const int gy = g.ty0 - 1 + py, gx = g.tx0 - 1 + px;
+        const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+        dst = *reinterpret_cast<const vec16<T>*>(a.x + ((size_t)(g.b * a.H + gyc) * a.W + gxc) * a.ldx + cxl);
+        const unsigned okb = (cxok && gy == gyc && gx == gxc) ? 1u : 0u;
+        okbits |= okb << it;
+    };
+    auto load_d = [&](const TileGeo& g, int it, vec16<T>& dst, unsigned& okbits) {
+        const int i = tid + it * 256;
+        const int pix = i / VPP;
+        const int py = pix / TW, px = pix - py * TW;
+        const int gy = g.ty0 + py, gx = g.tx0 + px;
+        const int gyc = min(gy, a.H - 1), gxc = min(gx, a.W - 1);
+        dst = *reinterpret_cast<const vec16<T>*>(a.dy + ((size_t)(g.b * a.H + gyc) * a.W + gxc) * a.lddy + cdl);
+        const unsigned okb = (cdok && gy == gyc && gx == gxc) ? 1u : 0u;
+        okbits |= okb << it;
+    };
+    auto xform_x = [&](vec16<T>& v, bool ok) {   // fused BN+ReLU of the producer, zero padding after it
 #pragma unroll
-        for (int it = 0; it < NXV; ++it) {
-            const int i = tid + it * 256;
-            const int pix = min(i / VPP, HH * HW_ - 1);
-            const int py = pix / HW_, px = pix - py * HW_;
-            const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
-            const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
-            prex[it] = *reinterpret_cast<const vec16<T>*>(a.x + ((size_t)(b * a.H + gyc) * a.W + gxc) * a.ldx + cxl);
-            if (cxok && gy == gyc && gx == gxc) okx |= 1u << it;
-        }
-#pragma unroll
-        for (int it = 0; it < NDV; ++it) {
-            const int i = tid + it * 256;
-            const int pix = i / VPP;
-            const int py = pix / TW, px = pix - py * TW;
-            const int gy = ty0 + py, gx = tx0 + px;
-            const int gyc = min(gy, a.H - 1), gxc = min(gx, a.W - 1);
-            pred[it] = *reinterpret_cast<const vec16<T>*>(a.dy + ((size_t)(b * a.H + gyc) * a.W + gxc) * a.lddy + cdl);
-            if (cdok && gy == gyc && gx == gxc) okd |= 1u << it;
+        for (int e = 0; e < VE; ++e) {
+            float f = v.get(e);
+            if (XFORM) f = fmaxf(sc[e] * f + sh[e], 0.f);
+            v.set(e, ok ? f : 0.f);
         }
     };
-    if ((int)blockIdx.x < a.ntiles) prefetch(blockIdx.x);
+    auto mask_d = [&](vec16<T>& v, bool ok) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v.set(e, ok ? v.get(e) : 0.f);
+    };
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int per = (a.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(a.ntiles, t_begin + per);
+
+    // one register set (a second one spills next to the 144 accumulator registers): the loads of tile+1 are
+    // issued in the first 19 of the 32 slots of the MFMA loop of tile, so the last of them still has ~40 % of
+    // the loop (>3,000 cycles) to land before the LDS write that consumes it
+    vec16<T> nxtx[NXV], nxtd[NDV];
+    unsigned nokx = 0, nokd = 0;
+    if (t_begin < t_end) {
+        const TileGeo g0 = geo(t_begin);
+#pragma unroll
+        for (int it = 0; it < NXV; ++it) load_x(g0, it, nxtx[it], nokx);
+#pragma unroll
+        for (int it = 0; it < NDV; ++it) load_d(g0, it, nxtd[it], nokd);
+    }
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
         __syncthreads();  // previous tile consumed
 #pragma unroll
         for (int it = 0; it < NXV; ++it) {
             const int i = tid + it * 256;
-            const int pix = min(i / VPP, HH * HW_ - 1);
-            vec16<T> v = prex[it];
-            const bool inb = (okx >> it) & 1u;
-#pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                float f = v.get(e);
-                if (XFORM) f = fmaxf(sc[e] * f + sh[e], 0.f);
-                v.set(e, inb ? f : 0.f);
-            }
-            if (i < HH * HW_ * VPP) *reinterpret_cast<vec16<T>*>(sX + pix * PS + vv * VE) = v;
+            xform_x(nxtx[it], (nokx >> it) & 1u);
+            if (i < HH * HW_ * VPP) *reinterpret_cast<vec16<T>*>(sX + (i / VPP) * PS + vv * VE) = nxtx[it];
         }
 #pragma unroll
         for (int it = 0; it < NDV; ++it) {
-            const int i = tid + it * 256;
-            const int pix = i / VPP;
-            vec16<T> v = pred[it];
-            if (!((okd >> it) & 1u)) {
-#pragma unroll
-                for (int e = 0; e < VE; ++e) v.set(e, 0.f);
-            }
-            *reinterpret_cast<vec16<T>*>(sD + pix * PS + vv * VE) = v;
+            mask_d(nxtd[it], (nokd >> it) & 1u);
+            *reinterpret_cast<vec16<T>*>(sD + ((tid + it * 256) / VPP) * PS + vv * VE) = nxtd[it];
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
-
-        if constexpr (sizeof(T) == 2) {
-            // transposing-read lane geometry: 16-lane group g = lane>>4; lane i = 4q+p of the group
-            const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-            const int chan = 16 * (g & 1) + 4 * p;  // channel offset inside the 32-channel block
-            const int pk = 8 * (g >> 1) + q;        // pixel offset inside the 16-pixel K step (+4 for the 2nd read)
-#pragma unroll 2
-            for (int kr = 0; kr < TH; ++kr) {
-                const bf16_t* pd = sD + (kr * TW + pk) * PS + ni * 32 + chan;
-                const bf16x8 bfrag = tr_frag(pd, pd + 4 * PS);
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int kh = tap / 3, kw = tap % 3;
-                    const bf16_t* px_ = sX + ((kr + kh) * HW_ + pk + kw) * PS + mi * 32 + chan;
-                    const bf16x8 afrag = tr_frag(px_, px_ + 4 * PS);
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[tap], 0, 0, 0);
-                }
+        nokx = 0; nokd = 0;
+        const bool have1 = tile + 1 < t_end;
+        const TileGeo g1 = geo(have1 ? tile + 1 : tile);
+        // slot s of the MFMA loop: global load s of tile+1 (x vectors first, then dy)
+        auto slot = [&](int sl, auto steady_tag) {
+            constexpr bool STEADY = decltype(steady_tag)::value;
+            if (sl < NXV) {
+                if (STEADY || have1) load_x(g1, sl, nxtx[sl], nokx);
+            } else if (sl < NXV + NDV) {
+                if (STEADY || have1) load_d(g1, sl - NXV, nxtd[sl - NXV], nokd);
             }
-        } else {
-            for (int kr = 0; kr < TH; ++kr) {
-                for (int kp = 0; kp < TW / 2; ++kp) {
-                    const int px = 2 * kp + h;
-                    const float bfrag = sD[(kr * TW + px) * PS + ni * 32 + r];
+        };
+
+        auto mfma_loop = [&](auto steady_tag) {
+            if constexpr (sizeof(T) == 2) {
+                // transposing-read lane geometry: 16-lane group g = lane>>4; lane i = 4q+p of the group
+                const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+                const int chan = 16 * (g & 1) + 4 * p;  // channel offset inside the 32-channel block
+                const int pk = 8 * (g >> 1) + q;        // pixel offset inside the 16-pixel K step (+4 for the 2nd read)
+#pragma unroll
+                for (int kr = 0; kr < TH; ++kr) {
+                    const bf16_t* pd = sD + (kr * TW + pk) * PS + ni * 32 + chan;
+                    const bf16x8 bfrag = tr_frag(pd, pd + 4 * PS);
 #pragma unroll
                     for (int tap = 0; tap < 9; ++tap) {
                         const int kh = tap / 3, kw = tap % 3;
-                        const float afrag = sX[((kr + kh) * HW_ + px + kw) * PS + mi * 32 + r];
-                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag, acc[tap], 0, 0, 0);
+                        const bf16_t* px_ = sX + ((kr + kh) * HW_ + pk + kw) * PS + mi * 32 + chan;
+                        const bf16x8 afrag = tr_frag(px_, px_ + 4 * PS);
+                        if (tap == 2) slot(2 * kr, steady_tag);
+                        if (tap == 6) slot(2 * kr + 1, steady_tag);
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[tap], 0, 0, 0);
+                    }
+                }
+            } else {
+                // f32 parity path: the loads of the next tile go out as one burst ahead of the loop (a fully
+                // unrolled loop with in-loop slots spills next to 144 accumulator registers)
+#pragma unroll
+                for (int sl = 0; sl < NXV + NDV; ++sl) slot(sl, steady_tag);
+                for (int kr = 0; kr < TH; ++kr) {
+                    for (int kp = 0; kp < TW / 2; ++kp) {
+                        const int px = 2 * kp + h;
+                        const float bfrag = sD[(kr * TW + px) * PS + ni * 32 + r];
+#pragma unroll
+                        for (int tap = 0; tap < 9; ++tap) {
+                            const int kh = tap / 3, kw = tap % 3;
+                            const float afrag = sX[((kr + kh) * HW_ + px + kw) * PS + mi * 32 + r];
+                            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag, acc[tap], 0, 0, 0);
+                        }
                     }
                 }
             }
-        }
+        };
+        if (have1) mfma_loop(std::true_type{});
+        else mfma_loop(std::false_type{});
     }
     // slab write: acc[tap][i] -> row (ci) = (i&3)+8*(i>>2)+4h, col (co) = r
     const int CinP = a.ciBlocks * CB, CoutP = a.coBlocks * CB;

@@ -141,6 +141,13 @@ class FlatModule:
             off += k
         object.__setattr__(self, "_flat", flat)
         object.__setattr__(self, "_gflat", gflat)
+        # BatchNorm step counters: views of one int64 tensor, so a forward bumps them with one launch
+        bns = [m for m in self.modules() if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None]
+        if bns:
+            nbt = torch.stack([m.num_batches_tracked.to(dev) for m in bns])
+            for i, m in enumerate(bns):
+                m._buffers["num_batches_tracked"] = nbt[i]
+            object.__setattr__(self, "_nbt", nbt)
 
     @property
     def flat_params(self):
@@ -161,3 +168,15 @@ def set_compute_dtype(module, dtype):
         if hasattr(m, "compute_dtype"):
             m.compute_dtype = dtype
     return module
+
+
+def bump_bn_counters(module):
+    """num_batches_tracked += 1 for every BatchNorm2d of `module` (one launch when the counters are flat)."""
+    nbt = getattr(module, "_nbt", None)
+    if nbt is not None and all(m.num_batches_tracked.data_ptr() == nbt[i].data_ptr() for i, m in enumerate(
+            mm for mm in module.modules() if isinstance(mm, torch.nn.BatchNorm2d) and mm.num_batches_tracked is not None)):
+        nbt += 1
+        return
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None:
+            m.num_batches_tracked += 1

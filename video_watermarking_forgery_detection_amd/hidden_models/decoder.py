@@ -92,7 +92,7 @@ class Decoder(nn.Module, engine.FlatModule):
         L = self.message_length
         out = torch.addmm(self.linear.bias.data, pooled[:, :L], self.linear.weight.data.t())  # [B,L]x[L,L]: plumbing-sized
         if training:
-            bump_bn_counters(self)
+            engine.bump_bn_counters(self)
         return out, ctx
 
     def bwd(self, ctx, g_out, grads, accumulate=False, need_input_grad=True):

@@ -32,7 +32,7 @@ class Discriminator(nn.Module, engine.FlatModule):
         pooled, ctx = stack_fwd(self._blocks(), image, self.compute_dtype, training)
         out = torch.addmm(self.linear.bias.data, pooled[:, :self.channels], self.linear.weight.data.t())
         if training:
-            bump_bn_counters(self)
+            engine.bump_bn_counters(self)
         return out, ctx
 
     def bwd(self, ctx, g_out, grads, accumulate=False, need_input_grad=False):

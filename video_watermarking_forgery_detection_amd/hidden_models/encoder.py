@@ -58,8 +58,7 @@ class Encoder(nn.Module, engine.FlatModule):
             ctx.layers.append(cx)
         cat = torch.empty(B, self.H, self.W, self._cat_ld, device=image.device, dtype=dt)
         ops.bnrelu_copy(a.t, a.scale, a.shift, cat, 0, c)
-        ops.broadcast_to_nhwc(message, cat, c)
-        ops.nchw_to_nhwc(image, cat, c + L, self._cat_ld - (c + L + 3))
+        ops.concat_tail(message, image, cat, c)   # [message | image | 0-pad] in one vectorised pass
         blk = self.after_concat_layer
         a5, ctx.cat_ctx = engine.cbr_forward(blk.layers[0], blk.layers[1], engine.Act(cat, c + L + 3), dt,
                                              perm=self._perm, training=training)
@@ -67,7 +66,7 @@ class Encoder(nn.Module, engine.FlatModule):
         fl = self.final_layer
         enc = ops.conv1x1_head_fwd(a5.t, a5.scale, a5.shift, fl.weight.data.view(3, c), fl.bias.data, act=0)
         if training:
-            self._bump_bn_counters()
+            engine.bump_bn_counters(self)
         return enc, ctx
 
     def bwd(self, ctx, g_enc, grads, accumulate=False):

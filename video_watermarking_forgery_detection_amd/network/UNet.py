@@ -116,9 +116,7 @@ class UNet(nn.Module, engine.FlatModule):
         out = ops.conv1x1_head_fwd(a.t, a.scale, a.shift, self.conv.weight.data.view(oc, f), self.conv.bias.data, act=1)
         ctx.out = out
         if training:
-            for m in self.modules():
-                if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None:
-                    m.num_batches_tracked += 1
+            engine.bump_bn_counters(self)
         return out, ctx
 
     def bwd(self, ctx, g_out, grads, accumulate=False, need_input_grad=True):

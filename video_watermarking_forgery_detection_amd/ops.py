@@ -107,6 +107,17 @@ def broadcast_to_nhwc(v, out, C_off):
     return out
 
 
+def concat_tail(msg, img, out, C_off):
+    """out[..., C_off:] = [msg | img | 0]  (encoder concat tail, one vectorised pass)"""
+    _need_cuda(msg, img, out)
+    B, H, W, ld = out.shape
+    msg = msg.contiguous().float(); img = img.contiguous().float()
+    rc = _lib.lib().wm_concat_tail(_p(msg), _p(img), _p(out), c_int(B), c_int(msg.shape[1]), c_int(H), c_int(W), c_int(ld),
+                                   c_int(C_off), c_int(ld - C_off), c_int(dtype_id(out)), _stream())
+    _lib.check(rc, "wm_concat_tail")
+    return out
+
+
 def bnrelu_copy(x, scale, shift, out, C_off, C):
     B, H, W, ldx = x.shape
     rc = _lib.lib().wm_bnrelu_copy(_p(x), c_int(ldx), _p(scale), _p(shift), _p(out), c_int(out.shape[-1]), c_int(C_off),
@@ -248,7 +259,7 @@ def conv1x1_head_bwd(y, scale, shift, w, gout, dw, dbias, accumulate):
     ldp = Cout * (Cin + 1)
     colsum(part, Cout * Cin, ldp, dw, accumulate)
     # the first call folded the rows in place to <= 64 (wm_colsum_finalize treats partials as scratch)
-    colsum(part[:min(nparts, 64), Cout * Cin:], Cout, ldp, dbias, accumulate)
+    colsum(part[:(nparts if nparts <= 256 else 64), Cout * Cin:], Cout, ldp, dbias, accumulate)
     return g
 
 
