@@ -21,6 +21,11 @@
 #include <type_traits>
 #include "wm_common.h"
 
+// wave-specialised 64->64 kernel (conv3x3_ws.hip)
+int wm_launch_conv3x3_ws64(const void* x, int ldx, const void* wp, const float* bias, int nbias, const float* in_scale,
+                           const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
+                           hipStream_t s);
+
 namespace {
 
 constexpr int TH = 16, TW = 16;
@@ -601,6 +606,8 @@ int launch_conv(const void* x, int ldx, const void* wp, const float* bias, int n
             const int ntiles = B * a.tilesX * a.tilesY;
             const int per = c64_tiles_per_wg(ntiles);
             dim3 grid((unsigned)c64_wgs(ntiles)), block(256);
+            static const bool v1 = getenv("WM_C64_V1") != nullptr;  // diagnostic knob: single-role persistent kernel
+            if (!v1) return wm_launch_conv3x3_ws64(x, ldx, wp, bias, nbias, in_scale, in_shift, y, stat, B, H, W, c64_wgs(ntiles), per, s);
             unsigned long long* nost = nullptr;
             const bool st = stat != nullptr;
             if (xf && st) hipLaunchKernelGGL((conv3x3_c64_kernel<true, true>), grid, block, 0, s, a, a.x, a.y, ntiles, per, nost);
