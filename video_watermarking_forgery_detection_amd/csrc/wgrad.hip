@@ -20,8 +20,13 @@
 //   epilogue   = f32 slab [9][CinP][CoutP] per workgroup; a second kernel sums the slabs in a
 //                fixed order (deterministic, no float atomics) into the PyTorch-layout gradient.
 //   f32 path   : v_mfma_f32_32x32x2_f32 on 8x16 tiles (parity path; plain ds_read_b32 operands).
+#include <stdlib.h>
 #include <type_traits>
 #include "wm_common.h"
+
+// wave-specialised bf16 kernel (wgrad_ws.hip)
+void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy,
+                        int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s);
 
 namespace {
 
@@ -306,7 +311,9 @@ extern "C" int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* i
                "wm_conv3x3_wgrad: bad pixel strides ldx=%d lddy=%d", ldx, lddy);
     WM_REQUIRE(perm_dev || CinX >= Cin, WM_E_BADARG, "wm_conv3x3_wgrad: x has fewer channels than the weight");
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == WM_BF16) launch_wgrad<bf16_t>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
+    static const bool v1 = getenv("WM_WGRAD_V1") != nullptr;  // diagnostic knob: single-role kernel
+    if (dtype == WM_BF16 && !v1) wm_launch_wgrad_ws(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, nslabs_for(B, H, W), s);
+    else if (dtype == WM_BF16) launch_wgrad<bf16_t>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
     else launch_wgrad<float>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad");
     const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;

@@ -1,0 +1,241 @@
+// Wave-specialised weight-gradient kernel (bf16) -- same role split as conv3x3_ws.hip:
+//   waves 0-3  CONSUMERS: per 16x16-pixel tile 16 K-steps x (1 dy fragment + 9 shifted x fragments, all through
+//              ds_read_b64_tr_b16, 9 v_mfma_f32_32x32x16_bf16); the 9 tap accumulators (144 registers) of the
+//              wave's 32 ci x 32 co block live across the whole run of tiles;
+//   waves 4-7  PRODUCERS: global loads of the x halo tile and the dy tile two tiles ahead (registers), fused
+//              BN+ReLU of x + zero padding, 16-byte LDS writes into the other buffer.
+// One workgroup barrier per tile.  LDS: 2 x (x halo 41,472 B + dy 32,768 B) = 148,480 B, rows of 128 B
+// (64 channels) without padding; the 64-byte half of a row is XOR-swizzled with (pixel >> 1) & 1, so the
+// 4 pixels x 64 B that one 32-lane half of ds_read_b64_tr_b16 touches always fill a 256-byte bank row exactly
+// once, for every tap shift.
+#include "wm_common.h"
+
+namespace {
+
+constexpr int TH = 16, TW = 16, HH = 18, HW = 18, CB = 64;
+constexpr int NPIX = HH * HW;
+constexpr int XVP = (NPIX * 8 + 255) / 256;   // x halo vectors per producer thread (11)
+constexpr int DVP = TH * TW * 8 / 256;        // dy vectors per producer thread (8)
+constexpr int X_BYTES = NPIX * CB * 2, D_BYTES = TH * TW * CB * 2;
+
+struct WsWgArgs {
+    const bf16_t* x; int ldx; int CinX;
+    const float* in_scale; const float* in_shift;
+    const bf16_t* dy; int lddy; int CoutY;
+    float* ws;           // [gridDim.x][9][CinP][CoutP]
+    int B, H, W, tilesX, tilesY, ntiles, ciBlocks, coBlocks;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p0));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p1));
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// byte offset of (pixel, channel byte cb) inside a tile of 128-byte pixel rows, 64-byte halves swizzled
+__device__ __forceinline__ int soff(int pix, int cb) { return pix * 128 + (cb ^ (((pix >> 1) & 1) << 6)); }
+
+template <bool XFORM>
+__global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(WsWgArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (X_BYTES + D_BYTES)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int cc = blockIdx.y / a.coBlocks, oc = blockIdx.y % a.coBlocks;
+    const int ci0 = cc * CB, co0 = oc * CB;
+    // balanced contiguous runs of tiles
+    const int t_begin = (int)(((long)blockIdx.x * a.ntiles) / (int)gridDim.x);
+    const int t_end = (int)(((long)(blockIdx.x + 1) * a.ntiles) / (int)gridDim.x);
+    struct TileGeo { int b, ty0, tx0; };
+    auto geo = [&](int tile) {
+        TileGeo g;
+        int t = tile;
+        const int txi = t % a.tilesX; t /= a.tilesX;
+        const int tyi = t % a.tilesY; t /= a.tilesY;
+        g.b = t; g.ty0 = tyi * TH; g.tx0 = txi * TW;
+        return g;
+    };
+
+    if (producer) {
+        // ================================================================== PRODUCER waves
+        const int ptid = tid - 256;
+        const int vv = ptid & 7;
+        const int cx = ci0 + vv * 8, cd = co0 + vv * 8;
+        const bool cxok = cx < a.CinX, cdok = cd < a.CoutY;
+        const int cxl = cxok ? cx : 0, cdl = cdok ? cd : 0;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+        if (XFORM && cxok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc[e] = a.in_scale[cx + e]; sh[e] = a.in_shift[cx + e]; }
+        }
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        auto load_x = [&](const TileGeo& g, int k, bf16x8& dst, unsigned& okbits) {
+            const int pix = min((ptid + 256 * k) >> 3, NPIX - 1);
+            const int py = pix / HW, px = pix - py * HW;
+            const int gy = g.ty0 - 1 + py, gx = g.tx0 - 1 + px;
+            const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+            dst = *reinterpret_cast<const bf16x8*>(a.x + ((size_t)(g.b * a.H + gyc) * a.W + gxc) * a.ldx + cxl);
+            const unsigned okb = (cxok && gy == gyc && gx == gxc) ? 1u : 0u;
+            okbits |= okb << k;
+        };
+        auto load_d = [&](const TileGeo& g, int k, bf16x8& dst, unsigned& okbits) {
+            const int pix = (ptid + 256 * k) >> 3;
+            const int gy = g.ty0 + (pix >> 4), gx = g.tx0 + (pix & 15);
+            const int gyc = min(gy, a.H - 1), gxc = min(gx, a.W - 1);
+            dst = *reinterpret_cast<const bf16x8*>(a.dy + ((size_t)(g.b * a.H + gyc) * a.W + gxc) * a.lddy + cdl);
+            const unsigned okb = (cdok && gy == gyc && gx == gxc) ? 1u : 0u;
+            okbits |= okb << k;
+        };
+        auto put_x = [&](unsigned char* base, int k, const bf16x8& src, bool ok) {
+            const int pix = (ptid + 256 * k) >> 3;
+            u32x4 w = __builtin_bit_cast(u32x4, src);
+            if (XFORM) {
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq) {
+                    f32x2 f = {__builtin_bit_cast(float, w[pq] << 16), __builtin_bit_cast(float, w[pq] & 0xffff0000u)};
+                    const f32x2 s2 = {sc[2 * pq], sc[2 * pq + 1]}, h2 = {sh[2 * pq], sh[2 * pq + 1]};
+                    f = f * s2 + h2;
+                    const bf16x2 pk = {(bf16_t)fmaxf(f[0], 0.f), (bf16_t)fmaxf(f[1], 0.f)};
+                    w[pq] = __builtin_bit_cast(unsigned, pk);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = ok ? w[q] : 0u;
+            if (pix < NPIX) *reinterpret_cast<u32x4*>(base + soff(pix, vv * 16)) = w;
+        };
+        auto put_d = [&](unsigned char* base, int k, const bf16x8& src, bool ok) {
+            const int pix = (ptid + 256 * k) >> 3;
+            u32x4 w = __builtin_bit_cast(u32x4, src);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = ok ? w[q] : 0u;
+            *reinterpret_cast<u32x4*>(base + X_BYTES + soff(pix, vv * 16)) = w;
+        };
+        bf16x8 x0[XVP], x1[XVP], d0[DVP], d1[DVP];
+        unsigned okx0 = 0, okx1 = 0, okd0 = 0, okd1 = 0;
+        if (t_begin < t_end) {
+            const TileGeo g0 = geo(t_begin);
+#pragma unroll
+            for (int k = 0; k < XVP; ++k) load_x(g0, k, x0[k], okx0);
+#pragma unroll
+            for (int k = 0; k < DVP; ++k) load_d(g0, k, d0[k], okd0);
+        }
+        if (t_begin + 1 < t_end) {
+            const TileGeo g1 = geo(t_begin + 1);
+#pragma unroll
+            for (int k = 0; k < XVP; ++k) load_x(g1, k, x1[k], okx1);
+#pragma unroll
+            for (int k = 0; k < DVP; ++k) load_d(g1, k, d1[k], okd1);
+        }
+        if (t_begin < t_end) {
+#pragma unroll
+            for (int k = 0; k < XVP; ++k) put_x(smem, k, x0[k], (okx0 >> k) & 1u);
+#pragma unroll
+            for (int k = 0; k < DVP; ++k) put_d(smem, k, d0[k], (okd0 >> k) & 1u);
+        }
+        __syncthreads();
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            unsigned char* nb = smem + ((((tile - t_begin) & 1) ^ 1) * (X_BYTES + D_BYTES));
+#pragma unroll
+            for (int k = 0; k < XVP; ++k) x0[k] = x1[k];
+#pragma unroll
+            for (int k = 0; k < DVP; ++k) d0[k] = d1[k];
+            okx0 = okx1; okd0 = okd1; okx1 = 0; okd1 = 0;
+            if (tile + 2 < t_end) {
+                const TileGeo g2 = geo(tile + 2);
+#pragma unroll
+                for (int k = 0; k < XVP; ++k) load_x(g2, k, x1[k], okx1);
+#pragma unroll
+                for (int k = 0; k < DVP; ++k) load_d(g2, k, d1[k], okd1);
+            }
+            if (tile + 1 < t_end) {
+#pragma unroll
+                for (int k = 0; k < XVP; ++k) put_x(nb, k, x0[k], (okx0 >> k) & 1u);
+#pragma unroll
+                for (int k = 0; k < DVP; ++k) put_d(nb, k, d0[k], (okd0 >> k) & 1u);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ====================================================================== CONSUMER waves
+    const int mi = wave >> 1, ni = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    // transposing-read lane geometry: 16-lane group g = lane>>4; lane i = 4q+p of the group supplies the address of
+    // pixel row q, channels 4p..4p+3 of the group's 16-channel block
+    const int g4 = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int chanb = (16 * (g4 & 1) + 4 * p) * 2;   // channel BYTE offset inside the 32-channel block
+    const int pk = 8 * (g4 >> 1) + q;                // pixel offset inside the 16-pixel K step (+4 for the 2nd read)
+    // swizzled byte offsets: for x the swizzle bit of pixel (row*18 + pk + kw [+4]) is (row & 1) ^ ((pk+kw[+4]) >> 1 & 1);
+    // the row part is a compile-time constant in the unrolled loop, so 3 kw x 2 halves x 2 row parities are enough
+    int xo[3][2][2];   // [kw][second read][row parity]
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const int col = pk + kw + 4 * s2;
+                const int cb = mi * 64 + chanb;
+                xo[kw][s2][par] = col * 128 + (cb ^ ((par ^ ((col >> 1) & 1)) << 6));
+            }
+    int dof[2];        // dy: pixel kr*16 + pk [+4] -> swizzle bit ((pk [+4]) >> 1) & 1  (kr*16 is a multiple of 4)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int col = pk + 4 * s2;
+        dof[s2] = col * 128 + ((ni * 64 + chanb) ^ (((col >> 1) & 1) << 6));
+    }
+    __syncthreads();
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const char* sXc = reinterpret_cast<const char*>(smem + (((tile - t_begin) & 1) * (X_BYTES + D_BYTES)));
+        const char* sDc = sXc + X_BYTES;
+#pragma unroll
+        for (int kr = 0; kr < TH; ++kr) {
+            const bf16x8 bfrag = tr_frag(sDc + kr * TW * 128 + dof[0], sDc + kr * TW * 128 + dof[1]);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap % 3;
+                const int row = kr + kh;
+                const bf16x8 afrag = tr_frag(sXc + row * HW * 128 + xo[kw][0][row & 1], sXc + row * HW * 128 + xo[kw][1][row & 1]);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[tap], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // slab write: acc[tap][i] -> row (ci) = (i&3)+8*(i>>2)+4h, col (co) = r
+    const int CinP = a.ciBlocks * CB, CoutP = a.coBlocks * CB;
+    float* slab = a.ws + (size_t)blockIdx.x * 9 * CinP * CoutP;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            slab[((size_t)tap * CinP + ci0 + mi * 32 + row) * CoutP + co0 + ni * 32 + r] = acc[tap][i];
+        }
+}
+
+}  // namespace
+
+void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy,
+                        int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s) {
+    WsWgArgs a;
+    a.x = (const bf16_t*)x; a.ldx = ldx; a.CinX = CinX; a.in_scale = in_scale; a.in_shift = in_shift;
+    a.dy = (const bf16_t*)dy; a.lddy = lddy; a.CoutY = CoutY; a.ws = ws; a.B = B; a.H = H; a.W = W;
+    a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
+    a.ciBlocks = wm_cdiv(CinX, CB); a.coBlocks = wm_cdiv(CoutY, CB);
+    const dim3 grid((unsigned)nslabs, (unsigned)(a.ciBlocks * a.coBlocks)), block(512);
+    if (in_scale) hipLaunchKernelGGL((wgrad_ws_kernel<true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wgrad_ws_kernel<false>), grid, block, 0, s, a);
+}
