@@ -13,9 +13,12 @@ decoder 7x64, discriminator 3x64; bf16 activations, f32 accumulate/params; synth
 random-init weights; inputs resident in HBM before the timed region.  One step = one batch.
 
 The JSON line carries, besides the driver contract:
-  roofline     -- the dominant kernel (bf16 64->64 conv3x3 implicit GEMM with fused BN+ReLU input),
+  roofline     -- the dominant kernel family (conv3x3_ws64_kernel<true,true>: bf16 64->64 conv3x3 implicit
+                  GEMM with fused BN+ReLU input and BatchNorm statistics, 15 launches / step),
                   77.3 GFLOP algorithmic per launch at B=16 256x256, duration measured live with
-                  events on the launch stream inside the timed region; peak = 2.5 PFLOP/s dense bf16
+                  events on the launch stream inside the timed region; peak = 2.5 PFLOP/s dense bf16;
+                  `traffic` = HBM bytes / launch from the committed rocprofv3 PMC passes of this round
+                  (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled as the gfx950 guide prescribes)
   cpu_baseline -- the oracle (oracle/hidden_ref.py, torch CPU fp32, all host cores) on a bounded
                   sample of the same step (rank 0, N=1 only)
 """
@@ -61,6 +64,17 @@ def cpu_baseline(size, frames):
     dt = time.time() - t0
     return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"1 step of the same HiDDeN-order step on {frames} frames {size}x{size} (oracle/hidden_ref.py, torch {torch.__version__} CPU fp32, {dt:.1f} s)"}
+
+
+def pmc_traffic(args, S, B):
+    """HBM bytes per launch of the dominant kernel, from this round's committed PMC passes (same workload only)."""
+    if args.dtype != "bf16" or S != 256 or B != 16:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -136,9 +150,10 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"C2: HiDDeN GAN step enc(4x64)->{args.noise}->dec(7x64)+disc(3x64), L=30, {S}x{S}, batch {B}/GPU",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel<%s,64,xform> (64->64 implicit GEMM)" % args.dtype,
+            "roofline": {"bound": "mfma",
+                         "kernel": ("conv3x3_ws64_kernel<true,true>" if dtype == torch.bfloat16 else "conv3x3_kernel<float,64,true>") + " (64->64 implicit GEMM, fused BN+ReLU input, BN statistics)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "launches_timed": len(kms), "avg_launch_ms": avg_ms,
+                         "traffic": pmc_traffic(args, S, B), "launches_timed": len(kms), "avg_launch_ms": avg_ms,
                          "flops_per_launch": flops_per_launch,
                          "hbm_algorithmic_bytes_per_launch": 2.0 * B * S * S * 64 * (2 if dtype == torch.bfloat16 else 4)},
             "step_flops_frac_of_peak": (249.0e9 * (S / 256.0) ** 2 * world * B * args.steps / dt) / (peak * 1e12 * world),
