@@ -10,9 +10,9 @@ w = torch.randn(C, C, 3, 3, device="cuda") * 0.05
 wp = ops.pack_w3x3(w, C, C, torch.bfloat16)
 sc = torch.rand(C, device="cuda") + 0.5; sh = torch.randn(C, device="cuda") * 0.3
 L = _lib.lib()
-cn = ["MFMA loop", "epilogue (bias/stats/pack/stores)", "barrier wait"]
-pn = ["halo load issue (tile+2)", "wait tile+1 + transform + LDS write", "barrier wait"]
-MODES = [(0, "full kernel"), (1, "no MFMA loop"), (2, "no stores"), (4, "no halo loads"), (3, "no MFMA, no stores"), (5, "no MFMA, no loads"), (6, "no stores, no loads")]
+cn = ["pass A: MFMA half 0 (+ drain of previous half 1)", "pass B: MFMA half 1 (+ drain of half 0)", "barrier wait"]
+pn = ["loads tile+2 interleaved with transform/write tile+1", "LDS write drain", "barrier wait"]
+MODES = [(0, "full kernel"), (8, "full kernel, producers at default priority"), (1, "no MFMA loop"), (2, "no stores"), (4, "no halo loads"), (3, "no MFMA, no stores"), (5, "no MFMA, no loads"), (6, "no stores, no loads")]
 for data in ("normal",):
     x = (torch.randn(B, H, W, C, device="cuda") if data == "normal" else torch.zeros(B, H, W, C, device="cuda")).bfloat16()
     y = torch.empty_like(x)
@@ -36,5 +36,5 @@ for data in ("normal",):
             for k, nm in enumerate(names):
                 v = s[:, off + k].median().item() / 16
                 tot += v
-                print(f"   {role} {nm:40s} {v:9.0f} cycles/tile")
-            print(f"   {role} {'total':40s} {tot:9.0f}")
+                print(f"   {role} {nm:58s} {v:9.0f} cycles/tile")
+            print(f"   {role} {'total':58s} {tot:9.0f}")

@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs<T> a) {
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    int t = blockIdx.x;
+    // XCD-aware tile assignment: workgroups b and b+8 share an XCD (round-robin dispatch); XCD x takes the
+    // contiguous tiles [x*G/8, (x+1)*G/8) so that neighbouring tiles share their halo in one L2
+    const int G = gridDim.x;
+    int t = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const int txi = t % a.tilesX; t /= a.tilesX;
     const int tyi = t % a.tilesY; t /= a.tilesY;
     const int b = t;

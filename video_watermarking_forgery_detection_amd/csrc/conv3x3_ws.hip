@@ -34,6 +34,7 @@ struct WsArgs {
     float* stat;                 // [gridDim.x][2][64] or null
     int B, H, W, tilesX, tilesY, ntiles, tiles_per_wg;
     int dbg;      // STAMPS build only: 1 = skip the MFMA loop, 2 = skip the stores, 4 = skip the halo loads
+    int xcd_map;
     int reverse;  // walk the workgroup's run of tiles backwards (Infinity Cache reuse of the previous kernel's tail)
 };
 
@@ -104,7 +105,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned
         }
     }
 
-    const int t_begin = blockIdx.x * a.tiles_per_wg;
+    // XCD-aware run assignment: workgroups b and b+8 share an XCD (round-robin dispatch), so give XCD x the
+    // consecutive runs [x*G/8, (x+1)*G/8): vertically adjacent tile rows then meet in ONE L2 at about the same time
+    // and the halo rows they share are fetched from HBM once
+    const int G = gridDim.x;
+    const int run = (a.xcd_map && (G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int t_begin = run * a.tiles_per_wg;
     const int t_end = min(a.ntiles, t_begin + a.tiles_per_wg);
     struct TileGeo { int b, ty0, tx0; };
     auto geo = [&](int tile) {
@@ -118,6 +124,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned
 
     if (producer) {
         // ================================================================== PRODUCER waves
+        if (!(STAMPS && (a.dbg & 8))) __builtin_amdgcn_s_setprio(3);   // their few VALU / LDS / memory instructions go first
         const int ptid = tid - 256;
         const int vec = ptid & 7;
         f32x2 sc2[4], sh2[4];
@@ -140,66 +147,96 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned
             lds[k] = pix * C64 + swz_px(hpx[k], vec) * 8;
         }
         const bool last_live = ((ptid + 256 * (XVP - 1)) >> 3) < NPIX;
-        // loads: always a valid address, never under a per-lane branch; the branch on `interior` is wave-uniform
+        // loads: always a valid address, never under a per-lane branch; the branches on `interior` are wave-uniform
+        auto is_interior = [&](const TileGeo& g) {
+            return g.ty0 >= 1 && g.ty0 + TH + 1 <= a.H && g.tx0 >= 1 && g.tx0 + TW + 1 <= a.W;
+        };
+        auto load_interior = [&](const bf16_t* xt, int k, bf16x8& d) { d = *reinterpret_cast<const bf16x8*>(xt + rel[k]); };
+        auto load_border = [&](const TileGeo& g, const bf16_t* xb, int k, bf16x8& d, unsigned& okbits) {
+            const int gy = g.ty0 - 1 + hpy[k], gx = g.tx0 - 1 + hpx[k];
+            const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+            d = *reinterpret_cast<const bf16x8*>(xb + (gyc * a.W + gxc) * a.ldx + vec * 8);
+            okbits |= ((gy == gyc && gx == gxc) ? 1u : 0u) << k;
+        };
+        auto tile_ptr = [&](const TileGeo& g) { return a.x + ((size_t)(g.b * a.H + g.ty0 - 1) * a.W + (g.tx0 - 1)) * a.ldx; };
+        auto image_ptr = [&](const TileGeo& g) { return a.x + (size_t)g.b * a.H * a.W * a.ldx; };
         auto load_tile = [&](const TileGeo& g, bf16x8 (&d)[XVP], unsigned& okbits) {
             if (STAMPS && (a.dbg & 4)) { okbits = 0xffffffffu; return; }
-            const bool interior = g.ty0 >= 1 && g.ty0 + TH + 1 <= a.H && g.tx0 >= 1 && g.tx0 + TW + 1 <= a.W;
-            if (interior) {
-                const bf16_t* xt = a.x + ((size_t)(g.b * a.H + g.ty0 - 1) * a.W + (g.tx0 - 1)) * a.ldx;
+            if (is_interior(g)) {
+                const bf16_t* xt = tile_ptr(g);
 #pragma unroll
-                for (int k = 0; k < XVP; ++k) d[k] = *reinterpret_cast<const bf16x8*>(xt + rel[k]);
+                for (int k = 0; k < XVP; ++k) load_interior(xt, k, d[k]);
                 okbits = 0xffffffffu;
             } else {
-                const bf16_t* xb = a.x + (size_t)g.b * a.H * a.W * a.ldx;
-                okbits = 0x80000000u;  // bit 31: "this tile needs masking"
+                const bf16_t* xb = image_ptr(g);
+                okbits = 0;
 #pragma unroll
-                for (int k = 0; k < XVP; ++k) {
-                    const int gy = g.ty0 - 1 + hpy[k], gx = g.tx0 - 1 + hpx[k];
-                    const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
-                    d[k] = *reinterpret_cast<const bf16x8*>(xb + (gyc * a.W + gxc) * a.ldx + vec * 8);
-                    okbits |= ((gy == gyc && gx == gxc) ? 1u : 0u) << k;
-                }
+                for (int k = 0; k < XVP; ++k) load_border(g, xb, k, d[k], okbits);
             }
         };
         // fused BN + ReLU (ReLU on the packed bf16 pair as a signed 16-bit max), zero padding AFTER the activation
-        auto put_tile = [&](bf16_t* sX, const bf16x8 (&d)[XVP], unsigned okbits) {
-            const bool masked = okbits != 0xffffffffu;   // wave-uniform (per tile)
+        auto put_one = [&](bf16_t* sX, int k, const bf16x8& d, unsigned okbits) {
+            u32x4 w = __builtin_bit_cast(u32x4, d);
+            if (XFORM) {
 #pragma unroll
-            for (int k = 0; k < XVP; ++k) {
-                u32x4 w = __builtin_bit_cast(u32x4, d[k]);
-                if (XFORM) {
-#pragma unroll
-                    for (int pq = 0; pq < 4; ++pq) {
-                        f32x2 f = {__builtin_bit_cast(float, w[pq] << 16), __builtin_bit_cast(float, w[pq] & 0xffff0000u)};
-                        f = f * sc2[pq] + sh2[pq];
-                        const bf16x2 pk = {(bf16_t)f[0], (bf16_t)f[1]};
-                        const i16x2 z = {0, 0};
-                        w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
-                    }
+                for (int pq = 0; pq < 4; ++pq) {
+                    // scalar v_fma_f32 on purpose: packed f32 VALU beside the partner wave's MFMAs costs far more than two scalar ops
+                    const float f0 = __builtin_fmaf(__builtin_bit_cast(float, w[pq] << 16), sc2[pq][0], sh2[pq][0]);
+                    const float f1 = __builtin_fmaf(__builtin_bit_cast(float, w[pq] & 0xffff0000u), sc2[pq][1], sh2[pq][1]);
+                    const bf16x2 pk = {(bf16_t)f0, (bf16_t)f1};
+                    const i16x2 z = {0, 0};
+                    w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
                 }
-                if (masked) {
-                    const unsigned keep = ((okbits >> k) & 1u) ? 0xffffffffu : 0u;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) w[q] &= keep;
-                }
-                if (k + 1 < XVP || last_live) *reinterpret_cast<u32x4*>(sX + lds[k]) = w;
             }
+            const unsigned keep = 0u - ((okbits >> k) & 1u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] &= keep;
+            if (k + 1 < XVP || last_live) *reinterpret_cast<u32x4*>(sX + lds[k]) = w;
         };
         bf16x8 dA[XVP], dB[XVP];
         unsigned okA = 0, okB = 0;
         if (t_begin < t_end) load_tile(geo(t_begin), dA, okA);
         if (t_begin + 1 < t_end) load_tile(geo(t_begin + 1), dB, okB);
-        if (t_begin < t_end) put_tile(sX0, dA, okA);
+        if (t_begin < t_end) {
+#pragma unroll
+            for (int k = 0; k < XVP; ++k) put_one(sX0, k, dA[k], okA);
+        }
         __syncthreads();  // filter + first halo tile visible
         stamp(-1);
-        // iteration `tile`: `cur` holds tile+1 (loaded one iteration ago): fetch tile+2 into `nxt`, then publish tile+1
+        // iteration `tile`: `cur` holds tile+1 (loaded one iteration ago) and is published (transform + LDS write) while
+        // the loads of tile+2 go into `nxt`; one load, one vector of VALU work, alternating, so the memory queue is fed
+        // at an even pace and never holds the whole burst
         auto iter = [&](int tile, bf16x8 (&nxt)[XVP], unsigned& oknxt, const bf16x8 (&cur)[XVP], unsigned okcur) {
-            const int nb = ((tile - t_begin) & 1) ^ 1;
-            if (tile + 2 < t_end) load_tile(geo(tile + 2), nxt, oknxt);
-            stamp(0);  // load issue
-            if (tile + 1 < t_end) put_tile(sX0 + nb * (NPIX * C64), cur, okcur);
+            bf16_t* sXn = sX0 + (((tile - t_begin) & 1) ^ 1) * (NPIX * C64);
+            const bool have_next = tile + 2 < t_end && !(STAMPS && (a.dbg & 4));
+            if (have_next) {
+                const TileGeo g2 = geo(tile + 2);
+                if (is_interior(g2)) {
+                    const bf16_t* xt = tile_ptr(g2);
+                    oknxt = 0xffffffffu;
+#pragma unroll
+                    for (int k = 0; k < XVP; ++k) {
+                        load_interior(xt, k, nxt[k]);
+                        put_one(sXn, k, cur[k], okcur);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    const bf16_t* xb = image_ptr(g2);
+                    oknxt = 0;
+#pragma unroll
+                    for (int k = 0; k < XVP; ++k) {
+                        load_border(g2, xb, k, nxt[k], oknxt);
+                        put_one(sXn, k, cur[k], okcur);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else if (tile + 1 < t_end) {
+#pragma unroll
+                for (int k = 0; k < XVP; ++k) put_one(sXn, k, cur[k], okcur);
+            }
+            stamp(0);  // loads of tile+2 interleaved with transform + LDS writes of tile+1
             if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            stamp(1);  // wait for the tile loaded one iteration ago + transform + LDS writes
+            stamp(1);
             __syncthreads();
             stamp(2);  // barrier
         };
@@ -220,7 +257,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned
 
     // ====================================================================== CONSUMER waves
     // lane (r, h): pixel r of a 32-pixel fragment (tile row wave*4 + 2*mf + (r>>4), column r&15); accumulator
-    // register i of channel fragment nf = output channel nf*32 + 16h + i
+    // register i of channel fragment nf = output channel nf*32 + 16h + i.
+    // Software pipeline at HALF-tile granularity, no extra registers: a tile is computed as two passes over K, pixel
+    // fragment mf = 0 then mf = 1 (2 MFMAs per step; the filter fragments are read twice -- the LDS has the room), and
+    // while one half accumulates, the finished other half is drained (BatchNorm sums, bf16 pack, stores) in the
+    // shadow of the MFMAs, a few instructions per step, so the matrix pipe never waits for an epilogue.
     const int r = lane & 31, h = lane >> 5;
     f32x2 s1[2][8], s2[2][8];
 #pragma unroll
@@ -238,83 +279,94 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned
         }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) boff[ks] = (r * C64 + swz(r, ks * 2 + h) * 8) * 2;
-    __syncthreads();  // filter + first halo tile visible
-    stamp(-1);
 
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        const TileGeo g = geo(tile);
-        const bf16_t* sX = sX0 + ((tile - t_begin) & 1) * (NPIX * C64);
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            acc[0][j] = *reinterpret_cast<const f32x16*>(sBias + j * 32 + 16 * h);
-            acc[1][j] = acc[0][j];
+    f32x16 acc[2][2];   // [pixel fragment mf][channel fragment nf]
+    struct Drain { bf16_t* yp; float mk; bool inb; };
+    auto drain_of = [&](const TileGeo& g, int mf) {
+        Drain d;
+        const int gy = g.ty0 + wave * 4 + mf * 2 + (r >> 4), gx = g.tx0 + (r & 15);
+        d.inb = gy < a.H && gx < a.W;
+        d.mk = d.inb ? 1.f : 0.f;
+        d.yp = a.y + (((size_t)g.b * a.H + gy) * a.W + gx) * C64 + 16 * h;
+        return d;
+    };
+    unsigned pk[8];
+    // micro-step m = 0..17 of draining half mf: m = 9 nf + j; j < 8: pair j (statistics + pack), j == 8: the two stores
+    auto drain_step = [&](int m, int mf, const Drain& d) {
+        const int nf = m / 9, j = m - nf * 9;
+        if (j < 8) {
+            const float v0 = acc[mf][nf][2 * j], v1 = acc[mf][nf][2 * j + 1];
+            if (STATS) {   // scalar f32 on purpose (packed f32 VALU is slow beside MFMAs)
+                const float t0 = v0 * d.mk, t1 = v1 * d.mk;
+                s1[nf][j][0] += t0; s1[nf][j][1] += t1;
+                s2[nf][j][0] = __builtin_fmaf(t0, v0, s2[nf][j][0]);
+                s2[nf][j][1] = __builtin_fmaf(t1, v1, s2[nf][j][1]);
+            }
+            const bf16x2 p2 = {(bf16_t)v0, (bf16_t)v1};
+            pk[j] = __builtin_bit_cast(unsigned, p2);
+        } else if (d.inb && !(STAMPS && (a.dbg & 2))) {
+            *reinterpret_cast<u32x4*>(d.yp + nf * 32) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+            *reinterpret_cast<u32x4*>(d.yp + nf * 32 + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
         }
-        bf16x8 af[2][2], bfr[2][2];
+    };
+    // one pass over K for pixel fragment mf of the halo tile sX; optionally drains half dmf of `d` on the way
+    auto pass = [&](const bf16_t* sX, int mf, bool drain, int dmf, const Drain& d) {
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) acc[mf][nf] = *reinterpret_cast<const f32x16*>(sBias + nf * 32 + 16 * h);
+        if (STAMPS && (a.dbg & 1)) {
+            if (drain) {
+#pragma unroll
+                for (int m = 0; m < 18; ++m) drain_step(m, dmf, d);
+            }
+            return;
+        }
+        constexpr int PF = STATS ? 2 : 3;   // fragment ring: fetched PF-1 steps ahead of use (the statistics take the registers)
+        bf16x8 af[PF], bfr[PF][2];
         auto load_frags = [&](int sidx, int buf) {
             const int tap = sidx >> 2, ks = sidx & 3;
             const int kh = tap / 3, kw = tap - kh * 3;
-#pragma unroll
-            for (int mf = 0; mf < 2; ++mf)
-                af[buf][mf] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sX) + aoff[kw][ks] + (mf * 2 + kh) * (HW * C64 * 2));
+            af[buf] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sX) + aoff[kw][ks] + (mf * 2 + kh) * (HW * C64 * 2));
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf)
                 bfr[buf][nf] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sW) + boff[ks] + (tap * C64 + nf * 32) * (C64 * 2));
         };
-        if (!(STAMPS && (a.dbg & 1))) {
-        load_frags(0, 0);
+#pragma unroll
+        for (int i = 0; i < PF - 1; ++i) load_frags(i, i);
 #pragma unroll
         for (int sidx = 0; sidx < 36; ++sidx) {
-            const int cb = sidx & 1;
-            if (sidx + 1 < 36) load_frags(sidx + 1, cb ^ 1);
-            __builtin_amdgcn_sched_barrier(0);  // reads of step s+1 stay ahead of the MFMAs of step s
+            const int cb = sidx % PF;
+            if (sidx + PF - 1 < 36) load_frags(sidx + PF - 1, (sidx + PF - 1) % PF);
+            __builtin_amdgcn_sched_barrier(0);  // reads of later steps stay ahead of the MFMAs of step s
 #pragma unroll
-            for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < 2; ++nf)
-                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cb][nf], af[cb][mf], acc[mf][nf], 0, 0, 0);
+            for (int nf = 0; nf < 2; ++nf)
+                acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cb][nf], af[cb], acc[mf][nf], 0, 0, 0);
+            if (drain && (sidx & 1) == 0) drain_step(sidx >> 1, dmf, d);
             __builtin_amdgcn_sched_barrier(0);
         }
-        }
-        stamp(0);  // MFMA loop
-        // ---- epilogue from registers (bias already inside): BatchNorm partial sums (packed f32 pairs), bf16 pack, 2 x 16-byte stores
-        const bool full_tile = g.ty0 + TH <= a.H && g.tx0 + TW <= a.W;   // wave-uniform
+    };
+    __syncthreads();  // filter + first halo tile visible
+    stamp(-1);
+
+    if (t_begin < t_end) {
+        Drain dnone; dnone.yp = a.y; dnone.mk = 0.f; dnone.inb = false;
+        pass(sX0, 0, false, 0, dnone);                       // prologue: first half of the first tile
+        stamp(0);
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            const TileGeo g = geo(tile);
+            const bf16_t* sX = sX0 + ((tile - t_begin) & 1) * (NPIX * C64);
+            pass(sX, 1, true, 0, drain_of(g, 0));            // second half; drain the first
+            stamp(1);
+            __syncthreads();  // X[t&1] is free for the producers, X[(t+1)&1] is ready
+            stamp(2);
+            const Drain d1 = drain_of(g, 1);
+            if (tile + 1 < t_end) {
+                pass(sX0 + (((tile - t_begin) & 1) ^ 1) * (NPIX * C64), 0, true, 1, d1);   // next tile's first half; drain the second
+            } else {
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf) {
-            const int gy = g.ty0 + wave * 4 + mf * 2 + (r >> 4), gx = g.tx0 + (r & 15);
-            const bool inb = full_tile || (gy < a.H && gx < a.W);
-            bf16_t* yp = a.y + (((size_t)g.b * a.H + gy) * a.W + gx) * C64 + 16 * h;
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf) {
-                unsigned pk[8];
-                f32x2 v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = f32x2{acc[mf][nf][2 * j], acc[mf][nf][2 * j + 1]};
-                if (STATS) {
-                    if (full_tile) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { s1[nf][j] += v[j]; s2[nf][j] = __builtin_elementwise_fma(v[j], v[j], s2[nf][j]); }
-                    } else {
-                        const float mk = inb ? 1.f : 0.f;
-                        const f32x2 mk2 = {mk, mk};
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { const f32x2 t = v[j] * mk2; s1[nf][j] += t; s2[nf][j] = __builtin_elementwise_fma(t, v[j], s2[nf][j]); }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bf16x2 p2 = {(bf16_t)v[j][0], (bf16_t)v[j][1]};
-                    pk[j] = __builtin_bit_cast(unsigned, p2);
-                }
-                if (inb && !(STAMPS && (a.dbg & 2))) {
-                    *reinterpret_cast<u32x4*>(yp + nf * 32) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-                    *reinterpret_cast<u32x4*>(yp + nf * 32 + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
-                }
+                for (int m = 0; m < 18; ++m) drain_step(m, 1, d1);
             }
+            stamp(0);
         }
-        stamp(1);  // epilogue issue
-        __syncthreads();  // X[t&1] is free for the producers, X[(t+1)&1] is ready
-        stamp(2);  // barrier
     }
     if (STAMPS && stamps && tid == 0) {
         unsigned long long rt_end;
@@ -357,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned
 extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const float* in_scale, const float* in_shift,
                                             void* y, float* stat, int B, int H, int W, unsigned long long* stamps, int dbg, void* stream) {
     WsArgs a;
-    a.dbg = dbg;
+    a.dbg = dbg; a.xcd_map = 1;
     a.x = (const bf16_t*)x; a.ldx = 64; a.wp = (const bf16_t*)wp; a.bias = nullptr; a.nbias = 0; a.in_scale = in_scale;
     a.in_shift = in_shift; a.y = (bf16_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
@@ -370,6 +422,9 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
 }
 
 static int g_ws_reverse = 0;
+static int g_ws_variant = 0;
+extern "C" void wm_debug_ws_variant(int v) { g_ws_variant = v; }
+
 extern "C" void wm_debug_ws_direction(int reverse) { g_ws_reverse = reverse; }
 
 // launcher used by conv3x3.hip
@@ -377,7 +432,7 @@ int wm_launch_conv3x3_ws64(const void* x, int ldx, const void* wp, const float* 
                            const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
                            hipStream_t s) {
     WsArgs a;
-    a.dbg = 0;
+    a.dbg = 0; a.xcd_map = g_ws_variant != 2;
     a.x = (const bf16_t*)x; a.ldx = ldx; a.wp = (const bf16_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
     a.in_shift = in_shift; a.y = (bf16_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY; a.tiles_per_wg = tiles_per_wg;

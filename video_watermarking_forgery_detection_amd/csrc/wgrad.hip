@@ -145,7 +145,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgArgs<T> a) {
     };
 
     const int per = (a.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int t_begin = blockIdx.x * per, t_end = min(a.ntiles, t_begin + per);
+    // XCD-aware run assignment (workgroups b and b+8 share an XCD): XCD x walks consecutive runs
+    const int G = gridDim.x;
+    const int run = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int t_begin = run * per, t_end = min(a.ntiles, t_begin + per);
 
     // one register set (a second one spills next to the 144 accumulator registers): the loads of tile+1 are
     // issued in the first 19 of the 32 slots of the MFMA loop of tile, so the last of them still has ~40 % of

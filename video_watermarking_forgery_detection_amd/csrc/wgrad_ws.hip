@@ -46,8 +46,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(WsWgArgs a) {
     const int cc = blockIdx.y / a.coBlocks, oc = blockIdx.y % a.coBlocks;
     const int ci0 = cc * CB, co0 = oc * CB;
     // balanced contiguous runs of tiles
-    const int t_begin = (int)(((long)blockIdx.x * a.ntiles) / (int)gridDim.x);
-    const int t_end = (int)(((long)(blockIdx.x + 1) * a.ntiles) / (int)gridDim.x);
+    // XCD-aware run assignment (workgroups b and b+8 share an XCD): XCD x walks the consecutive runs
+    // [x*G/8, (x+1)*G/8), so vertically adjacent tile rows share their halo rows in one L2
+    const int G = gridDim.x;
+    const int run = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int t_begin = (int)(((long)run * a.ntiles) / G);
+    const int t_end = (int)(((long)(run + 1) * a.ntiles) / G);
     struct TileGeo { int b, ty0, tx0; };
     auto geo = [&](int tile) {
         TileGeo g;
