@@ -1,4 +1,5 @@
-// Wave-specialised persistent 3x3 convolution for bf16, Cin = Cout = 64 (gfx950).
+// Wave-specialised persistent 3x3 convolution for bf16, Cout = 64, Cin = 64 (body layers, dgrad) or 16 (image-fed
+// first layers) (gfx950).
 //
 // Why: tools/phase_c64.py shows that a single wave per SIMD cannot overlap its own phases -- the MFMA loop
 // (4,742 cycles / tile), the HBM traffic of a tile (78 KB per CU = ~7,400 cycles at the ~10.7 B/clk a CU gets)
@@ -23,7 +24,6 @@ namespace {
 constexpr int TH = 16, TW = 16, HH = 18, HW = 18;
 constexpr int C64 = 64;
 constexpr int NPIX = HH * HW;                  // 324 halo pixels
-constexpr int XVP = (NPIX * 8 + 255) / 256;    // halo vectors per PRODUCER thread (256 producer threads): 11
 
 struct WsArgs {
     const bf16_t* x; int ldx;
@@ -42,8 +42,10 @@ struct WsArgs {
 // not depend on the halo ROW, so for a consumer lane the swizzled address of tap (kh, kw) is a per-(kw, k-step)
 // register plus a compile-time (kh, M-fragment) offset; 16 consecutive pixels of a row (from any kw) and the
 // pixels of the row below all land on distinct 16-byte bank slots.
-__device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
-__device__ __forceinline__ int swz_px(int px, int slot) { return slot ^ ((px >> 1) & 7); }
+// CIN = 16 (image-fed first layers: two 16-byte vectors per pixel) is stored unswizzled: its 9-step MFMA loop is a
+// small part of a store-bound kernel.
+template <int CIN> __device__ __forceinline__ int swz(int row, int slot) { return CIN == 64 ? slot ^ ((row >> 1) & 7) : slot; }
+template <int CIN> __device__ __forceinline__ int swz_px(int px, int slot) { return CIN == 64 ? slot ^ ((px >> 1) & 7) : slot; }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
@@ -51,8 +53,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 // STAMPS: diagnostic build only (tools/phase_ws.py) -- per-role cycle totals of the phases of the tile loop
-template <bool XFORM, bool STATS, bool STAMPS = false>
-__global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned long long* __restrict__ stamps = nullptr) {
+template <int CIN, bool XFORM, bool STATS, bool STAMPS = false>
+__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned long long* __restrict__ stamps = nullptr) {
+    static_assert(CIN == 64 || CIN == 16, "input channels");
+    constexpr int VPP = CIN / 8;                       // 16-byte vectors per pixel
+    constexpr int KS = CIN / 16;                       // MFMA k-steps per filter tap
+    constexpr int NSTEP = 9 * KS;
+    constexpr int XVP = (NPIX * VPP + 255) / 256;      // halo vectors per PRODUCER thread (256 producer threads)
     unsigned long long ph[4] = {0, 0, 0, 0}, tlast = 0, t_start = 0, rt_start = 0;
     auto now = [&]() {
         unsigned long long t;
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned
         t_start = now();
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_start)::"memory");
     }
-    constexpr int SW_BYTES = 9 * C64 * C64 * 2, SX_BYTES = NPIX * C64 * 2;
+    constexpr int SW_BYTES = 9 * C64 * CIN * 2, SX_BYTES = NPIX * CIN * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SW_BYTES + 2 * SX_BYTES + 4 * 2 * C64 * 4 + C64 * 4];
     bf16_t* sW = reinterpret_cast<bf16_t*>(smem);
     bf16_t* sX0 = reinterpret_cast<bf16_t*>(smem + SW_BYTES);  // two halo tiles back to back
@@ -87,21 +94,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned
     // rho(c) = (i&3) + 8(i>>2) + 4hh with hh = c>>4, i = c&15: register i of lane half h is channel 16h + i, and a
     // lane owns 16 ADJACENT channels of its pixel -- two 16-byte stores, no transpose.
     {
-        constexpr int WV = 9 * C64 * 8 / 512;  // 9 vectors per thread
+        constexpr int NV = 9 * C64 * VPP, WV = (NV + 511) / 512;
         bf16x8 wv[WV];
 #pragma unroll
         for (int k = 0; k < WV; ++k) {
-            const int i = tid + 512 * k;
-            wv[k] = *reinterpret_cast<const bf16x8*>(a.wp + (size_t)(i >> 3) * C64 + (i & 7) * 8);
+            const int i = min(tid + 512 * k, NV - 1);
+            wv[k] = *reinterpret_cast<const bf16x8*>(a.wp + (size_t)(i / VPP) * CIN + (i % VPP) * 8);
         }
 #pragma unroll
         for (int k = 0; k < WV; ++k) {
             const int i = tid + 512 * k;
-            const int row = i >> 3, tap = row >> 6, n = row & 63;
+            const int row = i / VPP, tap = row >> 6, n = row & 63;
             const int c = n & 31, ci = c & 15;
             const int rho = (ci & 3) + 8 * (ci >> 2) + 4 * (c >> 4);
             const int lrow = tap * C64 + (n >> 5) * 32 + rho;
-            *reinterpret_cast<bf16x8*>(sW + lrow * C64 + swz(lrow, i & 7) * 8) = wv[k];
+            if (i < NV) *reinterpret_cast<bf16x8*>(sW + lrow * CIN + swz<CIN>(lrow, i % VPP) * 8) = wv[k];
         }
     }
 
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned
         // ================================================================== PRODUCER waves
         if (!(STAMPS && (a.dbg & 8))) __builtin_amdgcn_s_setprio(3);   // their few VALU / LDS / memory instructions go first
         const int ptid = tid - 256;
-        const int vec = ptid & 7;
+        const int vec = ptid % VPP;
         f32x2 sc2[4], sh2[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sc2[e] = f32x2{1.f, 1.f}; sh2[e] = f32x2{0.f, 0.f}; }
@@ -141,12 +148,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned
         int hpy[XVP], hpx[XVP], rel[XVP], lds[XVP];
 #pragma unroll
         for (int k = 0; k < XVP; ++k) {
-            const int pix = min((ptid + 256 * k) >> 3, NPIX - 1);
+            const int pix = min((ptid + 256 * k) / VPP, NPIX - 1);
             hpy[k] = pix / HW; hpx[k] = pix - hpy[k] * HW;
             rel[k] = (hpy[k] * a.W + hpx[k]) * a.ldx + vec * 8;
-            lds[k] = pix * C64 + swz_px(hpx[k], vec) * 8;
+            lds[k] = pix * CIN + swz_px<CIN>(hpx[k], vec) * 8;
         }
-        const bool last_live = ((ptid + 256 * (XVP - 1)) >> 3) < NPIX;
+        const bool last_live = ((ptid + 256 * (XVP - 1)) / VPP) < NPIX;
         // loads: always a valid address, never under a per-lane branch; the branches on `interior` are wave-uniform
         auto is_interior = [&](const TileGeo& g) {
             return g.ty0 >= 1 && g.ty0 + TH + 1 <= a.H && g.tx0 >= 1 && g.tx0 + TW + 1 <= a.W;
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned
         // the loads of tile+2 go into `nxt`; one load, one vector of VALU work, alternating, so the memory queue is fed
         // at an even pace and never holds the whole burst
         auto iter = [&](int tile, bf16x8 (&nxt)[XVP], unsigned& oknxt, const bf16x8 (&cur)[XVP], unsigned okcur) {
-            bf16_t* sXn = sX0 + (((tile - t_begin) & 1) ^ 1) * (NPIX * C64);
+            bf16_t* sXn = sX0 + (((tile - t_begin) & 1) ^ 1) * (NPIX * CIN);
             const bool have_next = tile + 2 < t_end && !(STAMPS && (a.dbg & 4));
             if (have_next) {
                 const TileGeo g2 = geo(tile + 2);
@@ -269,16 +276,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s1[nf][j] = f32x2{0.f, 0.f}; s2[nf][j] = f32x2{0.f, 0.f}; }
     // swizzled LDS byte offsets of this lane's fragments (see swz_px): 12 + 4 registers, everything else immediate
-    int aoff[3][4], boff[4];
+    int aoff[3][KS], boff[KS];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             const int px = (r & 15) + kw;
-            aoff[kw][ks] = (((wave * 4 + (r >> 4)) * HW + px) * C64 + swz_px(px, ks * 2 + h) * 8) * 2;
+            aoff[kw][ks] = (((wave * 4 + (r >> 4)) * HW + px) * CIN + swz_px<CIN>(px, ks * 2 + h) * 8) * 2;
         }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) boff[ks] = (r * C64 + swz(r, ks * 2 + h) * 8) * 2;
+    for (int ks = 0; ks < KS; ++ks) boff[ks] = (r * CIN + swz<CIN>(r, ks * 2 + h) * 8) * 2;
 
     f32x16 acc[2][2];   // [pixel fragment mf][channel fragment nf]
     struct Drain { bf16_t* yp; float mk; bool inb; };
@@ -323,24 +330,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned
         constexpr int PF = STATS ? 2 : 3;   // fragment ring: fetched PF-1 steps ahead of use (the statistics take the registers)
         bf16x8 af[PF], bfr[PF][2];
         auto load_frags = [&](int sidx, int buf) {
-            const int tap = sidx >> 2, ks = sidx & 3;
+            const int tap = sidx / KS, ks = sidx % KS;
             const int kh = tap / 3, kw = tap - kh * 3;
-            af[buf] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sX) + aoff[kw][ks] + (mf * 2 + kh) * (HW * C64 * 2));
+            af[buf] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sX) + aoff[kw][ks] + (mf * 2 + kh) * (HW * CIN * 2));
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf)
-                bfr[buf][nf] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sW) + boff[ks] + (tap * C64 + nf * 32) * (C64 * 2));
+                bfr[buf][nf] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sW) + boff[ks] + (tap * C64 + nf * 32) * (CIN * 2));
         };
 #pragma unroll
         for (int i = 0; i < PF - 1; ++i) load_frags(i, i);
 #pragma unroll
-        for (int sidx = 0; sidx < 36; ++sidx) {
+        for (int sidx = 0; sidx < NSTEP; ++sidx) {
             const int cb = sidx % PF;
-            if (sidx + PF - 1 < 36) load_frags(sidx + PF - 1, (sidx + PF - 1) % PF);
+            if (sidx + PF - 1 < NSTEP) load_frags(sidx + PF - 1, (sidx + PF - 1) % PF);
             __builtin_amdgcn_sched_barrier(0);  // reads of later steps stay ahead of the MFMAs of step s
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf)
                 acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cb][nf], af[cb], acc[mf][nf], 0, 0, 0);
-            if (drain && (sidx & 1) == 0) drain_step(sidx >> 1, dmf, d);
+            if (drain) {   // the 18 drain micro-steps, spread evenly over the pass
+#pragma unroll
+                for (int m = sidx * 18 / NSTEP; m < (sidx + 1) * 18 / NSTEP; ++m) drain_step(m, dmf, d);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -353,14 +363,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(WsArgs a, unsigned
         stamp(0);
         for (int tile = t_begin; tile < t_end; ++tile) {
             const TileGeo g = geo(tile);
-            const bf16_t* sX = sX0 + ((tile - t_begin) & 1) * (NPIX * C64);
+            const bf16_t* sX = sX0 + ((tile - t_begin) & 1) * (NPIX * CIN);
             pass(sX, 1, true, 0, drain_of(g, 0));            // second half; drain the first
             stamp(1);
             __syncthreads();  // X[t&1] is free for the producers, X[(t+1)&1] is ready
             stamp(2);
             const Drain d1 = drain_of(g, 1);
             if (tile + 1 < t_end) {
-                pass(sX0 + (((tile - t_begin) & 1) ^ 1) * (NPIX * C64), 0, true, 1, d1);   // next tile's first half; drain the second
+                pass(sX0 + (((tile - t_begin) & 1) ^ 1) * (NPIX * CIN), 0, true, 1, d1);   // next tile's first half; drain the second
             } else {
 #pragma unroll
                 for (int m = 0; m < 18; ++m) drain_step(m, 1, d1);
@@ -416,8 +426,8 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
     const int wgs = a.ntiles < 256 ? a.ntiles : 256;
     a.tiles_per_wg = wm_cdiv(a.ntiles, wgs); a.reverse = 0;
     const dim3 grid((unsigned)wm_cdiv(a.ntiles, a.tiles_per_wg)), block(512);
-    if (in_scale && stat) hipLaunchKernelGGL((conv3x3_ws64_kernel<true, true, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
-    else hipLaunchKernelGGL((conv3x3_ws64_kernel<false, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
+    if (in_scale && stat) hipLaunchKernelGGL((conv3x3_ws_kernel<64, true, true, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
+    else hipLaunchKernelGGL((conv3x3_ws_kernel<64, false, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
     return (int)grid.x;
 }
 
@@ -428,7 +438,7 @@ extern "C" void wm_debug_ws_variant(int v) { g_ws_variant = v; }
 extern "C" void wm_debug_ws_direction(int reverse) { g_ws_reverse = reverse; }
 
 // launcher used by conv3x3.hip
-int wm_launch_conv3x3_ws64(const void* x, int ldx, const void* wp, const float* bias, int nbias, const float* in_scale,
+int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, const void* wp, const float* bias, int nbias, const float* in_scale,
                            const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
                            hipStream_t s) {
     WsArgs a;
@@ -439,9 +449,15 @@ int wm_launch_conv3x3_ws64(const void* x, int ldx, const void* wp, const float* 
     a.reverse = g_ws_reverse;
     const dim3 grid((unsigned)wgs), block(512);
     const bool xf = in_scale != nullptr, st = stat != nullptr;
-    if (xf && st) hipLaunchKernelGGL((conv3x3_ws64_kernel<true, true>), grid, block, 0, s, a);
-    else if (xf) hipLaunchKernelGGL((conv3x3_ws64_kernel<true, false>), grid, block, 0, s, a);
-    else if (st) hipLaunchKernelGGL((conv3x3_ws64_kernel<false, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((conv3x3_ws64_kernel<false, false>), grid, block, 0, s, a);
+#define WM_WS_LAUNCH(CIN_)                                                                                      \
+    do {                                                                                                        \
+        if (xf && st) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, true, true>), grid, block, 0, s, a, nullptr);   \
+        else if (xf) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, true, false>), grid, block, 0, s, a, nullptr);   \
+        else if (st) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, false, true>), grid, block, 0, s, a, nullptr);   \
+        else hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, false, false>), grid, block, 0, s, a, nullptr);          \
+    } while (0)
+    if (Cin == 64) WM_WS_LAUNCH(64);
+    else WM_WS_LAUNCH(16);
+#undef WM_WS_LAUNCH
     return WM_OK;
 }
