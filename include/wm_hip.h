@@ -124,6 +124,11 @@ int wm_bnrelu_copy(const void* x, int ldx, const float* scale, const float* shif
  * transpose != 0 builds the dgrad operand instead: [9][CinP][CoutP] with taps flipped. */
 int wm_pack_w3x3(const float* w, void* wp, int Cout, int Cin, int CoutP, int CinP, const int* perm,
                  int transpose, int dtype, void* stream);
+/* batched form: all convs of a network in ONE launch (the weights change every optimiser step, so every
+ * step re-packs them).  jobs_dev: DEVICE array of njobs records of 48 bytes each,
+ *   { const float* w; void* wp; const int* perm ( DEVICE int[Cin] or NULL ); int Cout, Cin, CoutP, CinP, transpose, pad; }
+ * with the meaning of wm_pack_w3x3's arguments; max_elems = the largest 9*RowsP*ColsP among the jobs. */
+int wm_pack_w3x3_batch(const void* jobs_dev, int njobs, size_t max_elems, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ conv 3x3, stride 1, pad 1
  * replaces: nn.Conv2d(…,3,1,padding=1) inside hidden_models/conv_bn_relu.py:11-15 and

@@ -42,19 +42,21 @@ inline int tree_reduce_rows(float* rows, int n, int W, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ forward statistics
-// partials: [nparts][2][CP] (sum, sum of squares).  One workgroup per 32 channels, 8 slices of parts.
+// partials: [nparts][2][CP] (sum, sum of squares).  One workgroup per 8 channels, 32 slices of parts.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nparts, int C, int CP,
                                                           double count, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* running_mean,
                                                           float* running_var, float momentum, float eps,
                                                           float* scale, float* shift, float* mean_out,
                                                           float* invstd_out) {
-    __shared__ double s1[8][32], s2[8][32];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    // 8 channels x 32 row slices per workgroup: every thread's <= 8 row loads are independent and in flight together
+    __shared__ double s1[32][8], s2[32][8];
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double a1 = 0.0, a2 = 0.0;
     if (c < CP) {
-        for (int p = sl; p < nparts; p += 8) {
+#pragma unroll 8
+        for (int p = sl; p < nparts; p += 32) {
             a1 += (double)partials[((size_t)p * 2 + 0) * CP + c];
             a2 += (double)partials[((size_t)p * 2 + 1) * CP + c];
         }
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     s1[sl][cl] = a1; s2[sl][cl] = a2;
     __syncthreads();
     if (sl == 0 && c < CP) {
-        for (int k = 1; k < 8; ++k) { a1 += s1[k][cl]; a2 += s2[k][cl]; }
+        for (int k = 1; k < 32; ++k) { a1 += s1[k][cl]; a2 += s2[k][cl]; }
         if (c < C) {
             const double m = a1 / count;
             double var = a2 / count - m * m;
@@ -86,8 +88,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 
 // ------------------------------------------------------------------ backward, pass 1
 // thread -> (pixel slot, 16-byte channel vector).  VPP vectors per pixel, PPB pixels per block-iteration.
-template <typename T, bool APPLY>
-__global__ __launch_bounds__(RED_THREADS) void bn_bwd_kernel(const T* __restrict__ g, int ldg, const float* __restrict__ gvec,
+// BT threads per workgroup: the passes that emit partial rows run 1024-thread workgroups on a grid of <= 256, so that the
+// finalisation walks 256 rows directly (no intermediate tree reduction); the pure apply pass streams with 256.
+template <typename T, bool APPLY, int BT>
+__global__ __launch_bounds__(BT) void bn_bwd_kernel(const T* __restrict__ g, int ldg, const float* __restrict__ gvec,
                                                              const T* __restrict__ y, int ldy,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_kernel(const T* __restrict
                                                              float* __restrict__ partials, size_t npix, size_t hw, int CP) {
     constexpr int VE = vec16<T>::N;
     const int VPP = CP / VE;
-    const int PPB = RED_THREADS / VPP;  // pixels per block iteration (VPP divides 256 for CP in {32,64,128,256,512})
+    const int PPB = BT / VPP;  // pixels per block iteration (VPP divides 256 for CP in {32,64,128,256,512})
     const int vv = threadIdx.x % VPP, ps = threadIdx.x / VPP;
     const int c0 = vv * VE;
     float sc[VE], sh[VE], mu[VE], is[VE], ca[VE], c1[VE], c2[VE];
@@ -136,12 +140,12 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_kernel(const T* __restrict
     }
     if (!partials) return;
     // block reduction over the PPB pixel slots that share a channel vector
-    __shared__ float red[2][RED_THREADS][vec16<T>::N + 1];
+    __shared__ float red[APPLY ? 1 : 2][BT][vec16<T>::N + 1];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) { red[0][threadIdx.x][e] = a1[e]; red[1][threadIdx.x][e] = a2[e]; }
+    for (int e = 0; e < VE; ++e) { red[0][threadIdx.x][e] = a1[e]; if (!APPLY) red[APPLY ? 0 : 1][threadIdx.x][e] = a2[e]; }
     __syncthreads();
     const int nwhich = APPLY ? 1 : 2;
-    for (int i = threadIdx.x; i < nwhich * CP; i += RED_THREADS) {
+    for (int i = threadIdx.x; i < nwhich * CP; i += BT) {
         const int which = i / CP, c = i - which * CP;
         const int v2 = c / VE, e = c - v2 * VE;
         float s = 0.f;
@@ -155,12 +159,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ invstd, float* dgamma,
                                                               float* dbeta, int accumulate, float* coef) {
-    __shared__ double s1[8][32], s2[8][32];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    // 8 channels x 32 row slices per workgroup: every thread's <= 8 row loads are independent and in flight together
+    __shared__ double s1[32][8], s2[32][8];
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double a1 = 0.0, a2 = 0.0;
     if (c < CP) {
-        for (int p = sl; p < nparts; p += 8) {
+#pragma unroll 8
+        for (int p = sl; p < nparts; p += 32) {
             a1 += (double)partials[((size_t)p * 2 + 0) * CP + c];
             a2 += (double)partials[((size_t)p * 2 + 1) * CP + c];
         }
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     s1[sl][cl] = a1; s2[sl][cl] = a2;
     __syncthreads();
     if (sl == 0 && c < CP) {
-        for (int k = 1; k < 8; ++k) { a1 += s1[k][cl]; a2 += s2[k][cl]; }
+        for (int k = 1; k < 32; ++k) { a1 += s1[k][cl]; a2 += s2[k][cl]; }
         if (c < C) {
             if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)a1;
             if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)a2;
@@ -270,15 +276,16 @@ extern "C" int wm_bn_finalize(const float* partials, int nparts, int C, int CP, 
     WM_REQUIRE(nparts > 0 && C > 0 && CP >= C && count > 0, WM_E_BADARG, "wm_bn_finalize: bad sizes");
     WM_REQUIRE((running_mean == nullptr) == (running_var == nullptr), WM_E_BADARG, "wm_bn_finalize: running stats must come together");
     nparts = tree_reduce_rows(const_cast<float*>(partials), nparts, 2 * CP, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(wm_cdiv(CP, 32)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C, CP,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(wm_cdiv(CP, 8)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C, CP,
                        count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
     WM_LAUNCH_CHECK("wm_bn_finalize");
     return WM_OK;
 }
 
+constexpr int BWD_BT = 1024;
 extern "C" int wm_bn_bwd_nparts(size_t npix) {
-    const size_t n = (npix + 255) / 256;
-    return (int)(n < 1 ? 1 : (n > 2048 ? 2048 : n));
+    const size_t n = (npix + BWD_BT - 1) / BWD_BT;
+    return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
 }
 
 extern "C" int wm_bn_bwd_reduce(const void* g, int ldg, const float* gvec, const void* y, int ldy, const float* scale,
@@ -291,7 +298,7 @@ extern "C" int wm_bn_bwd_reduce(const void* g, int ldg, const float* gvec, const
     const int nparts = wm_bn_bwd_nparts(npix);
     hipStream_t s = (hipStream_t)stream;
     WM_DISPATCH_DTYPE(dtype, "wm_bn_bwd_reduce",
-        hipLaunchKernelGGL((bn_bwd_kernel<T, false>), dim3(nparts), dim3(RED_THREADS), 0, s, (const T*)g, ldg, gvec,
+        hipLaunchKernelGGL((bn_bwd_kernel<T, false, BWD_BT>), dim3(nparts), dim3(BWD_BT), 0, s, (const T*)g, ldg, gvec,
                            (const T*)y, ldy, scale, shift, mean, invstd, (const float*)nullptr, (T*)nullptr, 0, partials,
                            npix, hw, CP));
     WM_LAUNCH_CHECK("wm_bn_bwd_reduce");
@@ -303,7 +310,7 @@ extern "C" int wm_bn_bwd_finalize(const float* partials, int nparts, int C, int 
                                   void* stream) {
     WM_REQUIRE(partials && gamma && invstd && coef, WM_E_BADARG, "wm_bn_bwd_finalize: null pointer");
     nparts = tree_reduce_rows(const_cast<float*>(partials), nparts, 2 * CP, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(wm_cdiv(CP, 32)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(wm_cdiv(CP, 8)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C,
                        CP, count, gamma, invstd, dgamma, dbeta, accumulate, coef);
     WM_LAUNCH_CHECK("wm_bn_bwd_finalize");
     return WM_OK;
@@ -318,9 +325,17 @@ extern "C" int wm_bn_bwd_apply(const void* g, int ldg, const float* gvec, const 
     const size_t npix = (size_t)B * hw;
     const int nparts = wm_bn_bwd_nparts(npix);
     hipStream_t s = (hipStream_t)stream;
-    WM_DISPATCH_DTYPE(dtype, "wm_bn_bwd_apply",
-        hipLaunchKernelGGL((bn_bwd_kernel<T, true>), dim3(nparts), dim3(RED_THREADS), 0, s, (const T*)g, ldg, gvec,
-                           (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, dbias_partials, npix, hw, CP));
+    if (dbias_partials) {   // rows for wm_colsum_finalize: same grid as the reduce pass
+        WM_DISPATCH_DTYPE(dtype, "wm_bn_bwd_apply",
+            hipLaunchKernelGGL((bn_bwd_kernel<T, true, BWD_BT>), dim3(nparts), dim3(BWD_BT), 0, s, (const T*)g, ldg, gvec,
+                               (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, dbias_partials, npix, hw, CP));
+    } else {
+        const size_t nb = (npix + 255) / 256;
+        const int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+        WM_DISPATCH_DTYPE(dtype, "wm_bn_bwd_apply",
+            hipLaunchKernelGGL((bn_bwd_kernel<T, true, 256>), dim3(grid), dim3(256), 0, s, (const T*)g, ldg, gvec,
+                               (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, dbias_partials, npix, hw, CP));
+    }
     WM_LAUNCH_CHECK("wm_bn_bwd_apply");
     return WM_OK;
 }

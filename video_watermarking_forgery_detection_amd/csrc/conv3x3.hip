@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(ConvArgs<bf16_t> a,
 constexpr int C64_MAX_WGS = 256;  // one persistent workgroup per CU
 inline bool use_c64(int Cin, int CoutP, int dtype) {
     static const bool off = getenv("WM_NO_C64") != nullptr;  // diagnostic knob: force the generic kernel
-    return !off && dtype == WM_BF16 && (Cin == 64 || Cin == 16) && CoutP == 64;
+    return !off && dtype == WM_BF16 && (Cin == 64 || Cin == 32 || Cin == 16) && CoutP == 64;
 }  // + ldy == 64 (always true for a 64-channel output tensor)
 inline int c64_tiles_per_wg(int ntiles) { return (ntiles + C64_MAX_WGS - 1) / C64_MAX_WGS; }
 inline int c64_wgs(int ntiles) { const int per = c64_tiles_per_wg(ntiles); return (ntiles + per - 1) / per; }
@@ -590,6 +590,38 @@ __global__ void pack_w3x3_kernel(const float* __restrict__ w, T* __restrict__ wp
                 for (int q = 0; q < Cin; ++q) if (perm.p[q] == cip) { ci = q; break; }
             }
             if (ci >= 0) v = w[(((size_t)co * Cin + ci) * 3 + kh) * 3 + kw];
+        }
+        wp[i] = from_f32<T>(v);
+    }
+}
+
+// batched form: one launch packs every conv of a network (blockIdx.y = job).  Jobs live in device memory.
+struct PackJob {
+    const float* w; void* wp; const int* perm;   // perm: device int[Cin] or null
+    int Cout, Cin, CoutP, CinP, transpose, pad;
+};
+template <typename T>
+__global__ void pack_w3x3_batch_kernel(const PackJob* __restrict__ jobs) {
+    const PackJob j = jobs[blockIdx.y];
+    const int rowsP = j.transpose ? j.CinP : j.CoutP, colsP = j.transpose ? j.CoutP : j.CinP;
+    const size_t total = (size_t)9 * rowsP * colsP;
+    T* wp = (T*)j.wp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % colsP);
+        const int row = (int)((i / colsP) % rowsP);
+        const int tap = (int)(i / ((size_t)colsP * rowsP));
+        const int co = j.transpose ? col : row;
+        const int cip = j.transpose ? row : col;
+        int kh = tap / 3, kw = tap % 3;
+        if (j.transpose) { kh = 2 - kh; kw = 2 - kw; }
+        float v = 0.f;
+        if (co < j.Cout) {
+            int ci = -1;
+            if (!j.perm) ci = cip < j.Cin ? cip : -1;
+            else {
+                for (int q = 0; q < j.Cin; ++q) if (j.perm[q] == cip) { ci = q; break; }
+            }
+            if (ci >= 0) v = j.w[(((size_t)co * j.Cin + ci) * 3 + kh) * 3 + kw];
         }
         wp[i] = from_f32<T>(v);
     }
@@ -654,7 +686,7 @@ extern "C" int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const floa
                "wm_conv3x3_fwd: pixel strides ldx=%d ldy=%d must cover the channels and be 16-byte multiples", ldx, ldy);
     WM_REQUIRE((((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y) & 15) == 0, WM_E_SHAPE, "wm_conv3x3_fwd: pointers must be 16-byte aligned");
     WM_REQUIRE(!use_c64(Cin, CoutP, dtype) || ldy == 64, WM_E_SHAPE,
-               "wm_conv3x3_fwd: the bf16 {16,64}->64 path writes a dense 64-channel output (ldy must be 64, got %d)", ldy);
+               "wm_conv3x3_fwd: the bf16 {16,32,64}->64 path writes a dense 64-channel output (ldy must be 64, got %d)", ldy);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == WM_BF16) launch_conv<bf16_t>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s);
     else launch_conv<float>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s);
@@ -687,6 +719,19 @@ extern "C" int wm_pack_w3x3(const float* w, void* wp, int Cout, int Cin, int Cou
     return WM_OK;
 }
 
+extern "C" int wm_pack_w3x3_batch(const void* jobs_dev, int njobs, size_t max_elems, int dtype, void* stream) {
+    WM_REQUIRE(jobs_dev && njobs > 0 && max_elems > 0, WM_E_BADARG, "wm_pack_w3x3_batch: bad arguments");
+    static_assert(sizeof(PackJob) == 48, "PackJob layout is part of the ABI (wm_hip.h)");
+    int blocks = (int)((max_elems + 255) / 256);
+    if (blocks > 64) blocks = 64;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)blocks, (unsigned)njobs);
+    if (dtype == WM_BF16) hipLaunchKernelGGL(pack_w3x3_batch_kernel<bf16_t>, grid, dim3(256), 0, s, (const PackJob*)jobs_dev);
+    else if (dtype == WM_F32) hipLaunchKernelGGL(pack_w3x3_batch_kernel<float>, grid, dim3(256), 0, s, (const PackJob*)jobs_dev);
+    else { wm_set_error("wm_pack_w3x3_batch: unsupported dtype %d", dtype); return WM_E_BADARG; }
+    WM_LAUNCH_CHECK("wm_pack_w3x3_batch");
+    return WM_OK;
+}
 
 // diagnostic only (not part of the public header): phase cycle totals of the persistent 64-channel kernel
 extern "C" int wm_debug_conv3x3_c64_phases(const void* x, const void* wp, const float* in_scale, const float* in_shift,

@@ -42,8 +42,8 @@ struct WsArgs {
 // not depend on the halo ROW, so for a consumer lane the swizzled address of tap (kh, kw) is a per-(kw, k-step)
 // register plus a compile-time (kh, M-fragment) offset; 16 consecutive pixels of a row (from any kw) and the
 // pixels of the row below all land on distinct 16-byte bank slots.
-// CIN = 16 (image-fed first layers: two 16-byte vectors per pixel) is stored unswizzled: its 9-step MFMA loop is a
-// small part of a store-bound kernel.
+// CIN = 16 / 32 (image-fed first layers, the dgrad of the 30-channel decoder layer) are stored unswizzled: their
+// 9 / 18-step MFMA loops are a small part of a store-bound kernel.
 template <int CIN> __device__ __forceinline__ int swz(int row, int slot) { return CIN == 64 ? slot ^ ((row >> 1) & 7) : slot; }
 template <int CIN> __device__ __forceinline__ int swz_px(int px, int slot) { return CIN == 64 ? slot ^ ((px >> 1) & 7) : slot; }
 
@@ -55,7 +55,7 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 // STAMPS: diagnostic build only (tools/phase_ws.py) -- per-role cycle totals of the phases of the tile loop
 template <int CIN, bool XFORM, bool STATS, bool STAMPS = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned long long* __restrict__ stamps = nullptr) {
-    static_assert(CIN == 64 || CIN == 16, "input channels");
+    static_assert(CIN == 64 || CIN == 32 || CIN == 16, "input channels");
     constexpr int VPP = CIN / 8;                       // 16-byte vectors per pixel
     constexpr int KS = CIN / 16;                       // MFMA k-steps per filter tap
     constexpr int NSTEP = 9 * KS;
@@ -457,6 +457,7 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, const void* wp, const 
         else hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, false, false>), grid, block, 0, s, a, nullptr);          \
     } while (0)
     if (Cin == 64) WM_WS_LAUNCH(64);
+    else if (Cin == 32) WM_WS_LAUNCH(32);
     else WM_WS_LAUNCH(16);
 #undef WM_WS_LAUNCH
     return WM_OK;

@@ -43,6 +43,15 @@ class CBRCtx:
     __slots__ = ("x", "y", "stats", "perm", "training")
 
 
+def _packed(conv, CoutP, CinP, dtype, perm, transpose):
+    """packed weights of `conv`: from the owning network's PackPlan (one launch per optimiser step, see
+    FlatModule.refresh_packs) when there is one, else packed on the spot."""
+    plan = getattr(conv, "_wm_plan", None)
+    if plan is None:
+        return ops.pack_w3x3(conv.weight.data, CoutP, CinP, dtype, perm=perm, transpose=transpose)
+    return plan.get(conv.weight.data, CoutP, CinP, dtype, perm=perm, transpose=transpose)
+
+
 def cbr_forward(conv, bn, x, dtype, perm=None, training=True, momentum=0.1):
     """ConvBNRelu forward (conv_bn_relu.py:11-15).  conv.weight [Cout,Cin,3,3], conv.bias or None,
     bn: BatchNorm2d parameters/buffers.  x: Act whose physical channel count (x.t.shape[-1]) is the
@@ -50,7 +59,7 @@ def cbr_forward(conv, bn, x, dtype, perm=None, training=True, momentum=0.1):
     Cout = conv.weight.shape[0]
     CoutP = round_up(Cout, 32)
     CinX = x.t.shape[-1]
-    wp = ops.pack_w3x3(conv.weight.data, CoutP, CinX, dtype, perm=perm)
+    wp = _packed(conv, CoutP, CinX, dtype, perm, False)
     bias = conv.bias.data if conv.bias is not None else None
     B, H, W, _ = x.t.shape
     y, st = ops.conv3x3_fwd(x.t, wp, bias, x.scale, x.shift, want_stats=training)
@@ -81,13 +90,16 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
     y, x = ctx.y, ctx.x
     Cout = conv.weight.shape[0]
     dtype = y.dtype
-    dbias = grads[conv.bias] if conv.bias is not None else None
+    # The gradient of a conv bias in front of a training-mode BatchNorm is identically zero (sum(dy) == 0: the batch mean
+    # removes the bias); the reference's autograd produces rounding noise of ~1e-9 there.  The bias gradient view is
+    # zero-initialised and never written, which is the exact value and saves a reduction + two launches per layer.
+    dbias = None
     dy = ops.bn_bwd(g, gvec, y, ctx.stats, Cout, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate, dbias)
     ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, perm_dev=perm_dev)
     if not need_input_grad:
         return None
     rows = dgrad_channels or round_up(x.t.shape[-1], 32)
-    wpt = ops.pack_w3x3(conv.weight.data, y.shape[-1], rows, dtype, perm=ctx.perm, transpose=True)
+    wpt = _packed(conv, y.shape[-1], rows, dtype, ctx.perm, True)
     gx, _ = ops.conv3x3_fwd(dy, wpt, None, None, None, want_stats=False)
     return gx
 
@@ -148,6 +160,31 @@ class FlatModule:
             for i, m in enumerate(bns):
                 m._buffers["num_batches_tracked"] = nbt[i]
             object.__setattr__(self, "_nbt", nbt)
+
+    # ---- packed conv weights: one launch per optimiser step instead of one per conv call
+    def pack_plan(self):
+        """the network's ops.PackPlan (created on first use; every 3x3 conv of the module points at it)."""
+        plan = getattr(self, "_pack_plan", None)
+        flat = getattr(self, "_flat", None)
+        if plan is None or getattr(self, "_pack_plan_flat", None) is not flat:
+            plan = ops.PackPlan()
+            object.__setattr__(self, "_pack_plan", plan)
+            object.__setattr__(self, "_pack_plan_flat", flat)   # a re-flatten moves the parameters: start over
+            for m in self.modules():
+                if isinstance(m, torch.nn.Conv2d) and tuple(m.kernel_size) == (3, 3):
+                    object.__setattr__(m, "_wm_plan", plan)
+        return plan
+
+    def refresh_packs(self):
+        """(re)pack every conv weight the network has used so far from the CURRENT parameters, in one launch; the packs
+        stay valid until invalidate_packs().  Callers own the validity window (Hidden.train_on_batch)."""
+        self.flatten_parameters_()
+        self.pack_plan().refresh()
+
+    def invalidate_packs(self):
+        plan = getattr(self, "_pack_plan", None)
+        if plan is not None:
+            plan.invalidate()
 
     @property
     def flat_params(self):

@@ -39,7 +39,8 @@ class _CBRFunction(torch.autograd.Function):
         CoutP = c.y.shape[-1]
         g = torch.empty(B, H, W, CoutP, device=gout.device, dtype=dtype)
         ops.nchw_to_nhwc(gout.float(), g, 0, CoutP - Cout)
-        tmp = {p: torch.empty_like(p.data) for p in (conv.weight, conv.bias, bn.weight, bn.bias)}
+        tmp = {p: torch.empty_like(p.data) for p in (conv.weight, bn.weight, bn.bias)}
+        tmp[conv.bias] = torch.zeros_like(conv.bias.data)   # identically zero in front of a training-mode BatchNorm
         gx = engine.cbr_backward(conv, bn, c, tmp, g=g, need_input_grad=ctx.needs_input_grad[0])
         gin = ops.nhwc_to_nchw(gx, ctx.C, 0) if gx is not None else None
         return gin, None, tmp[conv.weight], tmp[conv.bias], tmp[bn.weight], tmp[bn.bias]

@@ -160,7 +160,18 @@ class Hidden:
         gD = engine.grad_dict(D)
         gE = engine.grad_dict(enc_net)
         gDec = engine.grad_dict(dec_net)
+        # packed conv weights: one launch per network here (+ one for D after its optimiser step) instead of one per
+        # conv call; valid only inside this step (the parameters are ours to change until it returns)
+        nets = (enc_net, dec_net, D)
+        try:
+            for n in nets:
+                n.refresh_packs()
+            return self._train_step(images, messages, B, cfg, ed, enc_net, dec_net, D, gD, gE, gDec, extra_encoded_grad, clip)
+        finally:
+            for n in nets:
+                n.invalidate_packs()
 
+    def _train_step(self, images, messages, B, cfg, ed, enc_net, dec_net, D, gD, gE, gDec, extra_encoded_grad, clip):
         # ---------------- train the discriminator (hidden.py:68-83)
         d_on_cover, c = D.fwd(images)
         d_loss_on_cover, g = self._bce_logits(d_on_cover, self.cover_label)
@@ -178,6 +189,7 @@ class Hidden:
         if clip is not None:
             clip(D.flat_grads)
         self.optimizer_discrim.step()
+        D.refresh_packs()
 
         # ---------------- train the generator (hidden.py:85-103)
         d_on_encoded_for_enc, c = D.fwd(encoded)

@@ -139,6 +139,75 @@ def pack_w3x3(w, CoutP, CinP, dtype, perm=None, transpose=False):
     return wp
 
 
+class PackPlan:
+    """All packed conv weights of one network, refreshed by ONE launch (wm_pack_w3x3_batch).
+
+    Requests are registered lazily (`get` packs one-off with wm_pack_w3x3 while the plan is not valid and remembers the
+    request); `refresh()` (re)packs every registered request from the current parameter values and marks the plan valid;
+    `invalidate()` must be called whenever the parameters may have changed (optimiser step, state_dict load)."""
+
+    def __init__(self):
+        self.req = {}        # key -> (w, CoutP, CinP, dtype, perm tuple | None, transpose)
+        self.packed = {}     # key -> packed tensor (stable storage, rewritten by refresh)
+        self.jobs = None
+        self.njobs = 0
+        self.valid = False
+        self.max_elems = 0
+        self._perm_dev = {}
+
+    @staticmethod
+    def key(w, CoutP, CinP, dtype, perm, transpose):
+        return (w.data_ptr(), tuple(w.shape), CoutP, CinP, dtype, None if perm is None else tuple(int(v) for v in perm), bool(transpose))
+
+    def get(self, w, CoutP, CinP, dtype, perm=None, transpose=False):
+        k = self.key(w, CoutP, CinP, dtype, perm, transpose)
+        if self.valid and k in self.packed and self.jobs is not None:
+            return self.packed[k]
+        if k not in self.req:
+            self.req[k] = (w, CoutP, CinP, dtype, perm, transpose)
+            self.jobs = None           # the job table has to be rebuilt
+        return pack_w3x3(w, CoutP, CinP, dtype, perm=perm, transpose=transpose)
+
+    def invalidate(self):
+        self.valid = False
+
+    def _build(self):
+        import struct
+        recs = []
+        self.max_elems = 0
+        dts = set()
+        for k, (w, CoutP, CinP, dtype, perm, transpose) in self.req.items():
+            if k not in self.packed:
+                shape = (9, CinP, CoutP) if transpose else (9, CoutP, CinP)
+                self.packed[k] = torch.empty(shape, device=w.device, dtype=dtype)
+            pd = 0
+            if perm is not None:
+                pk = tuple(int(v) for v in perm)
+                if pk not in self._perm_dev:
+                    self._perm_dev[pk] = torch.tensor(pk, dtype=torch.int32, device=w.device)
+                pd = self._perm_dev[pk].data_ptr()
+            recs.append(struct.pack("<QQQiiiiii", w.data_ptr(), self.packed[k].data_ptr(), pd, w.shape[0], w.shape[1],
+                                    CoutP, CinP, 1 if transpose else 0, 0))
+            self.max_elems = max(self.max_elems, 9 * CoutP * CinP)
+            dts.add(dtype)
+        assert len(dts) == 1, "one compute dtype per plan"
+        self.dtype = dts.pop()
+        dev = next(iter(self.req.values()))[0].device
+        raw = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8)
+        self.jobs = raw.to(dev)
+        self.njobs = len(recs)
+
+    def refresh(self):
+        if not self.req:
+            return
+        if self.jobs is None:
+            self._build()
+        rc = _lib.lib().wm_pack_w3x3_batch(_p(self.jobs), c_int(self.njobs), c_size_t(self.max_elems),
+                                           c_int(WM_BF16 if self.dtype == torch.bfloat16 else WM_F32), _stream())
+        _lib.check(rc, "wm_pack_w3x3_batch")
+        self.valid = True
+
+
 # ----------------------------------------------------------------------------- conv / bn
 def conv3x3_nparts(B, H, W, Cin, CoutP, dtype):
     return _lib.lib().wm_conv3x3_nparts(c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(CoutP), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32))
