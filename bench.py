@@ -13,7 +13,7 @@ decoder 7x64, discriminator 3x64; bf16 activations, f32 accumulate/params; synth
 random-init weights; inputs resident in HBM before the timed region.  One step = one batch.
 
 The JSON line carries, besides the driver contract:
-  roofline     -- the dominant kernel family (conv3x3_ws64_kernel<true,true>: bf16 64->64 conv3x3 implicit
+  roofline     -- the dominant kernel family (conv3x3_ws_kernel<64,true,true,M16>: bf16 64->64 conv3x3 implicit
                   GEMM with fused BN+ReLU input and BatchNorm statistics, 15 launches / step),
                   77.3 GFLOP algorithmic per launch at B=16 256x256, duration measured live with
                   events on the launch stream inside the timed region; peak = 2.5 PFLOP/s dense bf16;
@@ -151,7 +151,7 @@ def main():
             "config": {"workload": f"C2: HiDDeN GAN step enc(4x64)->{args.noise}->dec(7x64)+disc(3x64), L=30, {S}x{S}, batch {B}/GPU",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma",
-                         "kernel": ("conv3x3_ws64_kernel<true,true>" if dtype == torch.bfloat16 else "conv3x3_kernel<float,64,true>") + " (64->64 implicit GEMM, fused BN+ReLU input, BN statistics)",
+                         "kernel": ("conv3x3_ws_kernel<64,true,true,M16>" if dtype == torch.bfloat16 else "conv3x3_kernel<float,64,true>") + " (64->64 implicit GEMM, fused BN+ReLU input, BN statistics)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc_traffic(args, S, B), "launches_timed": len(kms), "avg_launch_ms": avg_ms,
                          "flops_per_launch": flops_per_launch,

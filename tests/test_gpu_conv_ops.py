@@ -298,3 +298,53 @@ def test_shape_errors():
         ops.conv3x3_fwd(x, wp, None, None, None, False)
     with pytest.raises(RuntimeError, match="GPU only"):
         ops.conv3x3_fwd(x.cpu(), wp, None, None, None, False)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("case", [(2, 40, 52, 64, 64), (1, 20, 37, 32, 64), (2, 33, 18, 16, 64)])
+def test_ws_conv_mfma_shapes_agree(case, variant):
+    """the wave-specialised bf16 kernel: 16x16x32 consumers (default) and 32x32x16 consumers (debug knob) against
+    conv2d on the same bf16-rounded operands, with the fused BN+ReLU input transform and the statistics."""
+    import ctypes
+    from video_watermarking_forgery_detection_amd import ops, _lib
+    B, H, W, Cin, Cout = case
+    x = detgen.normal((B, Cin, H, W), 61).bfloat16().float()
+    w = detgen.normal((Cout, Cin, 3, 3), 62, std=(2.0 / (9 * Cin)) ** 0.5).bfloat16().float()
+    bias = detgen.normal((Cout,), 63, std=0.1)
+    sc = detgen.normal((Cin,), 64, mean=1.0, std=0.2); sh = detgen.normal((Cin,), 65, std=0.3)
+    a = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).bfloat16().float()
+    ref = F.conv2d(a, w, bias, padding=1)
+    wp = ops.pack_w3x3(w.cuda(), Cout, Cin, torch.bfloat16)
+    L = _lib.lib()
+    L.wm_debug_ws_variant(ctypes.c_int(variant))
+    try:
+        y, st = ops.conv3x3_fwd(nhwc(x, torch.bfloat16), wp, bias.cuda(), sc.cuda(), sh.cuda(), True)
+    finally:
+        L.wm_debug_ws_variant(ctypes.c_int(0))
+    torch.testing.assert_close(nchw(y, Cout), ref, rtol=1.5e-2, atol=1.5e-2)
+    s = st.sum(0).cpu()
+    torch.testing.assert_close(s[0], ref.sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
+    torch.testing.assert_close(s[1], (ref * ref).sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
+
+
+def test_pack_plan_matches_single_packs():
+    """ops.PackPlan (one wm_pack_w3x3_batch launch for a whole network) == wm_pack_w3x3 per conv, including the
+    permuted / transposed (dgrad) packs, and follows parameter updates after refresh()."""
+    from video_watermarking_forgery_detection_amd import ops
+    ws = [detgen.normal((64, 16, 3, 3), 71).cuda(), detgen.normal((64, 64, 3, 3), 72).cuda(), detgen.normal((30, 64, 3, 3), 73).cuda(),
+          detgen.normal((64, 97, 3, 3), 74).cuda()]
+    perm = list(range(64, 94)) + list(range(0, 64)) + list(range(94, 97))
+    reqs = [(ws[0], 64, 16, None, False), (ws[1], 64, 64, None, False), (ws[1], 64, 64, None, True), (ws[2], 32, 64, None, False),
+            (ws[2], 32, 64, None, True), (ws[3], 64, 112, perm, False), (ws[3], 64, 64, perm, True)]
+    plan = ops.PackPlan()
+    for w, a, b, p, t in reqs:       # registration pass: packs one by one
+        plan.get(w, a, b, torch.bfloat16, perm=p, transpose=t)
+    for rnd in range(2):
+        plan.refresh()
+        for w, a, b, p, t in reqs:
+            got = plan.get(w, a, b, torch.bfloat16, perm=p, transpose=t)
+            ref = ops.pack_w3x3(w, a, b, torch.bfloat16, perm=p, transpose=t)
+            assert torch.equal(got, ref)
+        plan.invalidate()
+        for w in ws:                 # "optimiser step"
+            w.mul_(0.5).add_(0.01)

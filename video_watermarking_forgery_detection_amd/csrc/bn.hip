@@ -96,7 +96,8 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const T* __restrict__ g, int
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ coef, T* __restrict__ dy, int lddy,
-                                                             float* __restrict__ partials, size_t npix, size_t hw, int CP) {
+                                                             float* __restrict__ partials, size_t npix, size_t hw, int CP,
+                                                             int reverse) {
     constexpr int VE = vec16<T>::N;
     const int VPP = CP / VE;
     const int PPB = BT / VPP;  // pixels per block iteration (VPP divides 256 for CP in {32,64,128,256,512})
@@ -112,7 +113,9 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const T* __restrict__ g, int
 #pragma unroll
     for (int e = 0; e < VE; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
     if (ps < PPB) {
-        for (size_t p = (size_t)blockIdx.x * PPB + ps; p < npix; p += (size_t)gridDim.x * PPB) {
+        for (size_t q = (size_t)blockIdx.x * PPB + ps; q < npix; q += (size_t)gridDim.x * PPB) {
+            // reverse: sweep the tensors from the end, where the previous pass of the chain stopped (Infinity Cache reuse)
+            const size_t p = reverse ? npix - 1 - q : q;
             const vec16<T> yv = *reinterpret_cast<const vec16<T>*>(y + p * ldy + c0);
             vec16<T> gv;
             const float* gb = nullptr;
@@ -283,6 +286,8 @@ extern "C" int wm_bn_finalize(const float* partials, int nparts, int C, int CP, 
 }
 
 constexpr int BWD_BT = 1024;
+static int g_bn_reverse = 1;   // bit 0: reduce pass sweeps backwards (it follows a forward-sweeping dgrad), bit 1: apply pass
+extern "C" void wm_debug_bn_reverse(int mask) { g_bn_reverse = mask; }
 extern "C" int wm_bn_bwd_nparts(size_t npix) {
     const size_t n = (npix + BWD_BT - 1) / BWD_BT;
     return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
@@ -300,7 +305,7 @@ extern "C" int wm_bn_bwd_reduce(const void* g, int ldg, const float* gvec, const
     WM_DISPATCH_DTYPE(dtype, "wm_bn_bwd_reduce",
         hipLaunchKernelGGL((bn_bwd_kernel<T, false, BWD_BT>), dim3(nparts), dim3(BWD_BT), 0, s, (const T*)g, ldg, gvec,
                            (const T*)y, ldy, scale, shift, mean, invstd, (const float*)nullptr, (T*)nullptr, 0, partials,
-                           npix, hw, CP));
+                           npix, hw, CP, g_bn_reverse & 1));
     WM_LAUNCH_CHECK("wm_bn_bwd_reduce");
     return WM_OK;
 }
@@ -328,13 +333,13 @@ extern "C" int wm_bn_bwd_apply(const void* g, int ldg, const float* gvec, const 
     if (dbias_partials) {   // rows for wm_colsum_finalize: same grid as the reduce pass
         WM_DISPATCH_DTYPE(dtype, "wm_bn_bwd_apply",
             hipLaunchKernelGGL((bn_bwd_kernel<T, true, BWD_BT>), dim3(nparts), dim3(BWD_BT), 0, s, (const T*)g, ldg, gvec,
-                               (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, dbias_partials, npix, hw, CP));
+                               (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, dbias_partials, npix, hw, CP, (g_bn_reverse >> 1) & 1));
     } else {
         const size_t nb = (npix + 255) / 256;
         const int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
         WM_DISPATCH_DTYPE(dtype, "wm_bn_bwd_apply",
             hipLaunchKernelGGL((bn_bwd_kernel<T, true, 256>), dim3(grid), dim3(256), 0, s, (const T*)g, ldg, gvec,
-                               (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, dbias_partials, npix, hw, CP));
+                               (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, dbias_partials, npix, hw, CP, (g_bn_reverse >> 1) & 1));
     }
     WM_LAUNCH_CHECK("wm_bn_bwd_apply");
     return WM_OK;

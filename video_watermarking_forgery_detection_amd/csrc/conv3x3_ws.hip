@@ -53,9 +53,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 // STAMPS: diagnostic build only (tools/phase_ws.py) -- per-role cycle totals of the phases of the tile loop
-template <int CIN, bool XFORM, bool STATS, bool STAMPS = false>
+// M16: consumers use v_mfma_f32_16x16x32_bf16 (needs CIN % 32 == 0) instead of 32x32x16: same FLOPs per cycle, but the
+// chip holds a higher clock on it under load (MI355X_MICROARCH.md, DVFS give-back item 7); A/B: tools/ab_step.py
+template <int CIN, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned long long* __restrict__ stamps = nullptr) {
     static_assert(CIN == 64 || CIN == 32 || CIN == 16, "input channels");
+    static_assert(!M16 || CIN % 32 == 0, "the 16x16x32 MFMA consumes 32 input channels per step");
     constexpr int VPP = CIN / 8;                       // 16-byte vectors per pixel
     constexpr int KS = CIN / 16;                       // MFMA k-steps per filter tap
     constexpr int NSTEP = 9 * KS;
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             const int row = i / VPP, tap = row >> 6, n = row & 63;
             const int c = n & 31, ci = c & 15;
             const int rho = (ci & 3) + 8 * (ci >> 2) + 4 * (c >> 4);
-            const int lrow = tap * C64 + (n >> 5) * 32 + rho;
+            // M16: accumulator row 4q + i of channel fragment nf is channel 16q + 4nf + i (a lane again owns 16 adjacent channels)
+            const int lrow = M16 ? tap * C64 + ((n >> 2) & 3) * 16 + 4 * (n >> 4) + (n & 3) : tap * C64 + (n >> 5) * 32 + rho;
             if (i < NV) *reinterpret_cast<bf16x8*>(sW + lrow * CIN + swz<CIN>(lrow, i % VPP) * 8) = wv[k];
         }
     }
@@ -269,6 +273,149 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
     // fragment mf = 0 then mf = 1 (2 MFMAs per step; the filter fragments are read twice -- the LDS has the room), and
     // while one half accumulates, the finished other half is drained (BatchNorm sums, bf16 pack, stores) in the
     // shadow of the MFMAs, a few instructions per step, so the matrix pipe never waits for an epilogue.
+    if constexpr (M16) {
+        // lane (p, q): pixel column p of the tile row wave*4 + mf; accumulator [mf][nf] register i = channel 16q + 4nf + i
+        constexpr int KS2 = CIN / 32, NSTEP2 = 9 * KS2;
+        const int p = lane & 15, q = lane >> 4;
+        float s1[16], s2[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+        int aoff[3][KS2], boff[KS2];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks)
+                aoff[kw][ks] = ((wave * 4 * HW + p + kw) * CIN + swz_px<CIN>(p + kw, ks * 4 + q) * 8) * 2;
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) boff[ks] = (p * CIN + swz<CIN>(p, ks * 4 + q) * 8) * 2;
+
+        f32x4 acc[4][4];   // [pixel fragment mf = tile row][channel fragment nf]
+        struct Drain { bf16_t* yp; float mk; bool inb; };
+        auto drain_of = [&](const TileGeo& g, int mf) {
+            Drain d;
+            const int gy = g.ty0 + wave * 4 + mf, gx = g.tx0 + p;
+            d.inb = gy < a.H && gx < a.W;
+            d.mk = d.inb ? 1.f : 0.f;
+            d.yp = a.y + (((size_t)g.b * a.H + gy) * a.W + gx) * C64 + 16 * q;
+            return d;
+        };
+        unsigned pk[8];
+        // micro-step m = 0..17 of draining the half {2*dh, 2*dh+1}: m = 9 ml + j; j < 8: channel pair j, j == 8: the stores
+        auto drain_step = [&](int m, int dh, const Drain (&d)[2]) {
+            const int ml = m / 9, j = m - ml * 9, mf = 2 * dh + ml;
+            if (j < 8) {
+                const int nf = j >> 1, i0 = 2 * (j & 1);
+                const float v0 = acc[mf][nf][i0], v1 = acc[mf][nf][i0 + 1];
+                if (STATS) {   // scalar f32 on purpose (packed f32 VALU is slow beside MFMAs)
+                    const float t0 = v0 * d[ml].mk, t1 = v1 * d[ml].mk;
+                    s1[2 * j] += t0; s1[2 * j + 1] += t1;
+                    s2[2 * j] = __builtin_fmaf(t0, v0, s2[2 * j]);
+                    s2[2 * j + 1] = __builtin_fmaf(t1, v1, s2[2 * j + 1]);
+                }
+                const bf16x2 p2 = {(bf16_t)v0, (bf16_t)v1};
+                pk[j] = __builtin_bit_cast(unsigned, p2);
+            } else if (d[ml].inb && !(STAMPS && (a.dbg & 2))) {
+                *reinterpret_cast<u32x4*>(d[ml].yp) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                *reinterpret_cast<u32x4*>(d[ml].yp + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+            }
+        };
+        // one pass over K for the tile rows {2*half, 2*half+1}; optionally drains half dh on the way
+        auto pass = [&](const bf16_t* sX, int half, bool drain, int dh, const Drain (&d)[2]) {
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) acc[2 * half + ml][nf] = *reinterpret_cast<const f32x4*>(sBias + 16 * q + 4 * nf);
+            if (STAMPS && (a.dbg & 1)) {
+                if (drain) {
+#pragma unroll
+                    for (int m = 0; m < 18; ++m) drain_step(m, dh, d);
+                }
+                return;
+            }
+            constexpr int PF = 2;   // a deeper ring measured the same
+            bf16x8 pix[PF][2], fil[PF][4];
+            auto load_frags = [&](int sidx, int buf) {
+                const int tap = sidx / KS2, ks = sidx % KS2;
+                const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+                for (int ml = 0; ml < 2; ++ml)
+                    pix[buf][ml] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sX) + aoff[kw][ks] + (2 * half + ml + kh) * (HW * CIN * 2));
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+                    fil[buf][nf] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sW) + boff[ks] + (tap * C64 + nf * 16) * (CIN * 2));
+            };
+#pragma unroll
+            for (int i = 0; i < PF - 1; ++i) load_frags(i, i);
+#pragma unroll
+            for (int sidx = 0; sidx < NSTEP2; ++sidx) {
+                const int cb = sidx % PF;
+                if (sidx + PF - 1 < NSTEP2) load_frags(sidx + PF - 1, (sidx + PF - 1) % PF);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf)
+                        acc[2 * half + ml][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fil[cb][nf], pix[cb][ml], acc[2 * half + ml][nf], 0, 0, 0);
+                if (drain) {
+#pragma unroll
+                    for (int m = sidx * 18 / NSTEP2; m < (sidx + 1) * 18 / NSTEP2; ++m) drain_step(m, dh, d);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        __syncthreads();  // filter + first halo tile visible
+        stamp(-1);
+        if (t_begin < t_end) {
+            Drain dnone[2];
+            dnone[0].yp = a.y; dnone[0].mk = 0.f; dnone[0].inb = false; dnone[1] = dnone[0];
+            pass(sX0, 0, false, 0, dnone);
+            stamp(0);
+            for (int tile = t_begin; tile < t_end; ++tile) {
+                const TileGeo g = geo(tile);
+                const bf16_t* sX = sX0 + ((tile - t_begin) & 1) * (NPIX * CIN);
+                const Drain d0[2] = {drain_of(g, 0), drain_of(g, 1)};
+                pass(sX, 1, true, 0, d0);
+                stamp(1);
+                __syncthreads();  // X[t&1] is free for the producers, X[(t+1)&1] is ready
+                stamp(2);
+                const Drain d1[2] = {drain_of(g, 2), drain_of(g, 3)};
+                if (tile + 1 < t_end) {
+                    pass(sX0 + (((tile - t_begin) & 1) ^ 1) * (NPIX * CIN), 0, true, 1, d1);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 18; ++m) drain_step(m, 1, d1);
+                }
+                stamp(0);
+            }
+        }
+        if (STAMPS && stamps && tid == 0) {
+            unsigned long long rt_end;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_end)::"memory");
+            unsigned long long* o = stamps + (size_t)blockIdx.x * 16;
+            o[0] = ph[0]; o[1] = ph[1]; o[2] = ph[2]; o[3] = ph[3];
+            o[4] = now() - t_start; o[5] = rt_end - rt_start;
+        }
+        if (STATS) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                float u1 = s1[c], u2 = s2[c];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { u1 += __shfl_xor(u1, o, 64); u2 += __shfl_xor(u2, o, 64); }
+                if (p == 0) {
+                    sRed[(wave * 2 + 0) * C64 + 16 * q + c] = u1;
+                    sRed[(wave * 2 + 1) * C64 + 16 * q + c] = u2;
+                }
+            }
+            __syncthreads();  // matched by the producers' final barrier
+            if (tid < 2 * C64) {
+                const int which = tid / C64, n = tid - which * C64;
+                a.stat[((size_t)blockIdx.x * 2 + which) * C64 + n] =
+                    sRed[(0 * 2 + which) * C64 + n] + sRed[(1 * 2 + which) * C64 + n] + sRed[(2 * 2 + which) * C64 + n] +
+                    sRed[(3 * 2 + which) * C64 + n];
+            }
+        }
+        return;
+    }
     const int r = lane & 31, h = lane >> 5;
     f32x2 s1[2][8], s2[2][8];
 #pragma unroll
@@ -426,13 +573,13 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
     const int wgs = a.ntiles < 256 ? a.ntiles : 256;
     a.tiles_per_wg = wm_cdiv(a.ntiles, wgs); a.reverse = 0;
     const dim3 grid((unsigned)wm_cdiv(a.ntiles, a.tiles_per_wg)), block(512);
-    if (in_scale && stat) hipLaunchKernelGGL((conv3x3_ws_kernel<64, true, true, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
-    else hipLaunchKernelGGL((conv3x3_ws_kernel<64, false, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
+    if (in_scale && stat) hipLaunchKernelGGL((conv3x3_ws_kernel<64, true, true, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
+    else hipLaunchKernelGGL((conv3x3_ws_kernel<64, false, false, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
     return (int)grid.x;
 }
 
 static int g_ws_reverse = 0;
-static int g_ws_variant = 0;
+static int g_ws_variant = getenv("WM_WS_VARIANT") ? atoi(getenv("WM_WS_VARIANT")) : 0;   // 1: 32x32x16 MFMA consumers (A/B knob), 2: no XCD-aware run assignment
 extern "C" void wm_debug_ws_variant(int v) { g_ws_variant = v; }
 
 extern "C" void wm_debug_ws_direction(int reverse) { g_ws_reverse = reverse; }
@@ -449,16 +596,18 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, const void* wp, const 
     a.reverse = g_ws_reverse;
     const dim3 grid((unsigned)wgs), block(512);
     const bool xf = in_scale != nullptr, st = stat != nullptr;
-#define WM_WS_LAUNCH(CIN_)                                                                                      \
-    do {                                                                                                        \
-        if (xf && st) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, true, true>), grid, block, 0, s, a, nullptr);   \
-        else if (xf) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, true, false>), grid, block, 0, s, a, nullptr);   \
-        else if (st) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, false, true>), grid, block, 0, s, a, nullptr);   \
-        else hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, false, false>), grid, block, 0, s, a, nullptr);          \
+#define WM_WS_LAUNCH(CIN_, M16_)                                                                                      \
+    do {                                                                                                              \
+        if (xf && st) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, true, true, M16_>), grid, block, 0, s, a, nullptr);   \
+        else if (xf) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, true, false, M16_>), grid, block, 0, s, a, nullptr);   \
+        else if (st) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, false, true, M16_>), grid, block, 0, s, a, nullptr);   \
+        else hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, false, false, M16_>), grid, block, 0, s, a, nullptr);          \
     } while (0)
-    if (Cin == 64) WM_WS_LAUNCH(64);
-    else if (Cin == 32) WM_WS_LAUNCH(32);
-    else WM_WS_LAUNCH(16);
+    // 16x16x32 consumers by default where Cin allows (-4.5 % on the 64->64 conv in the training step, tools/ab_step.py)
+    if (Cin == 64 && g_ws_variant != 1) WM_WS_LAUNCH(64, true);
+    else if (Cin == 64) WM_WS_LAUNCH(64, false);
+    else if (Cin == 32) WM_WS_LAUNCH(32, true);
+    else WM_WS_LAUNCH(16, false);
 #undef WM_WS_LAUNCH
     return WM_OK;
 }
