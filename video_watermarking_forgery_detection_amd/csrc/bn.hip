@@ -113,6 +113,7 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const T* __restrict__ g, int
 #pragma unroll
     for (int e = 0; e < VE; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
     if (ps < PPB) {
+#pragma unroll 2
         for (size_t q = (size_t)blockIdx.x * PPB + ps; q < npix; q += (size_t)gridDim.x * PPB) {
             // reverse: sweep the tensors from the end, where the previous pass of the chain stopped (Infinity Cache reuse)
             const size_t p = reverse ? npix - 1 - q : q;

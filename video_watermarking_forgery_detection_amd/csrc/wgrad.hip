@@ -245,33 +245,64 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgArgs<T> a) {
 }
 
 // dw[co][ci][kh][kw] (+)= sum_slab ws[slab][tap][perm(ci)][co]
+// A workgroup owns 32 quads of 4 consecutive co and splits the slabs 8 ways: every thread streams nslabs/8 slabs with
+// 16-byte loads, 8 of them in flight; the 8 partial sums meet in LDS (fixed order: deterministic).
+constexpr int RSPLIT = 8, RQUADS = 256 / RSPLIT;
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nslabs, int CinP, int CoutP,
                                                            float* __restrict__ dw, int Cin, int Cout,
                                                            const int* __restrict__ perm, int accumulate) {
+    __shared__ float4 red[RSPLIT][RQUADS];
     const size_t slab_elems = (size_t)9 * CinP * CoutP;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slab_elems; i += (size_t)gridDim.x * blockDim.x) {
-        const int co = (int)(i % CoutP);
-        const int cip = (int)((i / CoutP) % CinP);
-        const int tap = (int)(i / ((size_t)CoutP * CinP));
-        if (co >= Cout) continue;
-        int ci = -1;
-        if (!perm) ci = cip < Cin ? cip : -1;
-        else
-            for (int qq = 0; qq < Cin; ++qq)
-                if (perm[qq] == cip) { ci = qq; break; }
-        if (ci < 0) continue;
-        // independent partial sums keep 8 loads in flight (the loop is latency-bound otherwise)
-        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p5 = 0.f, p6 = 0.f, p7 = 0.f;
-        int k = 0;
-        for (; k + 8 <= nslabs; k += 8) {
-            const float* q = ws + (size_t)k * slab_elems + i;
-            p0 += q[0]; p1 += q[slab_elems]; p2 += q[2 * slab_elems]; p3 += q[3 * slab_elems];
-            p4 += q[4 * slab_elems]; p5 += q[5 * slab_elems]; p6 += q[6 * slab_elems]; p7 += q[7 * slab_elems];
+    const size_t nquads = slab_elems / 4;
+    const int ql = threadIdx.x % RQUADS, sp = threadIdx.x / RQUADS;
+    for (size_t q0 = (size_t)blockIdx.x * RQUADS; q0 < nquads; q0 += (size_t)gridDim.x * RQUADS) {
+        const size_t qd = q0 + ql;
+        float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        if (qd < nquads) {
+            const float* base = ws + qd * 4;
+            int k = sp;
+            for (; k + 3 * RSPLIT < nslabs; k += 4 * RSPLIT) {
+                const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)k * slab_elems);
+                const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)(k + RSPLIT) * slab_elems);
+                const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)(k + 2 * RSPLIT) * slab_elems);
+                const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)(k + 3 * RSPLIT) * slab_elems);
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+                a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+                a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+            }
+            for (; k < nslabs; k += RSPLIT) {
+                const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)k * slab_elems);
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+            }
         }
-        for (; k < nslabs; ++k) p0 += ws[(size_t)k * slab_elems + i];
-        const double s = ((double)p0 + (double)p1) + ((double)p2 + (double)p3) + ((double)p4 + (double)p5) + ((double)p6 + (double)p7);
-        float* o = dw + (((size_t)co * Cin + ci) * 9 + tap);
-        *o = (accumulate ? *o : 0.f) + (float)s;
+        red[sp][ql] = float4{(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                             (a0.w + a1.w) + (a2.w + a3.w)};
+        __syncthreads();
+        if (threadIdx.x < 4 * RQUADS) {
+            const int qq = threadIdx.x >> 2, e = threadIdx.x & 3;
+            const size_t i = (q0 + qq) * 4 + e;
+            if (i < slab_elems) {
+                double sum = 0.0;
+#pragma unroll
+                for (int t = 0; t < RSPLIT; ++t) sum += (double)reinterpret_cast<const float*>(&red[t][qq])[e];
+                const int co = (int)(i % CoutP);
+                const int cip = (int)((i / CoutP) % CinP);
+                const int tap = (int)(i / ((size_t)CoutP * CinP));
+                int ci = -1;
+                if (co < Cout) {
+                    if (!perm) ci = cip < Cin ? cip : -1;
+                    else
+                        for (int k2 = 0; k2 < Cin; ++k2)
+                            if (perm[k2] == cip) { ci = k2; break; }
+                }
+                if (ci >= 0) {
+                    float* o = dw + (((size_t)co * Cin + ci) * 9 + tap);
+                    *o = (accumulate ? *o : 0.f) + (float)sum;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -321,7 +352,8 @@ extern "C" int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* i
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad");
     const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
     const size_t slab_elems = (size_t)9 * CinP * CoutP;
-    const int blocks = (int)((slab_elems + 255) / 256 > 2048 ? 2048 : (slab_elems + 255) / 256);
+    const size_t rb = (slab_elems / 4 + RQUADS - 1) / RQUADS;
+    const int blocks = (int)(rb > 2048 ? 2048 : rb);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout,
                        perm_dev, accumulate);
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad(reduce)");
