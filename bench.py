@@ -87,11 +87,14 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # one rank per GPU; the modulo only matters when the multi-process flow is rehearsed on a box with fewer GPUs
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        # "nccl" IS RCCL on ROCm; WM_DIST_BACKEND=gloo only rehearses the multi-process flow on a one-GPU box
+        dist.init_process_group(os.environ.get("WM_DIST_BACKEND", "nccl"))
 
     import video_watermarking_forgery_detection_amd as wm
     from video_watermarking_forgery_detection_amd import ops
