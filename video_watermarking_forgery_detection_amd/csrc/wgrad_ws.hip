@@ -38,7 +38,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
 // byte offset of (pixel, channel byte cb) inside a tile of 128-byte pixel rows, 64-byte halves swizzled
 __device__ __forceinline__ int soff(int pix, int cb) { return pix * 128 + (cb ^ (((pix >> 1) & 1) << 6)); }
 
-template <bool XFORM>
+// PACED: producers interleave the loads of tile+2 with the transform / LDS writes of tile+1 and run at s_setprio 3
+// (A/B knob wm_debug_wgrad_variant; the transform is scalar f32 + packed-int ReLU either way)
+template <bool XFORM, bool PACED>
 __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(WsWgArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (X_BYTES + D_BYTES)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(WsWgArgs a) {
 
     if (producer) {
         // ================================================================== PRODUCER waves
+        if (PACED) __builtin_amdgcn_s_setprio(3);
         const int ptid = tid - 256;
         const int vv = ptid & 7;
         const int cx = ci0 + vv * 8, cd = co0 + vv * 8;
@@ -102,11 +105,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(WsWgArgs a) {
             if (XFORM) {
 #pragma unroll
                 for (int pq = 0; pq < 4; ++pq) {
-                    f32x2 f = {__builtin_bit_cast(float, w[pq] << 16), __builtin_bit_cast(float, w[pq] & 0xffff0000u)};
-                    const f32x2 s2 = {sc[2 * pq], sc[2 * pq + 1]}, h2 = {sh[2 * pq], sh[2 * pq + 1]};
-                    f = f * s2 + h2;
-                    const bf16x2 pk = {(bf16_t)fmaxf(f[0], 0.f), (bf16_t)fmaxf(f[1], 0.f)};
-                    w[pq] = __builtin_bit_cast(unsigned, pk);
+                    // scalar v_fma_f32 (packed f32 VALU is slow beside the partner wave's MFMAs); ReLU on the packed
+                    // bf16 pair as a signed 16-bit max
+                    const float f0 = __builtin_fmaf(__builtin_bit_cast(float, w[pq] << 16), sc[2 * pq], sh[2 * pq]);
+                    const float f1 = __builtin_fmaf(__builtin_bit_cast(float, w[pq] & 0xffff0000u), sc[2 * pq + 1], sh[2 * pq + 1]);
+                    const bf16x2 pk = {(bf16_t)f0, (bf16_t)f1};
+                    typedef short i16x2 __attribute__((ext_vector_type(2)));
+                    const i16x2 z = {0, 0};
+                    w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
                 }
             }
 #pragma unroll
@@ -143,27 +149,62 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(WsWgArgs a) {
             for (int k = 0; k < DVP; ++k) put_d(smem, k, d0[k], (okd0 >> k) & 1u);
         }
         __syncthreads();
-        for (int tile = t_begin; tile < t_end; ++tile) {
-            unsigned char* nb = smem + ((((tile - t_begin) & 1) ^ 1) * (X_BYTES + D_BYTES));
+        if (!PACED) {
+            for (int tile = t_begin; tile < t_end; ++tile) {
+                unsigned char* nb = smem + ((((tile - t_begin) & 1) ^ 1) * (X_BYTES + D_BYTES));
 #pragma unroll
-            for (int k = 0; k < XVP; ++k) x0[k] = x1[k];
+                for (int k = 0; k < XVP; ++k) x0[k] = x1[k];
 #pragma unroll
-            for (int k = 0; k < DVP; ++k) d0[k] = d1[k];
-            okx0 = okx1; okd0 = okd1; okx1 = 0; okd1 = 0;
-            if (tile + 2 < t_end) {
-                const TileGeo g2 = geo(tile + 2);
+                for (int k = 0; k < DVP; ++k) d0[k] = d1[k];
+                okx0 = okx1; okd0 = okd1; okx1 = 0; okd1 = 0;
+                if (tile + 2 < t_end) {
+                    const TileGeo g2 = geo(tile + 2);
 #pragma unroll
-                for (int k = 0; k < XVP; ++k) load_x(g2, k, x1[k], okx1);
+                    for (int k = 0; k < XVP; ++k) load_x(g2, k, x1[k], okx1);
 #pragma unroll
-                for (int k = 0; k < DVP; ++k) load_d(g2, k, d1[k], okd1);
+                    for (int k = 0; k < DVP; ++k) load_d(g2, k, d1[k], okd1);
+                }
+                if (tile + 1 < t_end) {
+#pragma unroll
+                    for (int k = 0; k < XVP; ++k) put_x(nb, k, x0[k], (okx0 >> k) & 1u);
+#pragma unroll
+                    for (int k = 0; k < DVP; ++k) put_d(nb, k, d0[k], (okd0 >> k) & 1u);
+                }
+                __syncthreads();
             }
-            if (tile + 1 < t_end) {
+        } else {
+            // iteration `tile`: (xc, dc) hold tile+1: publish them while the loads of tile+2 go into (xn, dn), one load
+            // and one vector of VALU / LDS work alternating, so the memory queue is fed at an even pace
+            auto iter = [&](int tile, bf16x8 (&xn)[XVP], bf16x8 (&dn)[DVP], unsigned& okxn, unsigned& okdn,
+                            const bf16x8 (&xc)[XVP], const bf16x8 (&dc)[DVP], unsigned okxc, unsigned okdc) {
+                unsigned char* nb = smem + ((((tile - t_begin) & 1) ^ 1) * (X_BYTES + D_BYTES));
+                okxn = 0; okdn = 0;
+                if (tile + 2 < t_end) {
+                    const TileGeo g2 = geo(tile + 2);
 #pragma unroll
-                for (int k = 0; k < XVP; ++k) put_x(nb, k, x0[k], (okx0 >> k) & 1u);
+                    for (int k = 0; k < XVP; ++k) {
+                        load_x(g2, k, xn[k], okxn);
+                        put_x(nb, k, xc[k], (okxc >> k) & 1u);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #pragma unroll
-                for (int k = 0; k < DVP; ++k) put_d(nb, k, d0[k], (okd0 >> k) & 1u);
+                    for (int k = 0; k < DVP; ++k) {
+                        load_d(g2, k, dn[k], okdn);
+                        put_d(nb, k, dc[k], (okdc >> k) & 1u);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (tile + 1 < t_end) {
+#pragma unroll
+                    for (int k = 0; k < XVP; ++k) put_x(nb, k, xc[k], (okxc >> k) & 1u);
+#pragma unroll
+                    for (int k = 0; k < DVP; ++k) put_d(nb, k, dc[k], (okdc >> k) & 1u);
+                }
+                __syncthreads();
+            };
+            for (int tile = t_begin; tile < t_end; tile += 2) {
+                iter(tile, x0, d0, okx0, okd0, x1, d1, okx1, okd1);
+                if (tile + 1 < t_end) iter(tile + 1, x1, d1, okx1, okd1, x0, d0, okx0, okd0);
             }
-            __syncthreads();
         }
         return;
     }
@@ -232,6 +273,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(WsWgArgs a) {
 
 }  // namespace
 
+static int g_wgrad_variant = 0;   // 1: paced producers at s_setprio 3 (A/B knob; measured 1.4 % SLOWER on the step here, unlike in the conv)
+extern "C" void wm_debug_wgrad_variant(int v) { g_wgrad_variant = v; }
+
 void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy,
                         int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s) {
     WsWgArgs a;
@@ -240,6 +284,11 @@ void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale,
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
     a.ciBlocks = wm_cdiv(CinX, CB); a.coBlocks = wm_cdiv(CoutY, CB);
     const dim3 grid((unsigned)nslabs, (unsigned)(a.ciBlocks * a.coBlocks)), block(512);
-    if (in_scale) hipLaunchKernelGGL((wgrad_ws_kernel<true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((wgrad_ws_kernel<false>), grid, block, 0, s, a);
+    if (g_wgrad_variant != 1) {
+        if (in_scale) hipLaunchKernelGGL((wgrad_ws_kernel<true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((wgrad_ws_kernel<false, false>), grid, block, 0, s, a);
+    } else {
+        if (in_scale) hipLaunchKernelGGL((wgrad_ws_kernel<true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((wgrad_ws_kernel<false, true>), grid, block, 0, s, a);
+    }
 }
