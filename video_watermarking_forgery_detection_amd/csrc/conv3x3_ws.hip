@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
 
     if (producer) {
         // ================================================================== PRODUCER waves
-        if (!(STAMPS && (a.dbg & 8))) __builtin_amdgcn_s_setprio(3);   // their few VALU / LDS / memory instructions go first
+        if (a.dbg & 8) __builtin_amdgcn_s_setprio(3);   // A/B knob (variant 3): raising the producers measured 1 % slower
         const int ptid = tid - 256;
         const int vec = ptid % VPP;
         f32x2 sc2[4], sh2[4];
@@ -579,7 +579,7 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
 }
 
 static int g_ws_reverse = 0;
-static int g_ws_variant = getenv("WM_WS_VARIANT") ? atoi(getenv("WM_WS_VARIANT")) : 0;   // 1: 32x32x16 MFMA consumers (A/B knob), 2: no XCD-aware run assignment
+static int g_ws_variant = getenv("WM_WS_VARIANT") ? atoi(getenv("WM_WS_VARIANT")) : 0;   // A/B knobs -- 1: 32x32x16 MFMA consumers, 2: no XCD-aware run assignment, 3: producers at s_setprio 3
 extern "C" void wm_debug_ws_variant(int v) { g_ws_variant = v; }
 
 extern "C" void wm_debug_ws_direction(int reverse) { g_ws_reverse = reverse; }
@@ -589,7 +589,7 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, const void* wp, const 
                            const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
                            hipStream_t s) {
     WsArgs a;
-    a.dbg = 0; a.xcd_map = g_ws_variant != 2;
+    a.dbg = g_ws_variant == 3 ? 8 : 0; a.xcd_map = g_ws_variant != 2;
     a.x = (const bf16_t*)x; a.ldx = ldx; a.wp = (const bf16_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
     a.in_shift = in_shift; a.y = (bf16_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY; a.tiles_per_wg = tiles_per_wg;
