@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--noise", default="Jpeg50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the bounded CPU-baseline sample (one batch: ~20 s)")
     return ap.parse_args()
 
 
