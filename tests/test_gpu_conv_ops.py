@@ -30,6 +30,7 @@ CASES = [  # B, H, W, Cin, Cout
     (1, 32, 32, 64, 64),
     (2, 16, 16, 112, 64),
     (1, 33, 16, 64, 32),
+    (2, 50, 70, 64, 32),      # persistent kernel, 32 output channels (image dgrads, the 30-channel layer)
     (1, 16, 48, 32, 128),
     (3, 100, 90, 64, 64),     # persistent 64-channel kernel, ragged tiles
     (2, 256, 256, 64, 64),    # persistent kernel, 2 tiles per workgroup

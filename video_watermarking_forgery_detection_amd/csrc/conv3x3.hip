@@ -22,7 +22,7 @@
 #include "wm_common.h"
 
 // wave-specialised {64,16}->64 kernel (conv3x3_ws.hip)
-int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, const void* wp, const float* bias, int nbias, const float* in_scale,
+int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void* wp, const float* bias, int nbias, const float* in_scale,
                          const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
                          hipStream_t s);
 
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(ConvArgs<bf16_t> a,
 constexpr int C64_MAX_WGS = 256;  // one persistent workgroup per CU
 inline bool use_c64(int Cin, int CoutP, int dtype) {
     static const bool off = getenv("WM_NO_C64") != nullptr;  // diagnostic knob: force the generic kernel
-    return !off && dtype == WM_BF16 && (Cin == 64 || Cin == 32 || Cin == 16) && CoutP == 64;
+    return !off && dtype == WM_BF16 && (((Cin == 64 || Cin == 32 || Cin == 16) && CoutP == 64) || (Cin == 64 && CoutP == 32));
 }  // + ldy == 64 (always true for a 64-channel output tensor)
 inline int c64_tiles_per_wg(int ntiles) { return (ntiles + C64_MAX_WGS - 1) / C64_MAX_WGS; }
 inline int c64_wgs(int ntiles) { const int per = c64_tiles_per_wg(ntiles); return (ntiles + per - 1) / per; }
@@ -642,7 +642,7 @@ int launch_conv(const void* x, int ldx, const void* wp, const float* bias, int n
             const int per = c64_tiles_per_wg(ntiles);
             dim3 grid((unsigned)c64_wgs(ntiles)), block(256);
             static const bool v1 = getenv("WM_C64_V1") != nullptr;  // diagnostic knob: single-role persistent kernel
-            if (!v1 || Cin != 64) return wm_launch_conv3x3_ws(x, ldx, Cin, wp, bias, nbias, in_scale, in_shift, y, stat, B, H, W, c64_wgs(ntiles), per, s);
+            if (!v1 || Cin != 64 || CoutP != 64) return wm_launch_conv3x3_ws(x, ldx, Cin, CoutP, wp, bias, nbias, in_scale, in_shift, y, stat, B, H, W, c64_wgs(ntiles), per, s);
             unsigned long long* nost = nullptr;
             const bool st = stat != nullptr;
             if (xf && st) hipLaunchKernelGGL((conv3x3_c64_kernel<true, true>), grid, block, 0, s, a, a.x, a.y, ntiles, per, nost);
@@ -685,8 +685,8 @@ extern "C" int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const floa
     WM_REQUIRE(ldx >= Cin && ldy >= CoutP && (ldx * esz) % 16 == 0 && (ldy * esz) % 16 == 0, WM_E_SHAPE,
                "wm_conv3x3_fwd: pixel strides ldx=%d ldy=%d must cover the channels and be 16-byte multiples", ldx, ldy);
     WM_REQUIRE((((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y) & 15) == 0, WM_E_SHAPE, "wm_conv3x3_fwd: pointers must be 16-byte aligned");
-    WM_REQUIRE(!use_c64(Cin, CoutP, dtype) || ldy == 64, WM_E_SHAPE,
-               "wm_conv3x3_fwd: the bf16 {16,32,64}->64 path writes a dense 64-channel output (ldy must be 64, got %d)", ldy);
+    WM_REQUIRE(!use_c64(Cin, CoutP, dtype) || ldy == CoutP, WM_E_SHAPE,
+               "wm_conv3x3_fwd: the persistent bf16 path writes a dense output (ldy must equal CoutP=%d, got %d)", CoutP, ldy);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == WM_BF16) launch_conv<bf16_t>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s);
     else launch_conv<float>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s);

@@ -55,10 +55,11 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 // STAMPS: diagnostic build only (tools/phase_ws.py) -- per-role cycle totals of the phases of the tile loop
 // M16: consumers use v_mfma_f32_16x16x32_bf16 (needs CIN % 32 == 0) instead of 32x32x16: same FLOPs per cycle, but the
 // chip holds a higher clock on it under load (MI355X_MICROARCH.md, DVFS give-back item 7); A/B: tools/ab_step.py
-template <int CIN, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false>
+template <int CIN, int COUT, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned long long* __restrict__ stamps = nullptr) {
     static_assert(CIN == 64 || CIN == 32 || CIN == 16, "input channels");
     static_assert(!M16 || CIN % 32 == 0, "the 16x16x32 MFMA consumes 32 input channels per step");
+    static_assert(COUT == 64 || (COUT == 32 && M16), "32 output channels (image dgrads, the 30-channel layer) only with the 16x16x32 consumers");
     constexpr int VPP = CIN / 8;                       // 16-byte vectors per pixel
     constexpr int KS = CIN / 16;                       // MFMA k-steps per filter tap
     constexpr int NSTEP = 9 * KS;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         t_start = now();
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_start)::"memory");
     }
-    constexpr int SW_BYTES = 9 * C64 * CIN * 2, SX_BYTES = NPIX * CIN * 2;
+    constexpr int SW_BYTES = 9 * COUT * CIN * 2, SX_BYTES = NPIX * CIN * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SW_BYTES + 2 * SX_BYTES + 4 * 2 * C64 * 4 + C64 * 4];
     bf16_t* sW = reinterpret_cast<bf16_t*>(smem);
     bf16_t* sX0 = reinterpret_cast<bf16_t*>(smem + SW_BYTES);  // two halo tiles back to back
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
-    if (tid < C64) sBias[tid] = (a.bias && tid < a.nbias) ? a.bias[tid] : 0.f;
+    if (tid < COUT) sBias[tid] = (a.bias && tid < a.nbias) ? a.bias[tid] : 0.f;
 
     // ---- filter -> LDS (all 512 threads).  The filter is the A operand of the MFMA (D rows = output channels, D
     // columns = pixels), so a lane of the accumulator tile holds ONE pixel and, in its 16 registers, the MFMA rows
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
     // rho(c) = (i&3) + 8(i>>2) + 4hh with hh = c>>4, i = c&15: register i of lane half h is channel 16h + i, and a
     // lane owns 16 ADJACENT channels of its pixel -- two 16-byte stores, no transpose.
     {
-        constexpr int NV = 9 * C64 * VPP, WV = (NV + 511) / 512;
+        constexpr int NV = 9 * COUT * VPP, WV = (NV + 511) / 512;
         bf16x8 wv[WV];
 #pragma unroll
         for (int k = 0; k < WV; ++k) {
@@ -107,11 +108,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
 #pragma unroll
         for (int k = 0; k < WV; ++k) {
             const int i = tid + 512 * k;
-            const int row = i / VPP, tap = row >> 6, n = row & 63;
+            const int row = i / VPP, tap = row / COUT, n = row % COUT;
             const int c = n & 31, ci = c & 15;
             const int rho = (ci & 3) + 8 * (ci >> 2) + 4 * (c >> 4);
-            // M16: accumulator row 4q + i of channel fragment nf is channel 16q + 4nf + i (a lane again owns 16 adjacent channels)
-            const int lrow = M16 ? tap * C64 + ((n >> 2) & 3) * 16 + 4 * (n >> 4) + (n & 3) : tap * C64 + (n >> 5) * 32 + rho;
+            // M16: accumulator row 4q + i of channel fragment nf is channel (COUT/4) q + 4nf + i: a lane again owns COUT/4
+            // adjacent channels
+            constexpr int CPL = COUT / 4, NFR = COUT / 16;
+            const int lrow = M16 ? tap * COUT + ((n >> 2) % NFR) * 16 + 4 * (n / CPL) + (n & 3) : tap * COUT + (n >> 5) * 32 + rho;
             if (i < NV) *reinterpret_cast<bf16x8*>(sW + lrow * CIN + swz<CIN>(lrow, i % VPP) * 8) = wv[k];
         }
     }
@@ -276,10 +279,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
     if constexpr (M16) {
         // lane (p, q): pixel column p of the tile row wave*4 + mf; accumulator [mf][nf] register i = channel 16q + 4nf + i
         constexpr int KS2 = CIN / 32, NSTEP2 = 9 * KS2;
+        constexpr int CPL = COUT / 4;          // adjacent channels per lane (16 or 8)
+        constexpr int NFR = COUT / 16;         // 16-channel filter fragments (4 or 2)
+        constexpr int NPAIR = CPL / 2;         // channel pairs per lane and tile row
+        constexpr int NDR = 2 * (NPAIR + 1);   // drain micro-steps per half
         const int p = lane & 15, q = lane >> 4;
-        float s1[16], s2[16];
+        float s1[CPL], s2[CPL];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+        for (int c = 0; c < CPL; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
         int aoff[3][KS2], boff[KS2];
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
@@ -289,21 +296,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks) boff[ks] = (p * CIN + swz<CIN>(p, ks * 4 + q) * 8) * 2;
 
-        f32x4 acc[4][4];   // [pixel fragment mf = tile row][channel fragment nf]
+        f32x4 acc[4][NFR];   // [pixel fragment mf = tile row][channel fragment nf]
         struct Drain { bf16_t* yp; float mk; bool inb; };
         auto drain_of = [&](const TileGeo& g, int mf) {
             Drain d;
             const int gy = g.ty0 + wave * 4 + mf, gx = g.tx0 + p;
             d.inb = gy < a.H && gx < a.W;
             d.mk = d.inb ? 1.f : 0.f;
-            d.yp = a.y + (((size_t)g.b * a.H + gy) * a.W + gx) * C64 + 16 * q;
+            d.yp = a.y + (((size_t)g.b * a.H + gy) * a.W + gx) * COUT + CPL * q;
             return d;
         };
-        unsigned pk[8];
-        // micro-step m = 0..17 of draining the half {2*dh, 2*dh+1}: m = 9 ml + j; j < 8: channel pair j, j == 8: the stores
+        unsigned pk[NPAIR];
+        // micro-step m of draining the half {2*dh, 2*dh+1}: m = (NPAIR+1) ml + j; j < NPAIR: channel pair j, j == NPAIR: the stores
         auto drain_step = [&](int m, int dh, const Drain (&d)[2]) {
-            const int ml = m / 9, j = m - ml * 9, mf = 2 * dh + ml;
-            if (j < 8) {
+            const int ml = m / (NPAIR + 1), j = m - ml * (NPAIR + 1), mf = 2 * dh + ml;
+            if (j < NPAIR) {
                 const int nf = j >> 1, i0 = 2 * (j & 1);
                 const float v0 = acc[mf][nf][i0], v1 = acc[mf][nf][i0 + 1];
                 if (STATS) {   // scalar f32 on purpose (packed f32 VALU is slow beside MFMAs)
@@ -315,8 +322,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 const bf16x2 p2 = {(bf16_t)v0, (bf16_t)v1};
                 pk[j] = __builtin_bit_cast(unsigned, p2);
             } else if (d[ml].inb && !(STAMPS && (a.dbg & 2))) {
-                *reinterpret_cast<u32x4*>(d[ml].yp) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-                *reinterpret_cast<u32x4*>(d[ml].yp + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+#pragma unroll
+                for (int v = 0; v < NPAIR / 4; ++v)
+                    *reinterpret_cast<u32x4*>(d[ml].yp + 8 * v) = u32x4{pk[4 * v], pk[4 * v + 1], pk[4 * v + 2], pk[4 * v + 3]};
             }
         };
         // one pass over K for the tile rows {2*half, 2*half+1}; optionally drains half dh on the way
@@ -324,16 +332,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
 #pragma unroll
             for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
-                for (int nf = 0; nf < 4; ++nf) acc[2 * half + ml][nf] = *reinterpret_cast<const f32x4*>(sBias + 16 * q + 4 * nf);
+                for (int nf = 0; nf < NFR; ++nf) acc[2 * half + ml][nf] = *reinterpret_cast<const f32x4*>(sBias + CPL * q + 4 * nf);
             if (STAMPS && (a.dbg & 1)) {
                 if (drain) {
 #pragma unroll
-                    for (int m = 0; m < 18; ++m) drain_step(m, dh, d);
+                    for (int m = 0; m < NDR; ++m) drain_step(m, dh, d);
                 }
                 return;
             }
             constexpr int PF = 2;   // a deeper ring measured the same
-            bf16x8 pix[PF][2], fil[PF][4];
+            bf16x8 pix[PF][2], fil[PF][NFR];
             auto load_frags = [&](int sidx, int buf) {
                 const int tap = sidx / KS2, ks = sidx % KS2;
                 const int kh = tap / 3, kw = tap - kh * 3;
@@ -341,8 +349,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 for (int ml = 0; ml < 2; ++ml)
                     pix[buf][ml] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sX) + aoff[kw][ks] + (2 * half + ml + kh) * (HW * CIN * 2));
 #pragma unroll
-                for (int nf = 0; nf < 4; ++nf)
-                    fil[buf][nf] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sW) + boff[ks] + (tap * C64 + nf * 16) * (CIN * 2));
+                for (int nf = 0; nf < NFR; ++nf)
+                    fil[buf][nf] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sW) + boff[ks] + (tap * COUT + nf * 16) * (CIN * 2));
             };
 #pragma unroll
             for (int i = 0; i < PF - 1; ++i) load_frags(i, i);
@@ -354,11 +362,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
 #pragma unroll
                 for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
-                    for (int nf = 0; nf < 4; ++nf)
+                    for (int nf = 0; nf < NFR; ++nf)
                         acc[2 * half + ml][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fil[cb][nf], pix[cb][ml], acc[2 * half + ml][nf], 0, 0, 0);
                 if (drain) {
 #pragma unroll
-                    for (int m = sidx * 18 / NSTEP2; m < (sidx + 1) * 18 / NSTEP2; ++m) drain_step(m, dh, d);
+                    for (int m = sidx * NDR / NSTEP2; m < (sidx + 1) * NDR / NSTEP2; ++m) drain_step(m, dh, d);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                     pass(sX0 + (((tile - t_begin) & 1) ^ 1) * (NPIX * CIN), 0, true, 1, d1);
                 } else {
 #pragma unroll
-                    for (int m = 0; m < 18; ++m) drain_step(m, 1, d1);
+                    for (int m = 0; m < NDR; ++m) drain_step(m, 1, d1);
                 }
                 stamp(0);
             }
@@ -397,21 +405,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         }
         if (STATS) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
+            for (int c = 0; c < CPL; ++c) {
                 float u1 = s1[c], u2 = s2[c];
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) { u1 += __shfl_xor(u1, o, 64); u2 += __shfl_xor(u2, o, 64); }
                 if (p == 0) {
-                    sRed[(wave * 2 + 0) * C64 + 16 * q + c] = u1;
-                    sRed[(wave * 2 + 1) * C64 + 16 * q + c] = u2;
+                    sRed[(wave * 2 + 0) * COUT + CPL * q + c] = u1;
+                    sRed[(wave * 2 + 1) * COUT + CPL * q + c] = u2;
                 }
             }
             __syncthreads();  // matched by the producers' final barrier
-            if (tid < 2 * C64) {
-                const int which = tid / C64, n = tid - which * C64;
-                a.stat[((size_t)blockIdx.x * 2 + which) * C64 + n] =
-                    sRed[(0 * 2 + which) * C64 + n] + sRed[(1 * 2 + which) * C64 + n] + sRed[(2 * 2 + which) * C64 + n] +
-                    sRed[(3 * 2 + which) * C64 + n];
+            if (tid < 2 * COUT) {
+                const int which = tid / COUT, n = tid - which * COUT;
+                a.stat[((size_t)blockIdx.x * 2 + which) * COUT + n] =
+                    sRed[(0 * 2 + which) * COUT + n] + sRed[(1 * 2 + which) * COUT + n] + sRed[(2 * 2 + which) * COUT + n] +
+                    sRed[(3 * 2 + which) * COUT + n];
             }
         }
         return;
@@ -573,8 +581,8 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
     const int wgs = a.ntiles < 256 ? a.ntiles : 256;
     a.tiles_per_wg = wm_cdiv(a.ntiles, wgs); a.reverse = 0;
     const dim3 grid((unsigned)wm_cdiv(a.ntiles, a.tiles_per_wg)), block(512);
-    if (in_scale && stat) hipLaunchKernelGGL((conv3x3_ws_kernel<64, true, true, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
-    else hipLaunchKernelGGL((conv3x3_ws_kernel<64, false, false, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
+    if (in_scale && stat) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, true, true, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
+    else hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
     return (int)grid.x;
 }
 
@@ -585,7 +593,7 @@ extern "C" void wm_debug_ws_variant(int v) { g_ws_variant = v; }
 extern "C" void wm_debug_ws_direction(int reverse) { g_ws_reverse = reverse; }
 
 // launcher used by conv3x3.hip
-int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, const void* wp, const float* bias, int nbias, const float* in_scale,
+int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void* wp, const float* bias, int nbias, const float* in_scale,
                            const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
                            hipStream_t s) {
     WsArgs a;
@@ -596,18 +604,21 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, const void* wp, const 
     a.reverse = g_ws_reverse;
     const dim3 grid((unsigned)wgs), block(512);
     const bool xf = in_scale != nullptr, st = stat != nullptr;
-#define WM_WS_LAUNCH(CIN_, M16_)                                                                                      \
-    do {                                                                                                              \
-        if (xf && st) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, true, true, M16_>), grid, block, 0, s, a, nullptr);   \
-        else if (xf) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, true, false, M16_>), grid, block, 0, s, a, nullptr);   \
-        else if (st) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, false, true, M16_>), grid, block, 0, s, a, nullptr);   \
-        else hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, false, false, M16_>), grid, block, 0, s, a, nullptr);          \
+#define WM_WS_LAUNCH2(CIN_, COUT_, M16_)                                                                                     \
+    do {                                                                                                                     \
+        if (xf && st) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, COUT_, true, true, M16_>), grid, block, 0, s, a, nullptr);   \
+        else if (xf) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, COUT_, true, false, M16_>), grid, block, 0, s, a, nullptr);   \
+        else if (st) hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, COUT_, false, true, M16_>), grid, block, 0, s, a, nullptr);   \
+        else hipLaunchKernelGGL((conv3x3_ws_kernel<CIN_, COUT_, false, false, M16_>), grid, block, 0, s, a, nullptr);          \
     } while (0)
+#define WM_WS_LAUNCH(CIN_, M16_) WM_WS_LAUNCH2(CIN_, 64, M16_)
     // 16x16x32 consumers by default where Cin allows (-4.5 % on the 64->64 conv in the training step, tools/ab_step.py)
-    if (Cin == 64 && g_ws_variant != 1) WM_WS_LAUNCH(64, true);
+    if (CoutP == 32) WM_WS_LAUNCH2(64, 32, true);
+    else if (Cin == 64 && g_ws_variant != 1) WM_WS_LAUNCH(64, true);
     else if (Cin == 64) WM_WS_LAUNCH(64, false);
     else if (Cin == 32) WM_WS_LAUNCH(32, true);
     else WM_WS_LAUNCH(16, false);
 #undef WM_WS_LAUNCH
+#undef WM_WS_LAUNCH2
     return WM_OK;
 }
