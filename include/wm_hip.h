@@ -115,6 +115,10 @@ int wm_broadcast_to_nhwc(const float* v, void* y, int B, int L, int H, int W, in
  * the 16-byte vector width. */
 int wm_concat_tail(const float* msg, const float* img, void* y, int B, int L, int H, int W, int ld, int c0,
                    int tail, int dtype, void* stream);
+/* the whole concat row in one pass: y[..., :C] = relu(scale*x+shift) (the encoder features, fused BN+ReLU),
+ * y[..., C:] = [message(L) | image(3) | 0]; x NHWC stride ldx, y NHWC stride ld. */
+int wm_concat_full(const void* x, int ldx, const float* scale, const float* shift, const float* msg, const float* img,
+                   void* y, int B, int C, int L, int H, int W, int ld, int dtype, void* stream);
 /* relu(scale*x+shift) of an NHWC tensor copied into another NHWC tensor (channel slice):
  * materialises a BatchNorm+ReLU output where a consumer cannot fuse it (concat). */
 int wm_bnrelu_copy(const void* x, int ldx, const float* scale, const float* shift, void* y, int ldy,

@@ -256,6 +256,10 @@ def test_layout_roundtrip_and_concat():
         assert torch.equal(c[..., 64:94], msg.view(B, 1, 1, 30).expand(B, H, W, 30))
         torch.testing.assert_close(c[..., 94:97], img.permute(0, 2, 3, 1).to(dtype).float())
         assert c[..., 97:].abs().max() == 0
+        # the one-pass form used by the encoder writes the very same row
+        cat2 = torch.full((B, H, W, 112), 7.0, device="cuda", dtype=dtype)
+        ops.concat_full(nhwc(feat, dtype), sc.cuda(), sh.cuda(), msg.cuda(), img.cuda(), cat2, 64)
+        assert torch.equal(cat2, cat)
 
 
 def test_adam_matches_torch():

@@ -88,6 +88,40 @@ __global__ __launch_bounds__(256) void concat_tail_kernel(const float* __restric
     }
 }
 
+// whole encoder concat row in one pass (hidden_models/encoder.py:34-40): [relu(scale*x+shift) (C feature channels) | message(L) |
+// image(3) | zero pad], every thread one 16-byte vector, consecutive threads consecutive vectors of the pixel: the ld-channel
+// rows are written as full contiguous lines (the two-kernel form wrote them as 128 + 96 byte pieces)
+template <typename T>
+__global__ __launch_bounds__(256) void concat_full_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ msg,
+                                                          const float* __restrict__ img, T* __restrict__ y, int B, int C,
+                                                          int L, size_t hw, int ld) {
+    constexpr int VE = vec16<T>::N;
+    const int nv = ld / VE, nvc = C / VE;
+    const size_t total = (size_t)B * hw * nv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % nv);
+        const size_t p = i / nv;
+        vec16<T> o;
+        if (v < nvc) {
+            o = *reinterpret_cast<const vec16<T>*>(x + p * ldx + v * VE);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) o.set(e, fmaxf(scale[v * VE + e] * o.get(e) + shift[v * VE + e], 0.f));
+        } else {
+            const size_t b = p / hw, q = p - b * hw;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const int c = (v - nvc) * VE + e;
+                float f = 0.f;
+                if (c < L) f = msg[b * L + c];
+                else if (c < L + 3) f = img[(b * 3 + (c - L)) * hw + q];
+                o.set(e, f);
+            }
+        }
+        *reinterpret_cast<vec16<T>*>(y + p * ld + v * VE) = o;
+    }
+}
+
 inline int grid_for(size_t n) {
     const size_t g = (n + 255) / 256;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -146,5 +180,20 @@ extern "C" int wm_concat_tail(const float* msg, const float* img, void* y, int B
     WM_DISPATCH_DTYPE(dtype, "wm_concat_tail",
         hipLaunchKernelGGL((concat_tail_kernel<T>), dim3(grid_for(B * hw * (tail / ve))), dim3(256), 0, s, msg, img, (T*)y, B, L, hw, ld, c0, tail));
     WM_LAUNCH_CHECK("wm_concat_tail");
+    return WM_OK;
+}
+
+extern "C" int wm_concat_full(const void* x, int ldx, const float* scale, const float* shift, const float* msg, const float* img,
+                              void* y, int B, int C, int L, int H, int W, int ld, int dtype, void* stream) {
+    WM_REQUIRE(x && scale && shift && msg && img && y, WM_E_BADARG, "wm_concat_full: null pointer");
+    const int ve = dtype == WM_BF16 ? 8 : 4;
+    WM_REQUIRE(B > 0 && C > 0 && L > 0 && H > 0 && W > 0 && ld >= C + L + 3 && ldx >= C, WM_E_BADARG, "wm_concat_full: bad shape");
+    WM_REQUIRE(C % ve == 0 && ld % ve == 0 && ldx % ve == 0, WM_E_SHAPE, "wm_concat_full: C=%d ld=%d ldx=%d must be multiples of %d", C, ld, ldx, ve);
+    const size_t hw = (size_t)H * W;
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_concat_full",
+        hipLaunchKernelGGL((concat_full_kernel<T>), dim3(grid_for(B * hw * (ld / ve))), dim3(256), 0, s, (const T*)x, ldx, scale, shift,
+                           msg, img, (T*)y, B, C, L, hw, ld));
+    WM_LAUNCH_CHECK("wm_concat_full");
     return WM_OK;
 }

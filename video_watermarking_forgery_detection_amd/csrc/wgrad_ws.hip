@@ -79,7 +79,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(WsWgArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { sc[e] = a.in_scale[cx + e]; sh[e] = a.in_shift[cx + e]; }
         }
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         auto load_x = [&](const TileGeo& g, int k, bf16x8& dst, unsigned& okbits) {

@@ -57,8 +57,7 @@ class Encoder(nn.Module, engine.FlatModule):
             a, cx = engine.cbr_forward(blk.layers[0], blk.layers[1], a, dt, training=training)
             ctx.layers.append(cx)
         cat = torch.empty(B, self.H, self.W, self._cat_ld, device=image.device, dtype=dt)
-        ops.bnrelu_copy(a.t, a.scale, a.shift, cat, 0, c)
-        ops.concat_tail(message, image, cat, c)   # [message | image | 0-pad] in one vectorised pass
+        ops.concat_full(a.t, a.scale, a.shift, message, image, cat, c)   # [features | message | image | 0-pad], one pass
         blk = self.after_concat_layer
         a5, ctx.cat_ctx = engine.cbr_forward(blk.layers[0], blk.layers[1], engine.Act(cat, c + L + 3), dt,
                                              perm=self._perm, training=training)

@@ -118,6 +118,17 @@ def concat_tail(msg, img, out, C_off):
     return out
 
 
+def concat_full(x, scale, shift, msg, img, out, C):
+    """out = [relu(scale*x+shift)[:C] | msg | img | 0]  (the encoder concat row, one pass, full-line writes)"""
+    _need_cuda(x, msg, img, out)
+    B, H, W, ld = out.shape
+    msg = msg.contiguous().float(); img = img.contiguous().float()
+    rc = _lib.lib().wm_concat_full(_p(x), c_int(x.shape[-1]), _p(scale), _p(shift), _p(msg), _p(img), _p(out), c_int(B), c_int(C),
+                                   c_int(msg.shape[1]), c_int(H), c_int(W), c_int(ld), c_int(dtype_id(out)), _stream())
+    _lib.check(rc, "wm_concat_full")
+    return out
+
+
 def bnrelu_copy(x, scale, shift, out, C_off, C):
     B, H, W, ldx = x.shape
     rc = _lib.lib().wm_bnrelu_copy(_p(x), c_int(ldx), _p(scale), _p(shift), _p(out), c_int(out.shape[-1]), c_int(C_off),
