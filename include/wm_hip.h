@@ -253,6 +253,13 @@ int wm_adam_step(float* p, const float* g, float* m, float* v, size_t n, float l
                  float beta2, float eps, float weight_decay, int decoupled, int step, float grad_scale,
                  void* stream);
 /* sum of squares partials (clip_grad_norm_) */
+/* nn.BCEWithLogitsLoss (mean) of n logits against a constant label (hidden_models/hidden.py:68-97): *loss_out = the
+ * loss, grad_out[n] (may be NULL) = gscale * d loss / d logits.  One small launch. */
+int wm_bce_logits(const float* logits, float target, int n, float gscale, float* loss_out, float* grad_out, void* stream);
+/* decoder message loss (hidden.py:96-99,109-111) on n = B*L values: out2[0] = mean (d-m)^2,
+ * out2[1] = mean |clip(round(d),0,1) - m| (the bitwise error), grad_out[n] (may be NULL) = gscale * (d - m). */
+int wm_message_loss(const float* decoded, const float* messages, int n, float gscale, float* out2, float* grad_out,
+                    void* stream);
 int wm_sumsq(const float* x, size_t n, float* partials, int nparts, void* stream);
 
 #ifdef __cplusplus

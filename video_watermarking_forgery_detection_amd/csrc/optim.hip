@@ -24,6 +24,44 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, c
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
+// nn.BCEWithLogitsLoss (mean) of a small logit vector against a constant label, value and gradient in one launch
+// (hidden_models/hidden.py:68-97: three of them per step on [B,1] tensors)
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ x, float target, int n, float gscale,
+                                                         float* __restrict__ loss_out, float* __restrict__ grad_out) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = x[i];
+        acc += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));   // the numerically stable form ATen uses
+        if (grad_out) grad_out[i] = (1.f / (1.f + expf(-v)) - target) * gscale / (float)n;
+    }
+    acc = wave_sum(acc);
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_out[0] = (s[0] + s[1] + s[2] + s[3]) / (float)n;
+}
+
+// decoder message loss (hidden.py:96-99,109-111): out[0] = mean (d-m)^2, out[1] = sum |clip(round(d),0,1) - m| / n,
+// grad = (d-m) * gscale
+__global__ __launch_bounds__(256) void message_loss_kernel(const float* __restrict__ d, const float* __restrict__ m, int n,
+                                                           float gscale, float* __restrict__ out, float* __restrict__ grad) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float df = d[i] - m[i];
+        a1 += df * df;
+        a2 += fabsf(fminf(fmaxf(rintf(d[i]), 0.f), 1.f) - m[i]);   // torch.round = round half to even
+        if (grad) grad[i] = df * gscale;
+    }
+    a1 = wave_sum(a1); a2 = wave_sum(a2);
+    __shared__ float s[2][4];
+    if ((threadIdx.x & 63) == 0) { s[0][threadIdx.x >> 6] = a1; s[1][threadIdx.x >> 6] = a2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = (s[0][0] + s[0][1] + s[0][2] + s[0][3]) / (float)n;
+        out[1] = (s[1][0] + s[1][1] + s[1][2] + s[1][3]) / (float)n;
+    }
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, float* __restrict__ partials, size_t n) {
     float acc = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += x[i] * x[i];
@@ -75,6 +113,22 @@ extern "C" int wm_mse_fwd_bwd(const float* a, const float* b, float* grad_a, flo
     WM_REQUIRE(nparts > 0 && nparts <= 2048, WM_E_BADARG, "wm_mse_fwd_bwd: nparts must be in 1..2048");
     hipLaunchKernelGGL(mse_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, a, b, grad_a, gscale, loss_partials, n);
     WM_LAUNCH_CHECK("wm_mse_fwd_bwd");
+    return WM_OK;
+}
+
+extern "C" int wm_bce_logits(const float* logits, float target, int n, float gscale, float* loss_out, float* grad_out,
+                             void* stream) {
+    WM_REQUIRE(logits && loss_out && n > 0, WM_E_BADARG, "wm_bce_logits: bad arguments");
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, n, gscale, loss_out, grad_out);
+    WM_LAUNCH_CHECK("wm_bce_logits");
+    return WM_OK;
+}
+
+extern "C" int wm_message_loss(const float* decoded, const float* messages, int n, float gscale, float* out2, float* grad_out,
+                               void* stream) {
+    WM_REQUIRE(decoded && messages && out2 && n > 0, WM_E_BADARG, "wm_message_loss: bad arguments");
+    hipLaunchKernelGGL(message_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, decoded, messages, n, gscale, out2, grad_out);
+    WM_LAUNCH_CHECK("wm_message_loss");
     return WM_OK;
 }
 

@@ -126,12 +126,10 @@ class Hidden:
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
-    def _bce_logits(logits, target):
-        """nn.BCEWithLogitsLoss (mean) value and gradient wrt logits, on a [B,1] tensor."""
-        t = torch.full_like(logits, float(target))
-        loss = F.binary_cross_entropy_with_logits(logits, t)
-        grad = (torch.sigmoid(logits) - t) / logits.numel()
-        return loss, grad
+    def _bce_logits(logits, target, gscale=1.0):
+        """nn.BCEWithLogitsLoss (mean) value ([1] tensor) and gscale * gradient wrt logits, on a [B,1] tensor: one launch."""
+        loss, grad = ops.bce_logits(logits, target, gscale)
+        return loss[0], grad.view_as(logits)
 
     def _run_noiser(self, enc, cover):
         n = self.encoder_decoder.noiser
@@ -193,17 +191,17 @@ class Hidden:
 
         # ---------------- train the generator (hidden.py:85-103)
         d_on_encoded_for_enc, c = D.fwd(encoded)
-        g_loss_adv, g = self._bce_logits(d_on_encoded_for_enc, self.cover_label)
+        g_loss_adv, g = self._bce_logits(d_on_encoded_for_enc, self.cover_label, cfg.adversarial_loss)
         # the reference's g_loss.backward() also accumulates into the discriminator's .grad (zeroed at
         # the start of the next step); kept, so .grad state matches
-        g_enc = D.bwd(c, g * cfg.adversarial_loss, gD, accumulate=True, need_input_grad=True)
+        g_enc = D.bwd(c, g, gD, accumulate=True, need_input_grad=True)
 
         n_img = encoded.numel()
         enc_part, g_mse = ops.mse_fwd_bwd(encoded, images, 2.0 * cfg.encoder_loss / n_img)
         ops.axpy_(g_enc, g_mse)
-        diff = decoded - messages
-        g_loss_dec = (diff * diff).mean()
-        g_dec = diff * (2.0 * cfg.decoder_loss / diff.numel())
+        msg_out, g_dec = ops.message_loss(decoded, messages, 2.0 * cfg.decoder_loss / decoded.numel())   # mse, bit error, grad
+        g_loss_dec = msg_out[0]
+        g_dec = g_dec.view_as(decoded)
         g_noised = dec_net.bwd(cDec, g_dec, gDec, accumulate=False, need_input_grad=True)
         g_from_noise = _noise_bwd(ed.noiser, cN, g_noised)
         ops.axpy_(g_enc, g_from_noise.contiguous())
@@ -223,8 +221,7 @@ class Hidden:
         # ---------------- metrics: one host sync for all seven scalars (hidden.py:105-117)
         g_loss_enc = enc_part.sum() / n_img
         g_loss = cfg.adversarial_loss * g_loss_adv + cfg.encoder_loss * g_loss_enc + cfg.decoder_loss * g_loss_dec
-        rounded = decoded.round().clamp(0, 1)
-        bit_err = (rounded - messages).abs().sum() / (B * messages.shape[1])
+        bit_err = msg_out[1]
         vals = torch.stack([g_loss, g_loss_enc, g_loss_dec, bit_err, g_loss_adv, d_loss_on_cover,
                             d_loss_on_encoded]).tolist()
         losses = {

@@ -279,6 +279,28 @@ def bn_bwd(g, gvec, y, stats, C, gamma, dgamma, dbeta, accumulate, dbias):
     return dy
 
 
+def bce_logits(logits, target, gscale=1.0, want_grad=True):
+    """BCEWithLogitsLoss(mean) against a constant label: (loss [1] tensor, gscale * d loss / d logits or None)."""
+    _need_cuda(logits)
+    x = logits.contiguous().float()
+    loss = torch.empty(1, device=x.device, dtype=torch.float32)
+    grad = torch.empty_like(x) if want_grad else None
+    rc = _lib.lib().wm_bce_logits(_p(x), c_float(float(target)), c_int(x.numel()), c_float(float(gscale)), _p(loss), _p(grad), _stream())
+    _lib.check(rc, "wm_bce_logits")
+    return loss, grad
+
+
+def message_loss(decoded, messages, gscale, want_grad=True):
+    """(out [2] = [mean squared error, bitwise error], gscale * (decoded - messages) or None)."""
+    _need_cuda(decoded, messages)
+    d = decoded.contiguous().float(); m = messages.contiguous().float()
+    out = torch.empty(2, device=d.device, dtype=torch.float32)
+    grad = torch.empty_like(d) if want_grad else None
+    rc = _lib.lib().wm_message_loss(_p(d), _p(m), c_int(d.numel()), c_float(float(gscale)), _p(out), _p(grad), _stream())
+    _lib.check(rc, "wm_message_loss")
+    return out, grad
+
+
 def colsum(partials, C, ldp, out, accumulate):
     rc = _lib.lib().wm_colsum_finalize(_p(partials), c_int(partials.shape[0]), c_int(C), c_int(ldp), _p(out),
                                        c_int(1 if accumulate else 0), _stream())
