@@ -253,6 +253,14 @@ int wm_adam_step(float* p, const float* g, float* m, float* v, size_t n, float l
                  float beta2, float eps, float weight_decay, int decoupled, int step, float grad_scale,
                  void* stream);
 /* sum of squares partials (clip_grad_norm_) */
+/* nn.Linear after the global average pool (hidden_models/decoder.py:26,32-34, discriminator.py:18,24-26), B ~ 16, I,O <= 64:
+ * fwd: out[B,O] = pooled[:, :I] @ w[O,I]^T + bias.
+ * bwd: dw[O,I] (+)= g_out^T @ pooled, db[O] (+)= sum_b g_out, gvec[B,CP] = (g_out @ w) * inv_hw zero padded to CP -- the
+ *      per-sample gradient vector wm_bn_bwd_* take for a globally pooled output. */
+int wm_linear_head_fwd(const float* pooled, int ldp, const float* w, const float* bias, float* out, int B, int I, int O,
+                       void* stream);
+int wm_linear_head_bwd(const float* pooled, int ldp, const float* w, const float* g_out, float* dw, float* db,
+                       int accumulate, float* gvec, int CP, float inv_hw, int B, int I, int O, void* stream);
 /* nn.BCEWithLogitsLoss (mean) of n logits against a constant label (hidden_models/hidden.py:68-97): *loss_out = the
  * loss, grad_out[n] (may be NULL) = gscale * d loss / d logits.  One small launch. */
 int wm_bce_logits(const float* logits, float target, int n, float gscale, float* loss_out, float* grad_out, void* stream);

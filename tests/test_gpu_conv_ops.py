@@ -374,3 +374,23 @@ def test_fused_loss_kernels_match_torch():
     torch.testing.assert_close(out[0], ((d - m) ** 2).mean(), rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(out[1], (d.round().clamp(0, 1) - m).abs().sum() / d.numel(), rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(grad, (d - m) * 0.01, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("shape", [(16, 30, 30, 32), (16, 64, 1, 64), (3, 7, 5, 16)])
+def test_linear_head_kernels_match_torch(shape):
+    """wm_linear_head_fwd/bwd == nn.Linear on the pooled features and its autograd (decoder.py:26-34, discriminator.py:18-26)."""
+    from video_watermarking_forgery_detection_amd import ops
+    B, I, O, CP = shape
+    pooled = detgen.normal((B, CP), 101).cuda()
+    w = detgen.normal((O, I), 102, std=0.3).cuda(); bias = detgen.normal((O,), 103, std=0.1).cuda()
+    g = detgen.normal((B, O), 104).cuda()
+    out = ops.linear_head_fwd(pooled, w, bias, I)
+    torch.testing.assert_close(out, pooled[:, :I] @ w.t() + bias, rtol=1e-5, atol=1e-5)
+    for accumulate in (False, True):
+        dw = torch.full((O, I), 0.5, device="cuda"); db = torch.full((O,), -0.25, device="cuda")
+        gvec = ops.linear_head_bwd(pooled, w, g, dw, db, accumulate, CP, 1.0 / 64.0)
+        base_w, base_b = (0.5, -0.25) if accumulate else (0.0, 0.0)
+        torch.testing.assert_close(dw, base_w + g.t() @ pooled[:, :I], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(db, base_b + g.sum(0), rtol=1e-5, atol=1e-5)
+        ref = torch.zeros(B, CP, device="cuda"); ref[:, :I] = (g @ w) / 64.0
+        torch.testing.assert_close(gvec, ref, rtol=1e-5, atol=1e-6)

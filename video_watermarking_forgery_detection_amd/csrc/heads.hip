@@ -169,3 +169,61 @@ extern "C" int wm_conv1x1_head_bwd(const void* y, int ldy, const float* scale, c
     WM_LAUNCH_CHECK("wm_conv1x1_head_bwd");
     return WM_OK;
 }
+
+// ------------------------------------------------------------------ nn.Linear after the global average pool
+// (hidden_models/decoder.py:26,32-34, discriminator.py:18,24-26): [B,I] x [O,I]^T with B = 16, I,O <= 64 -- one small
+// launch each way instead of a handful of library GEMM / elementwise launches.
+namespace {
+__global__ __launch_bounds__(256) void linear_head_fwd_kernel(const float* __restrict__ pooled, int ldp, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ out, int B, int I,
+                                                              int O) {
+    for (int idx = threadIdx.x; idx < B * O; idx += 256) {
+        const int b = idx / O, o = idx - b * O;
+        float acc = bias ? bias[o] : 0.f;
+        for (int i = 0; i < I; ++i) acc = fmaf(pooled[(size_t)b * ldp + i], w[(size_t)o * I + i], acc);
+        out[idx] = acc;
+    }
+}
+// dW[o,i] (+)= sum_b g[b,o] pooled[b,i];  db[o] (+)= sum_b g[b,o];  gvec[b, :CP] = (g[b,:] @ W) * inv_hw, zero padded
+__global__ __launch_bounds__(256) void linear_head_bwd_kernel(const float* __restrict__ pooled, int ldp, const float* __restrict__ w,
+                                                              const float* __restrict__ g, float* __restrict__ dw,
+                                                              float* __restrict__ db, int accumulate, float* __restrict__ gvec,
+                                                              int CP, float inv_hw, int B, int I, int O) {
+    for (int idx = threadIdx.x; idx < O * I; idx += 256) {
+        const int o = idx / I, i = idx - o * I;
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc = fmaf(g[(size_t)b * O + o], pooled[(size_t)b * ldp + i], acc);
+        dw[idx] = (accumulate ? dw[idx] : 0.f) + acc;
+    }
+    for (int o = threadIdx.x; o < O; o += 256) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += g[(size_t)b * O + o];
+        db[o] = (accumulate ? db[o] : 0.f) + acc;
+    }
+    for (int idx = threadIdx.x; idx < B * CP; idx += 256) {
+        const int b = idx / CP, i = idx - b * CP;
+        float acc = 0.f;
+        if (i < I)
+            for (int o = 0; o < O; ++o) acc = fmaf(g[(size_t)b * O + o], w[(size_t)o * I + i], acc);
+        gvec[idx] = acc * inv_hw;
+    }
+}
+}  // namespace
+
+extern "C" int wm_linear_head_fwd(const float* pooled, int ldp, const float* w, const float* bias, float* out, int B, int I,
+                                  int O, void* stream) {
+    WM_REQUIRE(pooled && w && out && B > 0 && I > 0 && O > 0 && ldp >= I, WM_E_BADARG, "wm_linear_head_fwd: bad arguments");
+    hipLaunchKernelGGL(linear_head_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pooled, ldp, w, bias, out, B, I, O);
+    WM_LAUNCH_CHECK("wm_linear_head_fwd");
+    return WM_OK;
+}
+
+extern "C" int wm_linear_head_bwd(const float* pooled, int ldp, const float* w, const float* g_out, float* dw, float* db,
+                                  int accumulate, float* gvec, int CP, float inv_hw, int B, int I, int O, void* stream) {
+    WM_REQUIRE(pooled && w && g_out && dw && db && gvec && B > 0 && I > 0 && O > 0 && ldp >= I && CP >= I, WM_E_BADARG,
+               "wm_linear_head_bwd: bad arguments");
+    hipLaunchKernelGGL(linear_head_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pooled, ldp, w, g_out, dw, db,
+                       accumulate, gvec, CP, inv_hw, B, I, O);
+    WM_LAUNCH_CHECK("wm_linear_head_bwd");
+    return WM_OK;
+}

@@ -26,12 +26,16 @@ def stack_fwd(blocks, image, dt, training):
     return ctx.pooled, ctx
 
 
-def stack_bwd(blocks, ctx, g_pooled, grads, accumulate, need_input_grad):
-    """g_pooled [B,C] f32 (gradient wrt the pooled features) -> gradient wrt the image [B,3,H,W] or None"""
+def head_bwd(mod, ctx, I, g_out, grads, accumulate):
+    """nn.Linear after the pool, backward: fills the weight / bias gradients and returns the per-sample gradient vector
+    [B,CP] of the last ConvBNRelu's pooled output (already / (H*W)), one launch."""
     CP = ctx.layers[-1].y.shape[-1]
-    B, C = g_pooled.shape
-    gvec = torch.zeros(B, CP, device=g_pooled.device, dtype=torch.float32)
-    gvec[:, :C] = g_pooled / ctx.HW
+    return ops.linear_head_bwd(ctx.pooled, mod.linear.weight.data, g_out, grads[mod.linear.weight], grads[mod.linear.bias],
+                               accumulate, CP, 1.0 / ctx.HW)
+
+
+def stack_bwd(blocks, ctx, gvec, grads, accumulate, need_input_grad):
+    """gvec [B,CP] f32 (gradient wrt the pooled features / (H*W), zero padded) -> gradient wrt the image [B,3,H,W] or None"""
     g = None
     n = len(blocks)
     for i in range(n - 1, -1, -1):
@@ -90,23 +94,14 @@ class Decoder(nn.Module, engine.FlatModule):
     def fwd(self, image, training=True):
         pooled, ctx = stack_fwd(self._blocks(), image, self.compute_dtype, training)
         L = self.message_length
-        out = torch.addmm(self.linear.bias.data, pooled[:, :L], self.linear.weight.data.t())  # [B,L]x[L,L]: plumbing-sized
+        out = ops.linear_head_fwd(pooled, self.linear.weight.data, self.linear.bias.data, L)
         if training:
             engine.bump_bn_counters(self)
         return out, ctx
 
     def bwd(self, ctx, g_out, grads, accumulate=False, need_input_grad=True):
-        L = self.message_length
-        pooled = ctx.pooled[:, :L]
-        gw, gb = g_out.t() @ pooled, g_out.sum(0)
-        if accumulate:
-            grads[self.linear.weight] += gw
-            grads[self.linear.bias] += gb
-        else:
-            grads[self.linear.weight].copy_(gw)
-            grads[self.linear.bias].copy_(gb)
-        g_pooled = g_out @ self.linear.weight.data
-        return stack_bwd(self._blocks(), ctx, g_pooled, grads, accumulate, need_input_grad)
+        gvec = head_bwd(self, ctx, self.message_length, g_out, grads, accumulate)
+        return stack_bwd(self._blocks(), ctx, gvec, grads, accumulate, need_input_grad)
 
     def forward(self, image_with_wm):
         if not image_with_wm.is_cuda:

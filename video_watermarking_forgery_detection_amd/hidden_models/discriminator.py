@@ -4,10 +4,10 @@ the sigmoid is commented out in the reference at :26)."""
 import torch
 import torch.nn as nn
 
-from .. import engine
+from .. import engine, ops
 from ..options import HiDDenConfiguration
 from .conv_bn_relu import ConvBNRelu
-from .decoder import _StackLinearFn, bump_bn_counters, stack_bwd, stack_fwd
+from .decoder import _StackLinearFn, bump_bn_counters, head_bwd, stack_bwd, stack_fwd
 
 
 class Discriminator(nn.Module, engine.FlatModule):
@@ -30,22 +30,14 @@ class Discriminator(nn.Module, engine.FlatModule):
 
     def fwd(self, image, training=True):
         pooled, ctx = stack_fwd(self._blocks(), image, self.compute_dtype, training)
-        out = torch.addmm(self.linear.bias.data, pooled[:, :self.channels], self.linear.weight.data.t())
+        out = ops.linear_head_fwd(pooled, self.linear.weight.data, self.linear.bias.data, self.channels)
         if training:
             engine.bump_bn_counters(self)
         return out, ctx
 
     def bwd(self, ctx, g_out, grads, accumulate=False, need_input_grad=False):
-        pooled = ctx.pooled[:, :self.channels]
-        gw, gb = g_out.t() @ pooled, g_out.sum(0)
-        if accumulate:
-            grads[self.linear.weight] += gw
-            grads[self.linear.bias] += gb
-        else:
-            grads[self.linear.weight].copy_(gw)
-            grads[self.linear.bias].copy_(gb)
-        g_pooled = g_out @ self.linear.weight.data
-        return stack_bwd(self._blocks(), ctx, g_pooled, grads, accumulate, need_input_grad)
+        gvec = head_bwd(self, ctx, self.channels, g_out, grads, accumulate)
+        return stack_bwd(self._blocks(), ctx, gvec, grads, accumulate, need_input_grad)
 
     def forward(self, image):
         if not image.is_cuda:

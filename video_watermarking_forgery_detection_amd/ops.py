@@ -279,6 +279,30 @@ def bn_bwd(g, gvec, y, stats, C, gamma, dgamma, dbeta, accumulate, dbias):
     return dy
 
 
+def linear_head_fwd(pooled, w, bias, I):
+    """pooled [B,ldp] f32 (first I columns used), w [O,I], bias [O] -> [B,O]"""
+    _need_cuda(pooled, w)
+    B, ldp = pooled.shape
+    O = w.shape[0]
+    out = torch.empty(B, O, device=pooled.device, dtype=torch.float32)
+    rc = _lib.lib().wm_linear_head_fwd(_p(pooled), c_int(ldp), _p(w), _p(bias), _p(out), c_int(B), c_int(I), c_int(O), _stream())
+    _lib.check(rc, "wm_linear_head_fwd")
+    return out
+
+
+def linear_head_bwd(pooled, w, g_out, dw, db, accumulate, CP, inv_hw):
+    """writes dw [O,I], db [O]; returns gvec [B,CP] = (g_out @ w) * inv_hw (zero padded)"""
+    _need_cuda(pooled, w, g_out)
+    B, ldp = pooled.shape
+    O, I = w.shape
+    g = g_out.contiguous().float()
+    gvec = torch.empty(B, CP, device=pooled.device, dtype=torch.float32)
+    rc = _lib.lib().wm_linear_head_bwd(_p(pooled), c_int(ldp), _p(w), _p(g), _p(dw), _p(db), c_int(1 if accumulate else 0), _p(gvec),
+                                       c_int(CP), c_float(inv_hw), c_int(B), c_int(I), c_int(O), _stream())
+    _lib.check(rc, "wm_linear_head_bwd")
+    return gvec
+
+
 def bce_logits(logits, target, gscale=1.0, want_grad=True):
     """BCEWithLogitsLoss(mean) against a constant label: (loss [1] tensor, gscale * d loss / d logits or None)."""
     _need_cuda(logits)
