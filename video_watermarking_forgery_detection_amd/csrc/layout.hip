@@ -96,29 +96,47 @@ __global__ __launch_bounds__(256) void concat_full_kernel(const T* __restrict__ 
                                                           const float* __restrict__ shift, const float* __restrict__ msg,
                                                           const float* __restrict__ img, T* __restrict__ y, int B, int C,
                                                           int L, size_t hw, int ld) {
-    constexpr int VE = vec16<T>::N;
-    const int nv = ld / VE, nvc = C / VE;
-    const size_t total = (size_t)B * hw * nv;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int v = (int)(i % nv);
-        const size_t p = i / nv;
-        vec16<T> o;
-        if (v < nvc) {
-            o = *reinterpret_cast<const vec16<T>*>(x + p * ldx + v * VE);
+    // 64 pixels per iteration through an LDS image of their output rows: feature vectors are read, and the finished rows
+    // written, as whole contiguous runs; tail vectors are built slot by slot (a wave works on ONE slot: no divergence,
+    // coalesced image-plane reads)
+    constexpr int VE = vec16<T>::N, PX = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* rows = reinterpret_cast<T*>(smem_raw);                           // [PX][ld]
+    float* sSc = reinterpret_cast<float*>(smem_raw + (size_t)PX * ld * sizeof(T));   // [C] scale, [C] shift
+    float* sSh = sSc + C;
+    for (int c = threadIdx.x; c < C; c += 256) { sSc[c] = scale[c]; sSh[c] = shift[c]; }
+    __syncthreads();
+    const int nv = ld / VE, nvc = C / VE, nvt = nv - nvc;
+    const size_t npix = (size_t)B * hw;
+    for (size_t p0 = (size_t)blockIdx.x * PX; p0 < npix; p0 += (size_t)gridDim.x * PX) {
+        const int npx = (int)((npix - p0) < (size_t)PX ? (npix - p0) : (size_t)PX);
+        for (int idx = threadIdx.x; idx < npx * nvc; idx += 256) {
+            const int px = idx / nvc, v = idx - px * nvc;
+            vec16<T> o = *reinterpret_cast<const vec16<T>*>(x + (p0 + px) * ldx + v * VE);
 #pragma unroll
-            for (int e = 0; e < VE; ++e) o.set(e, fmaxf(scale[v * VE + e] * o.get(e) + shift[v * VE + e], 0.f));
-        } else {
-            const size_t b = p / hw, q = p - b * hw;
+            for (int e = 0; e < VE; ++e) o.set(e, fmaxf(sSc[v * VE + e] * o.get(e) + sSh[v * VE + e], 0.f));
+            *reinterpret_cast<vec16<T>*>(rows + px * ld + v * VE) = o;
+        }
+        for (int idx = threadIdx.x; idx < PX * nvt; idx += 256) {
+            const int vt = idx / PX, px = idx - vt * PX;
+            if (px < npx) {
+                const size_t p = p0 + px, b = p / hw, q = p - b * hw;
+                vec16<T> o;
 #pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                const int c = (v - nvc) * VE + e;
-                float f = 0.f;
-                if (c < L) f = msg[b * L + c];
-                else if (c < L + 3) f = img[(b * 3 + (c - L)) * hw + q];
-                o.set(e, f);
+                for (int e = 0; e < VE; ++e) {
+                    const int c = vt * VE + e;
+                    float f = 0.f;
+                    if (c < L) f = msg[b * L + c];
+                    else if (c < L + 3) f = img[(b * 3 + (c - L)) * hw + q];
+                    o.set(e, f);
+                }
+                *reinterpret_cast<vec16<T>*>(rows + px * ld + C + vt * VE) = o;
             }
         }
-        *reinterpret_cast<vec16<T>*>(y + p * ld + v * VE) = o;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < npx * nv; idx += 256)
+            *reinterpret_cast<vec16<T>*>(y + p0 * ld + (size_t)idx * VE) = *reinterpret_cast<const vec16<T>*>(rows + (size_t)idx * VE);
+        __syncthreads();
     }
 }
 
@@ -191,8 +209,12 @@ extern "C" int wm_concat_full(const void* x, int ldx, const float* scale, const 
     WM_REQUIRE(C % ve == 0 && ld % ve == 0 && ldx % ve == 0, WM_E_SHAPE, "wm_concat_full: C=%d ld=%d ldx=%d must be multiples of %d", C, ld, ldx, ve);
     const size_t hw = (size_t)H * W;
     hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)64 * ld * (dtype == WM_BF16 ? 2 : 4) + (size_t)2 * C * 4;
+    WM_REQUIRE(lds <= 64 * 1024, WM_E_SHAPE, "wm_concat_full: row of %d channels is too wide", ld);
+    const size_t nb = ((size_t)B * hw + 63) / 64;
+    const int grid = (int)(nb > 2048 ? 2048 : nb);
     WM_DISPATCH_DTYPE(dtype, "wm_concat_full",
-        hipLaunchKernelGGL((concat_full_kernel<T>), dim3(grid_for(B * hw * (ld / ve))), dim3(256), 0, s, (const T*)x, ldx, scale, shift,
+        hipLaunchKernelGGL((concat_full_kernel<T>), dim3(grid), dim3(256), lds, s, (const T*)x, ldx, scale, shift,
                            msg, img, (T*)y, B, C, L, hw, ld));
     WM_LAUNCH_CHECK("wm_concat_full");
     return WM_OK;
