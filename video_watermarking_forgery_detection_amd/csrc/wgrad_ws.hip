@@ -270,9 +270,233 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(WsWgArgs a) {
         }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// 16x16x32 form (v_mfma_f32_16x16x32_bf16): the chip holds a higher clock on this shape (see conv3x3_ws.hip), and a
+// 16-row M lets the image-fed first layers (CinX = 16) run with CI = 16 instead of padding their input to 64 channels.
+//   D[ci 16 x co 16] += A[ci x 32 pixels] * B[32 pixels x co]; a K-step is two tile rows; lane (r = lane&15, kq = lane>>4)
+//   owns pixels 8kq .. 8kq+7 of the step = tile row (kq>>1), columns 8(kq&1) .. +7, fetched by two transposing reads.
+// LDS: pixel rows of CI*2 bytes.  CI = 64 and the dy tile: byte offset XOR (((col>>1)&1) << 5 | ((col>>3)&1) << 6) -- the
+// 8 pixels x 32 B one half-wave touches ({c..c+3} and {c+8..c+11}, any tap shift) fill a 256-byte bank row exactly once.
+// CI = 16 (32-byte pixels): halo column c is stored at slot c ^ (((c>>3)&1) << 2), which does the same.
+__device__ __forceinline__ int swz16(int col) { return (((col >> 1) & 1) << 5) | (((col >> 3) & 1) << 6); }
+__device__ __forceinline__ int slot16(int col) { return col ^ (((col >> 3) & 1) << 2); }
+
+template <int CI, bool XFORM>
+__global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
+    static_assert(CI == 64 || CI == 16, "input-channel block");
+    constexpr int VPX = CI / 8;                                   // 16-byte vectors per x pixel
+    constexpr int XV = (NPIX * VPX + 255) / 256;                  // x halo vectors per producer thread
+    constexpr int XB = NPIX * CI * 2;                             // x halo tile bytes
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (XB + D_BYTES)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int cc = blockIdx.y / a.coBlocks, oc = blockIdx.y % a.coBlocks;
+    const int ci0 = cc * CI, co0 = oc * CB;
+    const int G = gridDim.x;
+    const int run = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int t_begin = (int)(((long)run * a.ntiles) / G);
+    const int t_end = (int)(((long)(run + 1) * a.ntiles) / G);
+    struct TileGeo { int b, ty0, tx0; };
+    auto geo = [&](int tile) {
+        TileGeo g;
+        int t = tile;
+        const int txi = t % a.tilesX; t /= a.tilesX;
+        const int tyi = t % a.tilesY; t /= a.tilesY;
+        g.b = t; g.ty0 = tyi * TH; g.tx0 = txi * TW;
+        return g;
+    };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+    if (producer) {
+        // ================================================================== PRODUCER waves
+        const int ptid = tid - 256;
+        const int vx = ptid % VPX, vd = ptid & 7;
+        const int cx = ci0 + vx * 8, cd = co0 + vd * 8;
+        const bool cxok = cx < a.CinX, cdok = cd < a.CoutY;
+        const int cxl = cxok ? cx : 0, cdl = cdok ? cd : 0;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+        if (XFORM && cxok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc[e] = a.in_scale[cx + e]; sh[e] = a.in_shift[cx + e]; }
+        }
+        auto load_x = [&](const TileGeo& g, int k, bf16x8& dst, unsigned& okbits) {
+            const int pix = min((ptid + 256 * k) / VPX, NPIX - 1);
+            const int py = pix / HW, px = pix - py * HW;
+            const int gy = g.ty0 - 1 + py, gx = g.tx0 - 1 + px;
+            const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+            dst = *reinterpret_cast<const bf16x8*>(a.x + ((size_t)(g.b * a.H + gyc) * a.W + gxc) * a.ldx + cxl);
+            okbits |= ((cxok && gy == gyc && gx == gxc) ? 1u : 0u) << k;
+        };
+        auto load_d = [&](const TileGeo& g, int k, bf16x8& dst, unsigned& okbits) {
+            const int pix = (ptid + 256 * k) >> 3;
+            const int gy = g.ty0 + (pix >> 4), gx = g.tx0 + (pix & 15);
+            const int gyc = min(gy, a.H - 1), gxc = min(gx, a.W - 1);
+            dst = *reinterpret_cast<const bf16x8*>(a.dy + ((size_t)(g.b * a.H + gyc) * a.W + gxc) * a.lddy + cdl);
+            okbits |= ((cdok && gy == gyc && gx == gxc) ? 1u : 0u) << k;
+        };
+        auto put_x = [&](unsigned char* base, int k, const bf16x8& src, bool ok) {
+            const int pix = (ptid + 256 * k) / VPX;
+            const int py = pix / HW, px = pix - py * HW;
+            u32x4 w = __builtin_bit_cast(u32x4, src);
+            if (XFORM) {
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq) {
+                    const float f0 = __builtin_fmaf(__builtin_bit_cast(float, w[pq] << 16), sc[2 * pq], sh[2 * pq]);
+                    const float f1 = __builtin_fmaf(__builtin_bit_cast(float, w[pq] & 0xffff0000u), sc[2 * pq + 1], sh[2 * pq + 1]);
+                    const bf16x2 pk = {(bf16_t)f0, (bf16_t)f1};
+                    const i16x2 z = {0, 0};
+                    w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
+                }
+            }
+            const unsigned keep = ok ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] &= keep;
+            const int off = CI == 64 ? (py * HW + px) * 128 + ((vx * 16) ^ swz16(px)) : (py * HW + slot16(px)) * 32 + vx * 16;
+            if (pix < NPIX) *reinterpret_cast<u32x4*>(base + off) = w;
+        };
+        auto put_d = [&](unsigned char* base, int k, const bf16x8& src, bool ok) {
+            const int pix = (ptid + 256 * k) >> 3;
+            u32x4 w = __builtin_bit_cast(u32x4, src);
+            const unsigned keep = ok ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] &= keep;
+            *reinterpret_cast<u32x4*>(base + XB + pix * 128 + ((vd * 16) ^ swz16(pix & 15))) = w;
+        };
+        bf16x8 x0[XV], x1[XV], d0[DVP], d1[DVP];
+        unsigned okx0 = 0, okx1 = 0, okd0 = 0, okd1 = 0;
+        if (t_begin < t_end) {
+            const TileGeo g0 = geo(t_begin);
+#pragma unroll
+            for (int k = 0; k < XV; ++k) load_x(g0, k, x0[k], okx0);
+#pragma unroll
+            for (int k = 0; k < DVP; ++k) load_d(g0, k, d0[k], okd0);
+        }
+        if (t_begin + 1 < t_end) {
+            const TileGeo g1 = geo(t_begin + 1);
+#pragma unroll
+            for (int k = 0; k < XV; ++k) load_x(g1, k, x1[k], okx1);
+#pragma unroll
+            for (int k = 0; k < DVP; ++k) load_d(g1, k, d1[k], okd1);
+        }
+        if (t_begin < t_end) {
+#pragma unroll
+            for (int k = 0; k < XV; ++k) put_x(smem, k, x0[k], (okx0 >> k) & 1u);
+#pragma unroll
+            for (int k = 0; k < DVP; ++k) put_d(smem, k, d0[k], (okd0 >> k) & 1u);
+        }
+        __syncthreads();
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            unsigned char* nb = smem + ((((tile - t_begin) & 1) ^ 1) * (XB + D_BYTES));
+#pragma unroll
+            for (int k = 0; k < XV; ++k) x0[k] = x1[k];
+#pragma unroll
+            for (int k = 0; k < DVP; ++k) d0[k] = d1[k];
+            okx0 = okx1; okd0 = okd1; okx1 = 0; okd1 = 0;
+            if (tile + 2 < t_end) {
+                const TileGeo g2 = geo(tile + 2);
+#pragma unroll
+                for (int k = 0; k < XV; ++k) load_x(g2, k, x1[k], okx1);
+#pragma unroll
+                for (int k = 0; k < DVP; ++k) load_d(g2, k, d1[k], okd1);
+            }
+            if (tile + 1 < t_end) {
+#pragma unroll
+                for (int k = 0; k < XV; ++k) put_x(nb, k, x0[k], (okx0 >> k) & 1u);
+#pragma unroll
+                for (int k = 0; k < DVP; ++k) put_d(nb, k, d0[k], (okd0 >> k) & 1u);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ====================================================================== CONSUMER waves
+    // CI = 64: wave (mi, ni) owns the 32 ci x 32 co block = 2 x 2 fragments x 9 taps; CI = 16: wave w owns co fragment w
+    constexpr int FI = CI == 64 ? 2 : 1, FJ = CI == 64 ? 2 : 1;
+    const int mi = CI == 64 ? (wave >> 1) : 0, ni = CI == 64 ? (wave & 1) : 0;
+    const int r = lane & 15, kq = lane >> 4;
+    const int q = (lane >> 2) & 3, p = lane & 3;
+    f32x4 acc[9][FI][FJ];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // lane part of the fragment addresses (tile row (kq>>1) of the K-step, column 8(kq&1) + q [+4]); the K-step / tap rows
+    // are compile-time offsets
+    const int colb = 8 * (kq & 1) + q;
+    int xo[3][2][FI], dof[2][FJ];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int fi = 0; fi < FI; ++fi) {
+                const int col = colb + kw + 4 * s2;
+                if (CI == 64) xo[kw][s2][fi] = ((kq >> 1) * HW + col) * 128 + (((mi * 32 + fi * 16 + 4 * p) * 2) ^ swz16(col));
+                else xo[kw][s2][fi] = ((kq >> 1) * HW + slot16(col)) * 32 + 4 * p * 2;
+            }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int fj = 0; fj < FJ; ++fj) {
+            const int col = colb + 4 * s2;
+            const int cb = CI == 64 ? (ni * 32 + fj * 16 + 4 * p) * 2 : (wave * 16 + 4 * p) * 2;
+            dof[s2][fj] = ((kq >> 1) * TW + col) * 128 + (cb ^ swz16(col));
+        }
+    constexpr int XROW = HW * CI * 2;     // bytes per halo row
+    __syncthreads();
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const char* sXc = reinterpret_cast<const char*>(smem + (((tile - t_begin) & 1) * (XB + D_BYTES)));
+        const char* sDc = sXc + XB;
+#pragma unroll
+        for (int ks = 0; ks < TH / 2; ++ks) {
+            bf16x8 bfrag[FJ];
+#pragma unroll
+            for (int fj = 0; fj < FJ; ++fj)
+                bfrag[fj] = tr_frag(sDc + 2 * ks * TW * 128 + dof[0][fj], sDc + 2 * ks * TW * 128 + dof[1][fj]);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap % 3;
+                bf16x8 afrag[FI];
+#pragma unroll
+                for (int fi = 0; fi < FI; ++fi)
+                    afrag[fi] = tr_frag(sXc + (2 * ks + kh) * XROW + xo[kw][0][fi], sXc + (2 * ks + kh) * XROW + xo[kw][1][fi]);
+#pragma unroll
+                for (int fi = 0; fi < FI; ++fi)
+#pragma unroll
+                    for (int fj = 0; fj < FJ; ++fj)
+                        acc[tap][fi][fj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[fi], bfrag[fj], acc[tap][fi][fj], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // slab write: acc[tap][fi][fj][i] -> ci row 4*kq + i of fragment fi, co column r of fragment fj
+    const int CinP = a.ciBlocks * CB, CoutP = a.coBlocks * CB;
+    float* slab = a.ws + (size_t)blockIdx.x * 9 * CinP * CoutP;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int fi = 0; fi < FI; ++fi)
+#pragma unroll
+            for (int fj = 0; fj < FJ; ++fj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ci = ci0 + (CI == 64 ? mi * 32 + fi * 16 : 0) + 4 * kq + i;
+                    const int co = co0 + (CI == 64 ? ni * 32 + fj * 16 : wave * 16) + r;
+                    slab[((size_t)tap * CinP + ci) * CoutP + co] = acc[tap][fi][fj][i];
+                }
+}
+
 }  // namespace
 
-static int g_wgrad_variant = 0;   // 1: paced producers at s_setprio 3 (A/B knob; measured 1.4 % SLOWER on the step here, unlike in the conv)
+static int g_wgrad_variant = 0;   // A/B knobs -- 0: 16x16x32 kernels, 2: 32x32x16 kernel, 1: 32x32x16 with paced producers (1.4 % slower)
 extern "C" void wm_debug_wgrad_variant(int v) { g_wgrad_variant = v; }
 
 void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy,
@@ -282,7 +506,23 @@ void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale,
     a.dy = (const bf16_t*)dy; a.lddy = lddy; a.CoutY = CoutY; a.ws = ws; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
     a.ciBlocks = wm_cdiv(CinX, CB); a.coBlocks = wm_cdiv(CoutY, CB);
-    const dim3 grid((unsigned)nslabs, (unsigned)(a.ciBlocks * a.coBlocks)), block(512);
+    const dim3 block(512);
+    if (g_wgrad_variant != 2) {   // 16x16x32 kernels (default); CinX <= 16: one 16-channel input block
+        if (CinX <= 16) {
+            a.ciBlocks = 1;   // the slab keeps its 64-row pitch (rows >= 16 are never read back: ci >= Cin)
+            const dim3 grid((unsigned)nslabs, (unsigned)a.coBlocks);
+            WsWgArgs b = a; b.ciBlocks = 1;
+            // the kernel derives CinP from ciBlocks * CB: keep CB-row slabs
+            if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<16, true>), grid, block, 0, s, b);
+            else hipLaunchKernelGGL((wgrad_ws16_kernel<16, false>), grid, block, 0, s, b);
+        } else {
+            const dim3 grid((unsigned)nslabs, (unsigned)(a.ciBlocks * a.coBlocks));
+            if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<64, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((wgrad_ws16_kernel<64, false>), grid, block, 0, s, a);
+        }
+        return;
+    }
+    const dim3 grid((unsigned)nslabs, (unsigned)(a.ciBlocks * a.coBlocks));
     if (g_wgrad_variant != 1) {
         if (in_scale) hipLaunchKernelGGL((wgrad_ws_kernel<true, false>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((wgrad_ws_kernel<false, false>), grid, block, 0, s, a);
