@@ -32,10 +32,17 @@ def timeit(fn, n=20):
     return a.elapsed_time(b) / n * 1e3
 
 flops = 2.0 * B * H * W * C * 9 * C
-for name, x in xs.items():
+import ctypes
+from video_watermarking_forgery_detection_amd import _lib
+for variant in [int(v) for v in os.environ.get('VARIANTS', '0').split(',')]:
+  _lib.lib().wm_debug_ws_variant(ctypes.c_int(variant))
+  for name, x in xs.items():
     t1 = timeit(lambda: ops.conv3x3_fwd(x, wp, bias, sc, sh, True))
     t2 = timeit(lambda: ops.conv3x3_fwd(x, wp, None, None, None, False))
-    print(f"conv c64 input={name:7s} xform+stats: {t1:7.1f} us ({flops/t1/1e6:6.0f} TF)   plain: {t2:7.1f} us ({flops/t2/1e6:6.0f} TF)")
+    t3 = timeit(lambda: ops.conv3x3_fwd(x, wp, None, sc, sh, False))
+    t4 = timeit(lambda: ops.conv3x3_fwd(x, wp, bias, None, None, True))
+    print(f"variant {variant} conv c64 input={name:7s} xform+stats: {t1:7.1f} us  plain: {t2:7.1f} us  xform only: {t3:7.1f}  stats only: {t4:7.1f}")
+_lib.lib().wm_debug_ws_variant(ctypes.c_int(0))
 dw = torch.zeros(C, C, 3, 3, device=dev)
 for name in ("normal", "relu"):
     x = xs[name]; dy = xs["normal"]
