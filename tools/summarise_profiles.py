@@ -28,7 +28,7 @@ for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
             g.write(f"\"{k[:120]}\",{len(v)},{sum(v)/len(v):.2f}\n")
     out[name] = {k: sum(v) / len(v) for k, v in agg.items()}
-dom = [k for k in out["FETCH_SIZE"] if "conv3x3_ws_kernel<64, true, true" in k]
+dom = [k for k in out["FETCH_SIZE"] if "conv3x3_ws_kernel<64, 64, true, true" in k]
 k = dom[0]
 res = {"kernel": k, "FETCH_SIZE_KB": out["FETCH_SIZE"][k], "WRITE_SIZE_KB": out["WRITE_SIZE"][k],
        "hbm_bytes_per_launch": (2.0 * out["FETCH_SIZE"][k] + out["WRITE_SIZE"][k]) * 1024.0,
