@@ -10,7 +10,12 @@ from video_watermarking_forgery_detection_amd.hidden_models import Hidden
 from video_watermarking_forgery_detection_amd import noise_layers as NL
 from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
 
-setter = getattr(_lib.lib(), sys.argv[1])
+if sys.argv[1].startswith("attr:"):   # python attribute of the Hidden object instead of a library knob, e.g. attr:overlap_streams
+    _name = sys.argv[1][5:]
+    def setter(v):
+        setattr(h, _name, bool(v))
+else:
+    setter = getattr(_lib.lib(), sys.argv[1])
 variants = [int(v) for v in sys.argv[2:]]
 dev = torch.device("cuda", 0)
 torch.manual_seed(10)
