@@ -1,7 +1,7 @@
 // Wave-specialised persistent 3x3 convolution for bf16, Cout = 64, Cin = 64 (body layers, dgrad) or 16 (image-fed
 // first layers) (gfx950).
 //
-// Why: tools/phase_c64.py shows that a single wave per SIMD cannot overlap its own phases -- the MFMA loop
+// Why: phase stamps of its single-role predecessor show that one wave per SIMD cannot overlap its own phases -- the MFMA loop
 // (4,742 cycles / tile), the HBM traffic of a tile (78 KB per CU = ~7,400 cycles at the ~10.7 B/clk a CU gets)
 // and the VALU work (BN+ReLU transform, bias / statistics / pack) simply add up (10-12k cycles / tile), whatever
 // the instruction order.  Here the two kinds of work live in different waves of one 512-thread workgroup, two

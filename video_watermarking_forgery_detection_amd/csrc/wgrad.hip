@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgArgs<T> a) {
     }
 
     // ---- software pipeline over this workgroup's contiguous run of tiles (same scheme as the persistent conv
-    // kernel, measured there with tools/phase_c64.py): the x halo tile and the dy tile travel two tiles ahead
+    // kernel, measured there with in-kernel phase stamps): the x halo tile and the dy tile travel two tiles ahead
     // in registers; their global loads are issued from INSIDE the MFMA loop, one every few MFMAs, so the
     // per-CU memory queue never backs up and the HBM time hides under the matrix pipe; the fused BN+ReLU of the
     // next tile's registers is done in the same loop.  Loads are never under a per-lane branch (clamped, always

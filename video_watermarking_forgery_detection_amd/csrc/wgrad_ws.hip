@@ -1,22 +1,20 @@
-// Wave-specialised weight-gradient kernel (bf16) -- same role split as conv3x3_ws.hip:
-//   waves 0-3  CONSUMERS: per 16x16-pixel tile 16 K-steps x (1 dy fragment + 9 shifted x fragments, all through
-//              ds_read_b64_tr_b16, 9 v_mfma_f32_32x32x16_bf16); the 9 tap accumulators (144 registers) of the
-//              wave's 32 ci x 32 co block live across the whole run of tiles;
+// Wave-specialised weight-gradient kernels (bf16) -- same role split as conv3x3_ws.hip:
+//   waves 0-3  CONSUMERS: per 16x16-pixel tile 8 K-steps of 32 pixels x (dy fragments + 9 shifted x fragments, all through
+//              ds_read_b64_tr_b16, v_mfma_f32_16x16x32_bf16); the tap accumulators of the wave's block live across the
+//              whole run of tiles;
 //   waves 4-7  PRODUCERS: global loads of the x halo tile and the dy tile two tiles ahead (registers), fused
 //              BN+ReLU of x + zero padding, 16-byte LDS writes into the other buffer.
-// One workgroup barrier per tile.  LDS: 2 x (x halo 41,472 B + dy 32,768 B) = 148,480 B, rows of 128 B
-// (64 channels) without padding; the 64-byte half of a row is XOR-swizzled with (pixel >> 1) & 1, so the
-// 4 pixels x 64 B that one 32-lane half of ds_read_b64_tr_b16 touches always fill a 256-byte bank row exactly
-// once, for every tap shift.
+// One workgroup barrier per tile.  LDS (CI = 64): 2 x (x halo 41,472 B + dy 32,768 B) = 148,480 B.
+// (A 32x32x16 form with 64-byte-half swizzle preceded this one: 1.6 % slower on the step; a paced / prioritised
+// producer variant of it 1.4 % slower still -- tools/ab_step.py.)
 #include "wm_common.h"
 
 namespace {
 
 constexpr int TH = 16, TW = 16, HH = 18, HW = 18, CB = 64;
 constexpr int NPIX = HH * HW;
-constexpr int XVP = (NPIX * 8 + 255) / 256;   // x halo vectors per producer thread (11)
 constexpr int DVP = TH * TW * 8 / 256;        // dy vectors per producer thread (8)
-constexpr int X_BYTES = NPIX * CB * 2, D_BYTES = TH * TW * CB * 2;
+constexpr int D_BYTES = TH * TW * CB * 2;
 
 struct WsWgArgs {
     const bf16_t* x; int ldx; int CinX;
@@ -33,241 +31,6 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
     typedef short s8 __attribute__((ext_vector_type(8)));
     s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
-}
-
-// byte offset of (pixel, channel byte cb) inside a tile of 128-byte pixel rows, 64-byte halves swizzled
-__device__ __forceinline__ int soff(int pix, int cb) { return pix * 128 + (cb ^ (((pix >> 1) & 1) << 6)); }
-
-// PACED: producers interleave the loads of tile+2 with the transform / LDS writes of tile+1 and run at s_setprio 3
-// (A/B knob wm_debug_wgrad_variant; the transform is scalar f32 + packed-int ReLU either way)
-template <bool XFORM, bool PACED>
-__global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(WsWgArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (X_BYTES + D_BYTES)];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool producer = wave >= 4;
-    const int cc = blockIdx.y / a.coBlocks, oc = blockIdx.y % a.coBlocks;
-    const int ci0 = cc * CB, co0 = oc * CB;
-    // balanced contiguous runs of tiles
-    // XCD-aware run assignment (workgroups b and b+8 share an XCD): XCD x walks the consecutive runs
-    // [x*G/8, (x+1)*G/8), so vertically adjacent tile rows share their halo rows in one L2
-    const int G = gridDim.x;
-    const int run = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    const int t_begin = (int)(((long)run * a.ntiles) / G);
-    const int t_end = (int)(((long)(run + 1) * a.ntiles) / G);
-    struct TileGeo { int b, ty0, tx0; };
-    auto geo = [&](int tile) {
-        TileGeo g;
-        int t = tile;
-        const int txi = t % a.tilesX; t /= a.tilesX;
-        const int tyi = t % a.tilesY; t /= a.tilesY;
-        g.b = t; g.ty0 = tyi * TH; g.tx0 = txi * TW;
-        return g;
-    };
-
-    if (producer) {
-        // ================================================================== PRODUCER waves
-        if (PACED) __builtin_amdgcn_s_setprio(3);
-        const int ptid = tid - 256;
-        const int vv = ptid & 7;
-        const int cx = ci0 + vv * 8, cd = co0 + vv * 8;
-        const bool cxok = cx < a.CinX, cdok = cd < a.CoutY;
-        const int cxl = cxok ? cx : 0, cdl = cdok ? cd : 0;
-        float sc[8], sh[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
-        if (XFORM && cxok) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { sc[e] = a.in_scale[cx + e]; sh[e] = a.in_shift[cx + e]; }
-        }
-        typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        auto load_x = [&](const TileGeo& g, int k, bf16x8& dst, unsigned& okbits) {
-            const int pix = min((ptid + 256 * k) >> 3, NPIX - 1);
-            const int py = pix / HW, px = pix - py * HW;
-            const int gy = g.ty0 - 1 + py, gx = g.tx0 - 1 + px;
-            const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
-            dst = *reinterpret_cast<const bf16x8*>(a.x + ((size_t)(g.b * a.H + gyc) * a.W + gxc) * a.ldx + cxl);
-            const unsigned okb = (cxok && gy == gyc && gx == gxc) ? 1u : 0u;
-            okbits |= okb << k;
-        };
-        auto load_d = [&](const TileGeo& g, int k, bf16x8& dst, unsigned& okbits) {
-            const int pix = (ptid + 256 * k) >> 3;
-            const int gy = g.ty0 + (pix >> 4), gx = g.tx0 + (pix & 15);
-            const int gyc = min(gy, a.H - 1), gxc = min(gx, a.W - 1);
-            dst = *reinterpret_cast<const bf16x8*>(a.dy + ((size_t)(g.b * a.H + gyc) * a.W + gxc) * a.lddy + cdl);
-            const unsigned okb = (cdok && gy == gyc && gx == gxc) ? 1u : 0u;
-            okbits |= okb << k;
-        };
-        auto put_x = [&](unsigned char* base, int k, const bf16x8& src, bool ok) {
-            const int pix = (ptid + 256 * k) >> 3;
-            u32x4 w = __builtin_bit_cast(u32x4, src);
-            if (XFORM) {
-#pragma unroll
-                for (int pq = 0; pq < 4; ++pq) {
-                    // scalar v_fma_f32 (packed f32 VALU is slow beside the partner wave's MFMAs); ReLU on the packed
-                    // bf16 pair as a signed 16-bit max
-                    const float f0 = __builtin_fmaf(__builtin_bit_cast(float, w[pq] << 16), sc[2 * pq], sh[2 * pq]);
-                    const float f1 = __builtin_fmaf(__builtin_bit_cast(float, w[pq] & 0xffff0000u), sc[2 * pq + 1], sh[2 * pq + 1]);
-                    const bf16x2 pk = {(bf16_t)f0, (bf16_t)f1};
-                    typedef short i16x2 __attribute__((ext_vector_type(2)));
-                    const i16x2 z = {0, 0};
-                    w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w[q] = ok ? w[q] : 0u;
-            if (pix < NPIX) *reinterpret_cast<u32x4*>(base + soff(pix, vv * 16)) = w;
-        };
-        auto put_d = [&](unsigned char* base, int k, const bf16x8& src, bool ok) {
-            const int pix = (ptid + 256 * k) >> 3;
-            u32x4 w = __builtin_bit_cast(u32x4, src);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w[q] = ok ? w[q] : 0u;
-            *reinterpret_cast<u32x4*>(base + X_BYTES + soff(pix, vv * 16)) = w;
-        };
-        bf16x8 x0[XVP], x1[XVP], d0[DVP], d1[DVP];
-        unsigned okx0 = 0, okx1 = 0, okd0 = 0, okd1 = 0;
-        if (t_begin < t_end) {
-            const TileGeo g0 = geo(t_begin);
-#pragma unroll
-            for (int k = 0; k < XVP; ++k) load_x(g0, k, x0[k], okx0);
-#pragma unroll
-            for (int k = 0; k < DVP; ++k) load_d(g0, k, d0[k], okd0);
-        }
-        if (t_begin + 1 < t_end) {
-            const TileGeo g1 = geo(t_begin + 1);
-#pragma unroll
-            for (int k = 0; k < XVP; ++k) load_x(g1, k, x1[k], okx1);
-#pragma unroll
-            for (int k = 0; k < DVP; ++k) load_d(g1, k, d1[k], okd1);
-        }
-        if (t_begin < t_end) {
-#pragma unroll
-            for (int k = 0; k < XVP; ++k) put_x(smem, k, x0[k], (okx0 >> k) & 1u);
-#pragma unroll
-            for (int k = 0; k < DVP; ++k) put_d(smem, k, d0[k], (okd0 >> k) & 1u);
-        }
-        __syncthreads();
-        if (!PACED) {
-            for (int tile = t_begin; tile < t_end; ++tile) {
-                unsigned char* nb = smem + ((((tile - t_begin) & 1) ^ 1) * (X_BYTES + D_BYTES));
-#pragma unroll
-                for (int k = 0; k < XVP; ++k) x0[k] = x1[k];
-#pragma unroll
-                for (int k = 0; k < DVP; ++k) d0[k] = d1[k];
-                okx0 = okx1; okd0 = okd1; okx1 = 0; okd1 = 0;
-                if (tile + 2 < t_end) {
-                    const TileGeo g2 = geo(tile + 2);
-#pragma unroll
-                    for (int k = 0; k < XVP; ++k) load_x(g2, k, x1[k], okx1);
-#pragma unroll
-                    for (int k = 0; k < DVP; ++k) load_d(g2, k, d1[k], okd1);
-                }
-                if (tile + 1 < t_end) {
-#pragma unroll
-                    for (int k = 0; k < XVP; ++k) put_x(nb, k, x0[k], (okx0 >> k) & 1u);
-#pragma unroll
-                    for (int k = 0; k < DVP; ++k) put_d(nb, k, d0[k], (okd0 >> k) & 1u);
-                }
-                __syncthreads();
-            }
-        } else {
-            // iteration `tile`: (xc, dc) hold tile+1: publish them while the loads of tile+2 go into (xn, dn), one load
-            // and one vector of VALU / LDS work alternating, so the memory queue is fed at an even pace
-            auto iter = [&](int tile, bf16x8 (&xn)[XVP], bf16x8 (&dn)[DVP], unsigned& okxn, unsigned& okdn,
-                            const bf16x8 (&xc)[XVP], const bf16x8 (&dc)[DVP], unsigned okxc, unsigned okdc) {
-                unsigned char* nb = smem + ((((tile - t_begin) & 1) ^ 1) * (X_BYTES + D_BYTES));
-                okxn = 0; okdn = 0;
-                if (tile + 2 < t_end) {
-                    const TileGeo g2 = geo(tile + 2);
-#pragma unroll
-                    for (int k = 0; k < XVP; ++k) {
-                        load_x(g2, k, xn[k], okxn);
-                        put_x(nb, k, xc[k], (okxc >> k) & 1u);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int k = 0; k < DVP; ++k) {
-                        load_d(g2, k, dn[k], okdn);
-                        put_d(nb, k, dc[k], (okdc >> k) & 1u);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else if (tile + 1 < t_end) {
-#pragma unroll
-                    for (int k = 0; k < XVP; ++k) put_x(nb, k, xc[k], (okxc >> k) & 1u);
-#pragma unroll
-                    for (int k = 0; k < DVP; ++k) put_d(nb, k, dc[k], (okdc >> k) & 1u);
-                }
-                __syncthreads();
-            };
-            for (int tile = t_begin; tile < t_end; tile += 2) {
-                iter(tile, x0, d0, okx0, okd0, x1, d1, okx1, okd1);
-                if (tile + 1 < t_end) iter(tile + 1, x1, d1, okx1, okd1, x0, d0, okx0, okd0);
-            }
-        }
-        return;
-    }
-
-    // ====================================================================== CONSUMER waves
-    const int mi = wave >> 1, ni = wave & 1;
-    const int r = lane & 31, h = lane >> 5;
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    // transposing-read lane geometry: 16-lane group g = lane>>4; lane i = 4q+p of the group supplies the address of
-    // pixel row q, channels 4p..4p+3 of the group's 16-channel block
-    const int g4 = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    const int chanb = (16 * (g4 & 1) + 4 * p) * 2;   // channel BYTE offset inside the 32-channel block
-    const int pk = 8 * (g4 >> 1) + q;                // pixel offset inside the 16-pixel K step (+4 for the 2nd read)
-    // swizzled byte offsets: for x the swizzle bit of pixel (row*18 + pk + kw [+4]) is (row & 1) ^ ((pk+kw[+4]) >> 1 & 1);
-    // the row part is a compile-time constant in the unrolled loop, so 3 kw x 2 halves x 2 row parities are enough
-    int xo[3][2][2];   // [kw][second read][row parity]
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int par = 0; par < 2; ++par) {
-                const int col = pk + kw + 4 * s2;
-                const int cb = mi * 64 + chanb;
-                xo[kw][s2][par] = col * 128 + (cb ^ ((par ^ ((col >> 1) & 1)) << 6));
-            }
-    int dof[2];        // dy: pixel kr*16 + pk [+4] -> swizzle bit ((pk [+4]) >> 1) & 1  (kr*16 is a multiple of 4)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        const int col = pk + 4 * s2;
-        dof[s2] = col * 128 + ((ni * 64 + chanb) ^ (((col >> 1) & 1) << 6));
-    }
-    __syncthreads();
-
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        const char* sXc = reinterpret_cast<const char*>(smem + (((tile - t_begin) & 1) * (X_BYTES + D_BYTES)));
-        const char* sDc = sXc + X_BYTES;
-#pragma unroll
-        for (int kr = 0; kr < TH; ++kr) {
-            const bf16x8 bfrag = tr_frag(sDc + kr * TW * 128 + dof[0], sDc + kr * TW * 128 + dof[1]);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int kh = tap / 3, kw = tap % 3;
-                const int row = kr + kh;
-                const bf16x8 afrag = tr_frag(sXc + row * HW * 128 + xo[kw][0][row & 1], sXc + row * HW * 128 + xo[kw][1][row & 1]);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[tap], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-    // slab write: acc[tap][i] -> row (ci) = (i&3)+8*(i>>2)+4h, col (co) = r
-    const int CinP = a.ciBlocks * CB, CoutP = a.coBlocks * CB;
-    float* slab = a.ws + (size_t)blockIdx.x * 9 * CinP * CoutP;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-            slab[((size_t)tap * CinP + ci0 + mi * 32 + row) * CoutP + co0 + ni * 32 + r] = acc[tap][i];
-        }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -496,9 +259,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
 
 }  // namespace
 
-static int g_wgrad_variant = 0;   // A/B knobs -- 0: 16x16x32 kernels, 2: 32x32x16 kernel, 1: 32x32x16 with paced producers (1.4 % slower)
-extern "C" void wm_debug_wgrad_variant(int v) { g_wgrad_variant = v; }
-
 void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy,
                         int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s) {
     WsWgArgs a;
@@ -507,27 +267,14 @@ void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale,
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
     a.ciBlocks = wm_cdiv(CinX, CB); a.coBlocks = wm_cdiv(CoutY, CB);
     const dim3 block(512);
-    if (g_wgrad_variant != 2) {   // 16x16x32 kernels (default); CinX <= 16: one 16-channel input block
-        if (CinX <= 16) {
-            a.ciBlocks = 1;   // the slab keeps its 64-row pitch (rows >= 16 are never read back: ci >= Cin)
-            const dim3 grid((unsigned)nslabs, (unsigned)a.coBlocks);
-            WsWgArgs b = a; b.ciBlocks = 1;
-            // the kernel derives CinP from ciBlocks * CB: keep CB-row slabs
-            if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<16, true>), grid, block, 0, s, b);
-            else hipLaunchKernelGGL((wgrad_ws16_kernel<16, false>), grid, block, 0, s, b);
-        } else {
-            const dim3 grid((unsigned)nslabs, (unsigned)(a.ciBlocks * a.coBlocks));
-            if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<64, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((wgrad_ws16_kernel<64, false>), grid, block, 0, s, a);
-        }
-        return;
-    }
-    const dim3 grid((unsigned)nslabs, (unsigned)(a.ciBlocks * a.coBlocks));
-    if (g_wgrad_variant != 1) {
-        if (in_scale) hipLaunchKernelGGL((wgrad_ws_kernel<true, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((wgrad_ws_kernel<false, false>), grid, block, 0, s, a);
+    if (CinX <= 16) {   // one 16-channel input block; the slab keeps its 64-row pitch (rows >= 16 are never read back)
+        a.ciBlocks = 1;
+        const dim3 grid((unsigned)nslabs, (unsigned)a.coBlocks);
+        if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<16, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((wgrad_ws16_kernel<16, false>), grid, block, 0, s, a);
     } else {
-        if (in_scale) hipLaunchKernelGGL((wgrad_ws_kernel<true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((wgrad_ws_kernel<false, true>), grid, block, 0, s, a);
+        const dim3 grid((unsigned)nslabs, (unsigned)(a.ciBlocks * a.coBlocks));
+        if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<64, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((wgrad_ws16_kernel<64, false>), grid, block, 0, s, a);
     }
 }
