@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 // thread -> (pixel slot, 16-byte channel vector).  VPP vectors per pixel, PPB pixels per block-iteration.
 // BT threads per workgroup: the passes that emit partial rows run 1024-thread workgroups on a grid of <= 256, so that the
 // finalisation walks 256 rows directly (no intermediate tree reduction); the pure apply pass streams with 256.
-template <typename T, bool APPLY, int BT>
+template <typename T, bool APPLY, int BT, bool GVEC>
 __global__ __launch_bounds__(BT) void bn_bwd_kernel(const T* __restrict__ g, int ldg, const float* __restrict__ gvec,
                                                              const T* __restrict__ y, int ldy,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
@@ -112,34 +112,58 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const T* __restrict__ g, int
     float a1[VE], a2[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
-    if (ps < PPB) {
-#pragma unroll 2
-        for (size_t q = (size_t)blockIdx.x * PPB + ps; q < npix; q += (size_t)gridDim.x * PPB) {
-            // reverse: sweep the tensors from the end, where the previous pass of the chain stopped (Infinity Cache reuse)
-            const size_t p = reverse ? npix - 1 - q : q;
-            const vec16<T> yv = *reinterpret_cast<const vec16<T>*>(y + p * ldy + c0);
-            vec16<T> gv;
-            const float* gb = nullptr;
-            if (g) gv = *reinterpret_cast<const vec16<T>*>(g + p * ldg + c0);
-            else gb = gvec + (p / hw) * CP + c0;
-            vec16<T> out;
+    // GVEC: the gradient is one vector per sample (a globally pooled output): its values, not a tensor, are streamed
+    auto load_g = [&](size_t p, float (&gg)[VE]) {
+        if (GVEC) {
+            const float* gb = gvec + (p / hw) * CP + c0;
 #pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                const float yy = yv.get(e);
-                const float gg = g ? gv.get(e) : gb[e];
-                const float z = sc[e] * yy + sh[e];
-                const float gz = z > 0.f ? gg : 0.f;
-                const float xh = (yy - mu[e]) * is[e];
-                if (APPLY) {
-                    const float d = ca[e] * (gz - c1[e] - xh * c2[e]);
-                    out.set(e, d);
-                    a1[e] += d;
-                } else {
-                    a1[e] += gz;
-                    a2[e] += gz * xh;
-                }
+            for (int e = 0; e < VE; ++e) gg[e] = gb[e];
+        } else {
+            const vec16<T> gv = *reinterpret_cast<const vec16<T>*>(g + p * ldg + c0);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) gg[e] = gv.get(e);
+        }
+    };
+    auto body = [&](size_t p, const vec16<T>& yv, const float (&gg)[VE]) {
+        vec16<T> out;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            const float yy = yv.get(e);
+            const float z = sc[e] * yy + sh[e];
+            const float gz = z > 0.f ? gg[e] : 0.f;
+            const float xh = (yy - mu[e]) * is[e];
+            if (APPLY) {
+                const float d = ca[e] * (gz - c1[e] - xh * c2[e]);
+                out.set(e, d);
+                a1[e] += d;
+            } else {
+                a1[e] += gz;
+                a2[e] += gz * xh;
             }
-            if (APPLY) *reinterpret_cast<vec16<T>*>(dy + p * lddy + c0) = out;
+        }
+        if (APPLY) *reinterpret_cast<vec16<T>*>(dy + p * lddy + c0) = out;
+    };
+    if (ps < PPB) {
+        // reverse: sweep the tensors from the end, where the previous pass of the chain stopped (Infinity Cache reuse).
+        // Two pixels per trip, all four loads issued before the arithmetic: a straight-line, branch-free body
+        const size_t stride = (size_t)gridDim.x * PPB;
+        size_t q = (size_t)blockIdx.x * PPB + ps;
+        for (; q + stride < npix; q += 2 * stride) {
+            const size_t p0 = reverse ? npix - 1 - q : q, p1 = reverse ? npix - 1 - (q + stride) : q + stride;
+            const vec16<T> y0 = *reinterpret_cast<const vec16<T>*>(y + p0 * ldy + c0);
+            const vec16<T> y1 = *reinterpret_cast<const vec16<T>*>(y + p1 * ldy + c0);
+            float g0[VE], g1[VE];
+            load_g(p0, g0);
+            load_g(p1, g1);
+            body(p0, y0, g0);
+            body(p1, y1, g1);
+        }
+        if (q < npix) {
+            const size_t p0 = reverse ? npix - 1 - q : q;
+            const vec16<T> y0 = *reinterpret_cast<const vec16<T>*>(y + p0 * ldy + c0);
+            float g0[VE];
+            load_g(p0, g0);
+            body(p0, y0, g0);
         }
     }
     if (!partials) return;
@@ -304,7 +328,10 @@ extern "C" int wm_bn_bwd_reduce(const void* g, int ldg, const float* gvec, const
     const int nparts = wm_bn_bwd_nparts(npix);
     hipStream_t s = (hipStream_t)stream;
     WM_DISPATCH_DTYPE(dtype, "wm_bn_bwd_reduce",
-        hipLaunchKernelGGL((bn_bwd_kernel<T, false, BWD_BT>), dim3(nparts), dim3(BWD_BT), 0, s, (const T*)g, ldg, gvec,
+        if (g) hipLaunchKernelGGL((bn_bwd_kernel<T, false, BWD_BT, false>), dim3(nparts), dim3(BWD_BT), 0, s, (const T*)g, ldg, gvec,
+                           (const T*)y, ldy, scale, shift, mean, invstd, (const float*)nullptr, (T*)nullptr, 0, partials,
+                           npix, hw, CP, g_bn_reverse & 1);
+        else hipLaunchKernelGGL((bn_bwd_kernel<T, false, BWD_BT, true>), dim3(nparts), dim3(BWD_BT), 0, s, (const T*)g, ldg, gvec,
                            (const T*)y, ldy, scale, shift, mean, invstd, (const float*)nullptr, (T*)nullptr, 0, partials,
                            npix, hw, CP, g_bn_reverse & 1));
     WM_LAUNCH_CHECK("wm_bn_bwd_reduce");
@@ -333,13 +360,17 @@ extern "C" int wm_bn_bwd_apply(const void* g, int ldg, const float* gvec, const 
     hipStream_t s = (hipStream_t)stream;
     if (dbias_partials) {   // rows for wm_colsum_finalize: same grid as the reduce pass
         WM_DISPATCH_DTYPE(dtype, "wm_bn_bwd_apply",
-            hipLaunchKernelGGL((bn_bwd_kernel<T, true, BWD_BT>), dim3(nparts), dim3(BWD_BT), 0, s, (const T*)g, ldg, gvec,
+            if (g) hipLaunchKernelGGL((bn_bwd_kernel<T, true, BWD_BT, false>), dim3(nparts), dim3(BWD_BT), 0, s, (const T*)g, ldg, gvec,
+                               (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, dbias_partials, npix, hw, CP, (g_bn_reverse >> 1) & 1);
+            else hipLaunchKernelGGL((bn_bwd_kernel<T, true, BWD_BT, true>), dim3(nparts), dim3(BWD_BT), 0, s, (const T*)g, ldg, gvec,
                                (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, dbias_partials, npix, hw, CP, (g_bn_reverse >> 1) & 1));
     } else {
         const size_t nb = (npix + 255) / 256;
         const int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
         WM_DISPATCH_DTYPE(dtype, "wm_bn_bwd_apply",
-            hipLaunchKernelGGL((bn_bwd_kernel<T, true, 256>), dim3(grid), dim3(256), 0, s, (const T*)g, ldg, gvec,
+            if (g) hipLaunchKernelGGL((bn_bwd_kernel<T, true, 256, false>), dim3(grid), dim3(256), 0, s, (const T*)g, ldg, gvec,
+                               (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, dbias_partials, npix, hw, CP, (g_bn_reverse >> 1) & 1);
+            else hipLaunchKernelGGL((bn_bwd_kernel<T, true, 256, true>), dim3(grid), dim3(256), 0, s, (const T*)g, ldg, gvec,
                                (const T*)y, ldy, scale, shift, mean, invstd, coef, (T*)dy, lddy, dbias_partials, npix, hw, CP, (g_bn_reverse >> 1) & 1));
     }
     WM_LAUNCH_CHECK("wm_bn_bwd_apply");
