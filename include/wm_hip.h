@@ -239,6 +239,23 @@ int wm_upconv2x2_dw_chunks(int B, int H, int W);
 int wm_upconv2x2_bwd(const void* x, int ldx, const float* scale, const float* shift, const float* w_t,
                      const void* gy, int ldgy, int c0, void* gx, int ldgx, float* dw_partials,
                      int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
+/* MFMA form of the same layer for bf16 with Cin % 64 == 0 and Cout % 64 == 0 (network/UNet.py:14-38 at every level):
+ * four 1x1 GEMMs over the input pixels + pixel shuffle.  wm_upconv2x2_pack builds the two bf16 operands from the
+ * PyTorch weight [Cin][Cout][2][2]: wf [(ij,co)][Cin] (forward) and wb [Cin][(ij,co)] (dgrad).
+ *   fwd  : y[b,2h+i,2w+j,c0+co] = bias[co] + sum_ci relu(scale*x+shift)[b,h,w,ci] * w[ci,co,i,j]
+ *   dgrad: gx[b,h,w,ci] = sum_(i,j,co) gy[b,2h+i,2w+j,c0+co] * w[ci,co,i,j]   (gradient wrt the ACTIVATED input)
+ *   wgrad: dw[ci,co,i,j] (+)= sum_(b,h,w) relu(scale*x+shift)[b,h,w,ci] * gy[b,2h+i,2w+j,c0+co];  dbias[co] (+)= sum gy
+ *          partial: f32[wm_upconv2x2_wgrad_nsplit][Cin][4*Cout], bias_partial: f32[nsplit][4*Cout] (scratch). */
+int wm_upconv2x2_mfma_supported(int Cin, int Cout, int dtype);
+int wm_upconv2x2_pack(const float* w, void* wf, void* wb, int Cin, int Cout, void* stream);
+int wm_upconv2x2_fwd_mfma(const void* x, int ldx, const float* scale, const float* shift, const void* wf, const float* bias,
+                          void* y, int ldy, int c0, int B, int H, int W, int Cin, int Cout, void* stream);
+int wm_upconv2x2_dgrad_mfma(const void* gy, int ldgy, int c0, const void* wb, void* gx, int ldgx, int B, int H, int W, int Cin,
+                            int Cout, void* stream);
+int wm_upconv2x2_wgrad_nsplit(int B, int H, int W, int Cin, int Cout);
+int wm_upconv2x2_wgrad_mfma(const void* x, int ldx, const float* scale, const float* shift, const void* gy, int ldgy, int c0,
+                            float* partial, float* bias_partial, float* dw, float* dbias, int accumulate, int B, int H, int W,
+                            int Cin, int Cout, void* stream);
 
 /* ------------------------------------------------------------------ losses / optimiser
  * sum((a-b)^2) partials and gradient 2*w*(a-b)/n of nn.MSELoss (hidden.py:37,90). */

@@ -49,7 +49,7 @@ def test_maxpool_fwd_bwd(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(2, 6, 10, 64, 32), (1, 4, 4, 512, 256)])
+@pytest.mark.parametrize("case", [(2, 6, 10, 64, 32), (1, 4, 4, 512, 256), (2, 24, 20, 128, 64), (3, 17, 13, 64, 64)])
 def test_upconv_fwd_bwd(dtype, case):
     from video_watermarking_forgery_detection_amd import ops
     B, H, W, Cin, Cout = case
@@ -77,6 +77,11 @@ def test_upconv_fwd_bwd(dtype, case):
     t2 = 1e-4 if dtype == torch.float32 else 1e-2
     torch.testing.assert_close(dw.cpu(), up.weight.grad, rtol=t2, atol=t2 * up.weight.grad.abs().max().item())
     torch.testing.assert_close(db.cpu(), up.bias.grad, rtol=t2, atol=t2 * up.bias.grad.abs().max().item())
+    # accumulate=True adds onto what is there
+    dw2 = dw.clone(); db2 = db.clone()
+    ops.upconv2x2_bwd(nhwc(x, dtype), sc.cuda(), sh.cuda(), up.weight.detach().cuda(), gcat.cuda(), 0, dw2, db2, True)
+    torch.testing.assert_close(dw2, 2 * dw, rtol=1e-5, atol=1e-5 * dw.abs().max().item())
+    torch.testing.assert_close(db2, 2 * db, rtol=1e-5, atol=1e-5 * db.abs().max().item())
 
 
 def test_unet_golden(golden):

@@ -558,10 +558,30 @@ def maxpool2_bwd(y, scale, shift, gpooled, g_skip, g_skip_c0, C):
     return g
 
 
+def upconv2x2_mfma_supported(Cin, Cout, dtype):
+    return bool(_lib.lib().wm_upconv2x2_mfma_supported(c_int(Cin), c_int(Cout), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32)))
+
+
+def upconv2x2_pack(w):
+    """w [Cin,Cout,2,2] f32 -> (wf bf16 [4*Cout, Cin] rows (ij, co), wb bf16 [Cin, 4*Cout] columns (ij, co)): the MFMA operands"""
+    Cin, Cout = w.shape[0], w.shape[1]
+    wf = torch.empty(4 * Cout, Cin, device=w.device, dtype=torch.bfloat16)
+    wb = torch.empty(Cin, 4 * Cout, device=w.device, dtype=torch.bfloat16)
+    rc = _lib.lib().wm_upconv2x2_pack(_p(w), _p(wf), _p(wb), c_int(Cin), c_int(Cout), _stream())
+    _lib.check(rc, "wm_upconv2x2_pack")
+    return wf, wb
+
+
 def upconv2x2_fwd(x, scale, shift, w, bias, out, c0):
     """x [B,H,W,Cin] (raw + pending BN/ReLU) ; w [Cin,Cout,2,2] f32 -> writes out[B,2H,2W,ld] channels [c0,c0+Cout)."""
     B, H, W, ldx = x.shape
     Cin, Cout = w.shape[0], w.shape[1]
+    if upconv2x2_mfma_supported(Cin, Cout, x.dtype):
+        wf, _ = upconv2x2_pack(w)
+        rc = _lib.lib().wm_upconv2x2_fwd_mfma(_p(x), c_int(ldx), _p(scale), _p(shift), _p(wf), _p(bias), _p(out), c_int(out.shape[-1]),
+                                              c_int(c0), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(Cout), _stream())
+        _lib.check(rc, "wm_upconv2x2_fwd_mfma")
+        return out
     rc = _lib.lib().wm_upconv2x2_fwd(_p(x), c_int(ldx), _p(scale), _p(shift), _p(w), _p(bias), _p(out), c_int(out.shape[-1]),
                                      c_int(c0), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(Cout), c_int(dtype_id(x)), _stream())
     _lib.check(rc, "wm_upconv2x2_fwd")
@@ -573,6 +593,20 @@ def upconv2x2_bwd(x, scale, shift, w, gy, c0, dw, dbias, accumulate):
     B, H, W, ldx = x.shape
     Cin, Cout = w.shape[0], w.shape[1]
     L = _lib.lib()
+    if upconv2x2_mfma_supported(Cin, Cout, x.dtype):
+        _, wb = upconv2x2_pack(w)
+        gx = torch.empty(B, H, W, Cin, device=x.device, dtype=x.dtype)
+        rc = L.wm_upconv2x2_dgrad_mfma(_p(gy), c_int(gy.shape[-1]), c_int(c0), _p(wb), _p(gx), c_int(Cin), c_int(B), c_int(H), c_int(W),
+                                       c_int(Cin), c_int(Cout), _stream())
+        _lib.check(rc, "wm_upconv2x2_dgrad_mfma")
+        ns = L.wm_upconv2x2_wgrad_nsplit(c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(Cout))
+        part = torch.empty(ns, Cin, 4 * Cout, device=x.device, dtype=torch.float32)
+        bpart = torch.empty(ns, 4 * Cout, device=x.device, dtype=torch.float32)
+        rc = L.wm_upconv2x2_wgrad_mfma(_p(x), c_int(ldx), _p(scale), _p(shift), _p(gy), c_int(gy.shape[-1]), c_int(c0), _p(part), _p(bpart),
+                                       _p(dw), _p(dbias), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W), c_int(Cin),
+                                       c_int(Cout), _stream())
+        _lib.check(rc, "wm_upconv2x2_wgrad_mfma")
+        return gx
     chunks = L.wm_upconv2x2_dw_chunks(c_int(B), c_int(H), c_int(W))
     N = 4 * Cout
     part = torch.empty(chunks, (Cin + 1) * N, device=x.device, dtype=torch.float32)
