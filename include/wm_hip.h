@@ -239,7 +239,7 @@ int wm_upconv2x2_dw_chunks(int B, int H, int W);
 int wm_upconv2x2_bwd(const void* x, int ldx, const float* scale, const float* shift, const float* w_t,
                      const void* gy, int ldgy, int c0, void* gx, int ldgx, float* dw_partials,
                      int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
-/* MFMA form of the same layer for bf16 with Cin % 64 == 0 and Cout % 64 == 0 (network/UNet.py:14-38 at every level):
+/* MFMA form of the same layer for bf16 with Cin % 64 == 0 and Cout % 16 == 0 (network/UNet.py:14-38 at every level):
  * four 1x1 GEMMs over the input pixels + pixel shuffle.  wm_upconv2x2_pack builds the two bf16 operands from the
  * PyTorch weight [Cin][Cout][2][2]: wf [(ij,co)][Cin] (forward) and wb [Cin][(ij,co)] (dgrad).
  *   fwd  : y[b,2h+i,2w+j,c0+co] = bias[co] + sum_ci relu(scale*x+shift)[b,h,w,ci] * w[ci,co,i,j]

@@ -49,7 +49,7 @@ def test_maxpool_fwd_bwd(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(2, 6, 10, 64, 32), (1, 4, 4, 512, 256), (2, 24, 20, 128, 64), (3, 17, 13, 64, 64)])
+@pytest.mark.parametrize("case", [(2, 6, 10, 64, 32), (1, 4, 4, 512, 256), (2, 24, 20, 128, 64), (3, 17, 13, 64, 64), (2, 10, 12, 64, 16)])
 def test_upconv_fwd_bwd(dtype, case):
     from video_watermarking_forgery_detection_amd import ops
     B, H, W, Cin, Cout = case

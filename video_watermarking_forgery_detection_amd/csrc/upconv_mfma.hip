@@ -1,4 +1,4 @@
-// ConvTranspose2d(kernel 2, stride 2) of network/UNet.py:14-38 on MFMA (bf16, Cin % 64 == 0, Cout % 64 == 0).
+// ConvTranspose2d(kernel 2, stride 2) of network/UNet.py:14-38 on MFMA (bf16, Cin % 64 == 0, Cout % 16 == 0).
 // k2s2 means every output pixel (2h+i, 2w+j) has exactly ONE tap (i, j): the layer is four 1x1 GEMMs over the INPUT
 // pixels, Y4[p][(ij, co)] = sum_ci A[p][ci] * W[ci][co][ij], followed by a pixel shuffle.  Three kernels:
 //   upconv_mfma_kernel<0>  forward : A = relu(scale*x+shift) fused while staging, columns (ij, co), shuffle + bias on store
@@ -69,8 +69,9 @@ __global__ __launch_bounds__(256, 2) void upconv_mfma_kernel(UpArgs a) {
             size_t off;
             if (MODE == 0) off = ibase[k] + k0 + ivec * 8;
             else {
-                const int ij = k0 / a.Cout, co0 = k0 - ij * a.Cout;     // the chunk lies inside one tap (Cout % 64 == 0)
-                off = ibase[k] + ((size_t)(ij >> 1) * 2 * a.W + (ij & 1)) * a.ldin + co0 + ivec * 8;
+                const int kk = k0 + ivec * 8;                           // an 8-channel vector lies inside one tap (Cout % 16 == 0)
+                const int ij = kk / a.Cout, co = kk - ij * a.Cout;
+                off = ibase[k] + ((size_t)(ij >> 1) * 2 * a.W + (ij & 1)) * a.ldin + co;
             }
             rin[k] = *reinterpret_cast<const bf16x8*>(a.in + off);
         }
@@ -148,12 +149,12 @@ __global__ __launch_bounds__(256, 2) void upconv_mfma_kernel(UpArgs a) {
     float bv[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) bv[j] = 0.f;
-    int ij = 0, co0 = 0;
+    int ij = 0, co0 = 0;   // the lane's 16 columns n0 + 16q .. lie inside one tap (Cout % 16 == 0)
     if (MODE == 0) {
-        ij = n0 / a.Cout; co0 = n0 - ij * a.Cout;
+        ij = (n0 + 16 * q) / a.Cout; co0 = (n0 + 16 * q) - ij * a.Cout;
         if (a.bias) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) bv[j] = a.bias[co0 + 16 * q + j];
+            for (int j = 0; j < 16; ++j) bv[j] = a.bias[co0 + j];
         }
     }
 #pragma unroll
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void upconv_mfma_kernel(UpArgs a) {
             const int w_ = (int)(P % a.W);
             const int h_ = (int)((P / a.W) % a.H);
             const size_t b = P / ((size_t)a.W * a.H);
-            o = a.out + ((b * 2 * a.H + 2 * h_ + (ij >> 1)) * 2 * a.W + 2 * w_ + (ij & 1)) * (size_t)a.ldout + a.c0 + co0 + 16 * q;
+            o = a.out + ((b * 2 * a.H + 2 * h_ + (ij >> 1)) * 2 * a.W + 2 * w_ + (ij & 1)) * (size_t)a.ldout + a.c0 + co0;
         } else {
             o = a.out + P * a.ldout + n0 + 16 * q;
         }
@@ -210,13 +211,13 @@ __global__ __launch_bounds__(256, 2) void upconv_wgrad_kernel(UpWgArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci0 = blockIdx.x * 64, n0 = blockIdx.y * 64, split = blockIdx.z;
     const int N = 4 * a.Cout;
-    const int ij = n0 / a.Cout, co0 = n0 - ij * a.Cout;
     const size_t Min = (size_t)a.B * a.H * a.W;
     const size_t per = ((Min + a.nsplit - 1) / a.nsplit + PC - 1) / PC * PC;
     const size_t pbeg = (size_t)split * per, pend = pbeg + per < Min ? pbeg + per : Min;
     const int nchunks = pbeg < pend ? (int)((pend - pbeg + PC - 1) / PC) : 0;
 
     const int vec = tid & 7, prow = tid >> 3;   // staging: pixel rows prow, prow + 32; 16-byte vector `vec`
+    const int ij = (n0 + vec * 8) / a.Cout, co0 = (n0 + vec * 8) - ij * a.Cout;   // this thread's 8 columns lie inside one tap
     float sc[8], sh[8];
     const bool xf = a.scale != nullptr;
 #pragma unroll
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void upconv_wgrad_kernel(UpWgArgs a) {
             const int h_ = (int)((Pc / a.W) % a.H);
             const size_t b = Pc / ((size_t)a.W * a.H);
             rg[k] = *reinterpret_cast<const bf16x8*>(a.gy + ((b * 2 * a.H + 2 * h_ + (ij >> 1)) * 2 * a.W + 2 * w_ + (ij & 1)) * (size_t)a.ldgy +
-                                                     a.c0 + co0 + vec * 8);
+                                                     a.c0 + co0);
         }
     };
     auto put_chunk = [&](int buf) {
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256) void upconv_pack_kernel(const float* __restric
 }  // namespace
 
 extern "C" int wm_upconv2x2_mfma_supported(int Cin, int Cout, int dtype) {
-    return (dtype == WM_BF16 && Cin % 64 == 0 && Cout % 64 == 0) ? 1 : 0;
+    return (dtype == WM_BF16 && Cin % 64 == 0 && Cout % 16 == 0) ? 1 : 0;
 }
 
 extern "C" int wm_upconv2x2_pack(const float* w, void* wf, void* wb, int Cin, int Cout, void* stream) {
@@ -370,7 +371,7 @@ extern "C" int wm_upconv2x2_fwd_mfma(const void* x, int ldx, const float* scale,
                                      void* stream) {
     WM_REQUIRE(x && wf && y, WM_E_BADARG, "wm_upconv2x2_fwd_mfma: null pointer");
     WM_REQUIRE((scale == nullptr) == (shift == nullptr), WM_E_BADARG, "wm_upconv2x2_fwd_mfma: scale/shift must come together");
-    WM_REQUIRE(wm_upconv2x2_mfma_supported(Cin, Cout, WM_BF16), WM_E_SHAPE, "wm_upconv2x2_fwd_mfma: Cin=%d, Cout=%d must be multiples of 64", Cin, Cout);
+    WM_REQUIRE(wm_upconv2x2_mfma_supported(Cin, Cout, WM_BF16), WM_E_SHAPE, "wm_upconv2x2_fwd_mfma: Cin=%d, Cout=%d must be multiples of 64 / 16", Cin, Cout);
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && ldx >= Cin && ldy >= c0 + Cout && ldx % 8 == 0 && ldy % 8 == 0 && c0 % 8 == 0, WM_E_SHAPE,
                "wm_upconv2x2_fwd_mfma: bad strides (ldx=%d ldy=%d c0=%d)", ldx, ldy, c0);
     UpArgs a;
@@ -386,7 +387,7 @@ extern "C" int wm_upconv2x2_fwd_mfma(const void* x, int ldx, const float* scale,
 extern "C" int wm_upconv2x2_dgrad_mfma(const void* gy, int ldgy, int c0, const void* wb, void* gx, int ldgx, int B, int H, int W,
                                        int Cin, int Cout, void* stream) {
     WM_REQUIRE(gy && wb && gx, WM_E_BADARG, "wm_upconv2x2_dgrad_mfma: null pointer");
-    WM_REQUIRE(wm_upconv2x2_mfma_supported(Cin, Cout, WM_BF16), WM_E_SHAPE, "wm_upconv2x2_dgrad_mfma: Cin=%d, Cout=%d must be multiples of 64", Cin, Cout);
+    WM_REQUIRE(wm_upconv2x2_mfma_supported(Cin, Cout, WM_BF16), WM_E_SHAPE, "wm_upconv2x2_dgrad_mfma: Cin=%d, Cout=%d must be multiples of 64 / 16", Cin, Cout);
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && ldgx >= Cin && ldgy >= c0 + Cout && ldgx % 8 == 0 && ldgy % 8 == 0 && c0 % 8 == 0, WM_E_SHAPE,
                "wm_upconv2x2_dgrad_mfma: bad strides (ldgx=%d ldgy=%d c0=%d)", ldgx, ldgy, c0);
     UpArgs a;
@@ -415,7 +416,7 @@ extern "C" int wm_upconv2x2_wgrad_mfma(const void* x, int ldx, const float* scal
                                        int H, int W, int Cin, int Cout, void* stream) {
     WM_REQUIRE(x && gy && partial && bias_partial && dw && dbias, WM_E_BADARG, "wm_upconv2x2_wgrad_mfma: null pointer");
     WM_REQUIRE((scale == nullptr) == (shift == nullptr), WM_E_BADARG, "wm_upconv2x2_wgrad_mfma: scale/shift must come together");
-    WM_REQUIRE(wm_upconv2x2_mfma_supported(Cin, Cout, WM_BF16), WM_E_SHAPE, "wm_upconv2x2_wgrad_mfma: Cin=%d, Cout=%d must be multiples of 64", Cin, Cout);
+    WM_REQUIRE(wm_upconv2x2_mfma_supported(Cin, Cout, WM_BF16), WM_E_SHAPE, "wm_upconv2x2_wgrad_mfma: Cin=%d, Cout=%d must be multiples of 64 / 16", Cin, Cout);
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && ldx >= Cin && ldgy >= c0 + Cout && ldx % 8 == 0 && ldgy % 8 == 0 && c0 % 8 == 0, WM_E_SHAPE,
                "wm_upconv2x2_wgrad_mfma: bad strides (ldx=%d ldgy=%d c0=%d)", ldx, ldgy, c0);
     UpWgArgs a;
