@@ -396,8 +396,8 @@ extern "C" int wm_pack_w3x3(const float* w, void* wp, int Cout, int Cin, int Cou
 extern "C" int wm_pack_w3x3_batch(const void* jobs_dev, int njobs, size_t max_elems, int dtype, void* stream) {
     WM_REQUIRE(jobs_dev && njobs > 0 && max_elems > 0, WM_E_BADARG, "wm_pack_w3x3_batch: bad arguments");
     static_assert(sizeof(PackJob) == 48, "PackJob layout is part of the ABI (wm_hip.h)");
-    int blocks = (int)((max_elems + 255) / 256);
-    if (blocks > 64) blocks = 64;
+    int blocks = (int)((max_elems + 255) / 256);   // per job (grid.y = jobs); small jobs leave their surplus blocks idle
+    if (blocks > 512) blocks = 512;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks, (unsigned)njobs);
     if (dtype == WM_BF16) hipLaunchKernelGGL(pack_w3x3_batch_kernel<bf16_t>, grid, dim3(256), 0, s, (const PackJob*)jobs_dev);

@@ -175,12 +175,16 @@ class IRNrhiModel(BaseModel):
         tampered = fwd_img * (1 - mask) + prev * mask           # splice (:348)
         attacked, cA = self.attack.fwd(tampered)
         attacked_q = ops.quant(attacked)                          # Quantization (:373)
-        pred, cU = net.fwd(attacked_q)
-        # reference applies BCEWithLogits to the sigmoid output (:378,391-393)
-        loss = F.binary_cross_entropy_with_logits(pred, mask)
-        g_pred = (torch.sigmoid(pred) - mask) / pred.numel() * self.localizer_weight
-        grads = engine.grad_dict(net)
-        g_att = net.bwd(cU, g_pred, grads, accumulate=False, need_input_grad=True)
+        net.refresh_packs()   # all conv weights of the localiser packed in one launch, valid until its optimiser step
+        try:
+            pred, cU = net.fwd(attacked_q)
+            # reference applies BCEWithLogits to the sigmoid output (:378,391-393)
+            loss = F.binary_cross_entropy_with_logits(pred, mask)
+            g_pred = (torch.sigmoid(pred) - mask) / pred.numel() * self.localizer_weight
+            grads = engine.grad_dict(net)
+            g_att = net.bwd(cU, g_pred, grads, accumulate=False, need_input_grad=True)
+        finally:
+            net.invalidate_packs()
         if self.grad_sync is not None:
             self.grad_sync(net.flat_grads)
         self._clip(net.flat_grads)
