@@ -260,6 +260,11 @@ def test_layout_roundtrip_and_concat():
         cat2 = torch.full((B, H, W, 112), 7.0, device="cuda", dtype=dtype)
         ops.concat_full(nhwc(feat, dtype), sc.cuda(), sh.cuda(), msg.cuda(), img.cuda(), cat2, 64)
         assert torch.equal(cat2, cat)
+        # ... and so do the two halves it replaced (wm_bnrelu_copy + wm_concat_tail)
+        cat3 = torch.full((B, H, W, 112), 3.0, device="cuda", dtype=dtype)
+        ops.bnrelu_copy(nhwc(feat, dtype), sc.cuda(), sh.cuda(), cat3, 0, 64)
+        ops.concat_tail(msg.cuda(), img.cuda(), cat3, 64)
+        assert torch.equal(cat3, cat)
 
 
 def test_adam_matches_torch():
