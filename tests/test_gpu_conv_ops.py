@@ -32,6 +32,8 @@ CASES = [  # B, H, W, Cin, Cout
     (1, 33, 16, 64, 32),
     (2, 50, 70, 64, 32),      # persistent kernel, 32 output channels (image dgrads, the 30-channel layer)
     (1, 16, 48, 32, 128),
+    (2, 40, 36, 128, 128),    # streamed-filter kernel (Cin > 64), ragged tiles, two output tiles
+    (1, 20, 21, 256, 64),
     (3, 100, 90, 64, 64),     # persistent 64-channel kernel, ragged tiles
     (2, 256, 256, 64, 64),    # persistent kernel, 2 tiles per workgroup
 ]

@@ -20,7 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # MFMA kernels: keep the compiler from SLP-packing scalar f32 VALU into v_pk_*_f32 -- packed f32 issues far slower
 # than two scalar ops beside MFMAs (MI355X_MICROARCH.md, constants table)
-EXTRA = {"conv3x3_ws.hip": ["-fno-slp-vectorize"], "wgrad_ws.hip": ["-fno-slp-vectorize"], "upconv_mfma.hip": ["-fno-slp-vectorize"]}
+EXTRA = {"conv3x3_ws.hip": ["-fno-slp-vectorize"], "wgrad_ws.hip": ["-fno-slp-vectorize"], "upconv_mfma.hip": ["-fno-slp-vectorize"], "conv3x3_stream.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():

@@ -21,6 +21,12 @@
 #include <type_traits>
 #include "wm_common.h"
 
+// streamed-filter wave-specialised kernel for bf16 Cin > 64 (conv3x3_stream.hip)
+int wm_conv3x3_stream_supported(int Cin, int CoutP);
+int wm_conv3x3_stream_nparts(int B, int H, int W);
+int wm_launch_conv3x3_stream(const void* x, int ldx, const void* wp, const float* bias, int nbias, const float* in_scale,
+                             const float* in_shift, void* y, int ldy, float* stat, int B, int H, int W, int Cin, int CoutP,
+                             hipStream_t s);
 // persistent wave-specialised kernel for bf16 Cin in {64,32,16}, Cout in {64,32} (conv3x3_ws.hip)
 int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void* wp, const float* bias, int nbias, const float* in_scale,
                          const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
@@ -244,6 +250,10 @@ inline bool use_ws(int Cin, int CoutP, int dtype) {
     static const bool off = getenv("WM_NO_WS") != nullptr;  // diagnostic knob: force the generic kernel
     return !off && dtype == WM_BF16 && (((Cin == 64 || Cin == 32 || Cin == 16) && CoutP == 64) || (Cin == 64 && CoutP == 32));
 }  // + ldy == CoutP (a dense output tensor)
+inline bool use_stream(int Cin, int CoutP, int dtype) {
+    static const bool off = getenv("WM_NO_STREAM") != nullptr;  // diagnostic knob: force the generic kernel
+    return !off && dtype == WM_BF16 && !use_ws(Cin, CoutP, dtype) && wm_conv3x3_stream_supported(Cin, CoutP);
+}
 inline int ws_tiles_per_wg(int ntiles) { return (ntiles + WS_MAX_WGS - 1) / WS_MAX_WGS; }
 inline int ws_wgs(int ntiles) { const int per = ws_tiles_per_wg(ntiles); return (ntiles + per - 1) / per; }
 
@@ -326,6 +336,10 @@ int launch_conv(const void* x, int ldx, const void* wp, const float* bias, int n
             return wm_launch_conv3x3_ws(x, ldx, Cin, CoutP, wp, bias, nbias, in_scale, in_shift, y, stat, B, H, W, ws_wgs(ntiles), per, s);
         }
     }
+    if constexpr (sizeof(T) == 2) {
+        if (use_stream(Cin, CoutP, WM_BF16))
+            return wm_launch_conv3x3_stream(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat, B, H, W, Cin, CoutP, s);
+    }
     const int BN = (CoutP % 64 == 0) ? 64 : 32;
     dim3 grid((unsigned)(B * a.tilesX * a.tilesY), (unsigned)(CoutP / BN)), block(256);
     if (BN == 64) {
@@ -342,6 +356,7 @@ int launch_conv(const void* x, int ldx, const void* wp, const float* bias, int n
 
 extern "C" int wm_conv3x3_nparts(int B, int H, int W, int Cin, int CoutP, int dtype) {
     const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
+    if (use_stream(Cin, CoutP, dtype)) return wm_conv3x3_stream_nparts(B, H, W);
     return use_ws(Cin, CoutP, dtype) ? ws_wgs(ntiles) : ntiles;
 }
 
