@@ -152,15 +152,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             }
         }
         // tile-invariant per-vector geometry: halo pixel (py, px), its offset inside an interior tile, its LDS slot
+        // EDGE (CIN = 64): the vector slots are ordered so that k < KMAIN covers halo columns 2..17 (18 x 16 pixels x 8 vectors
+        // = 9 x 256 exactly) and k >= KMAIN the columns 0..1, which a tile shares with its left neighbour: when the previous
+        // tile of the run IS that neighbour, those 36 pixels are copied LDS -> LDS from its columns 16..17 (already transformed)
+        // instead of being loaded again: 11 % fewer bytes through the CU's memory path, which is what bounds this kernel
+        constexpr bool EDGE = CIN == 64;
+        constexpr int KMAIN = EDGE ? 9 : XVP;
         int hpy[XVP], hpx[XVP], rel[XVP], lds[XVP];
 #pragma unroll
         for (int k = 0; k < XVP; ++k) {
-            const int pix = min((ptid + 256 * k) / VPP, NPIX - 1);
-            hpy[k] = pix / HW; hpx[k] = pix - hpy[k] * HW;
-            rel[k] = (hpy[k] * a.W + hpx[k]) * a.ldx + vec * 8;
-            lds[k] = pix * CIN + swz_px<CIN>(hpx[k], vec) * 8;
+            int py, px;
+            if (EDGE) {
+                if (k < KMAIN) { const int m = (ptid + 256 * k) >> 3; py = m >> 4; px = 2 + (m & 15); }
+                else { const int e = min((ptid + 256 * (k - KMAIN)) >> 3, 35); py = e >> 1; px = e & 1; }
+            } else {
+                const int pix = min((ptid + 256 * k) / VPP, NPIX - 1);
+                py = pix / HW; px = pix - py * HW;
+            }
+            hpy[k] = py; hpx[k] = px;
+            rel[k] = (py * a.W + px) * a.ldx + vec * 8;
+            lds[k] = (py * HW + px) * CIN + swz_px<CIN>(px, vec) * 8;
         }
-        const bool last_live = ((ptid + 256 * (XVP - 1)) / VPP) < NPIX;
+        const bool last_live = EDGE ? (((ptid + 256 * (XVP - 1 - KMAIN)) >> 3) < 36) : (((ptid + 256 * (XVP - 1)) / VPP) < NPIX);
+        // does tile T start with the two columns its predecessor in the run ended with?
+        auto reuse_of = [&](int T) { return EDGE && !a.reverse && !(a.dbg & 64) && T > t_begin && (T % a.tilesX) != 0; };
         // loads: always a valid address, never under a per-lane branch; the branches on `interior` are wave-uniform
         auto is_interior = [&](const TileGeo& g) {
             return g.ty0 >= 1 && g.ty0 + TH + 1 <= a.H && g.tx0 >= 1 && g.tx0 + TW + 1 <= a.W;
@@ -174,19 +189,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         };
         auto tile_ptr = [&](const TileGeo& g) { return a.x + ((size_t)(g.b * a.H + g.ty0 - 1) * a.W + (g.tx0 - 1)) * a.ldx; };
         auto image_ptr = [&](const TileGeo& g) { return a.x + (size_t)g.b * a.H * a.W * a.ldx; };
-        auto load_tile = [&](const TileGeo& g, bf16x8 (&d)[XVP], unsigned& okbits) {
+        auto load_tile = [&](const TileGeo& g, bf16x8 (&d)[XVP], unsigned& okbits, bool reuse) {
             if (STAMPS && (a.dbg & 4)) { okbits = 0xffffffffu; return; }
             if (is_interior(g)) {
                 const bf16_t* xt = tile_ptr(g);
 #pragma unroll
-                for (int k = 0; k < XVP; ++k) load_interior(xt, k, d[k]);
+                for (int k = 0; k < KMAIN; ++k) load_interior(xt, k, d[k]);
+                if (!reuse) {
+#pragma unroll
+                    for (int k = KMAIN; k < XVP; ++k) load_interior(xt, k, d[k]);
+                }
                 okbits = 0xffffffffu;
             } else {
                 const bf16_t* xb = image_ptr(g);
                 okbits = 0;
 #pragma unroll
-                for (int k = 0; k < XVP; ++k) load_border(g, xb, k, d[k], okbits);
+                for (int k = 0; k < KMAIN; ++k) load_border(g, xb, k, d[k], okbits);
+                if (!reuse) {
+#pragma unroll
+                    for (int k = KMAIN; k < XVP; ++k) load_border(g, xb, k, d[k], okbits);
+                }
             }
+        };
+        // edge vector k of the tile being published <- columns 16..17 of the tile in the other buffer
+        auto copy_edge = [&](bf16_t* sX, const bf16_t* sPrev, int k) {
+            const int px = hpx[k] + 16;
+            const u32x4 w = *reinterpret_cast<const u32x4*>(sPrev + (hpy[k] * HW + px) * CIN + swz_px<CIN>(px, vec) * 8);
+            if (k + 1 < XVP || last_live) *reinterpret_cast<u32x4*>(sX + lds[k]) = w;
         };
         // fused BN + ReLU (ReLU on the packed bf16 pair as a signed 16-bit max), zero padding AFTER the activation
         auto put_one = [&](bf16_t* sX, int k, const bf16x8& d, unsigned okbits) {
@@ -209,8 +238,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         };
         bf16x8 dA[XVP], dB[XVP];
         unsigned okA = 0, okB = 0;
-        if (t_begin < t_end) load_tile(geo(t_begin), dA, okA);
-        if (t_begin + 1 < t_end) load_tile(geo(t_begin + 1), dB, okB);
+        if (t_begin < t_end) load_tile(geo(t_begin), dA, okA, false);
+        if (t_begin + 1 < t_end) load_tile(geo(t_begin + 1), dB, okB, reuse_of(t_begin + 1));
         if (t_begin < t_end) {
 #pragma unroll
             for (int k = 0; k < XVP; ++k) put_one(sX0, k, dA[k], okA);
@@ -222,31 +251,50 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         // at an even pace and never holds the whole burst
         auto iter = [&](int tile, bf16x8 (&nxt)[XVP], unsigned& oknxt, const bf16x8 (&cur)[XVP], unsigned okcur) {
             bf16_t* sXn = sX0 + (((tile - t_begin) & 1) ^ 1) * (NPIX * CIN);
+            const bf16_t* sXc = sX0 + ((tile - t_begin) & 1) * (NPIX * CIN);   // the tile the consumers are on: left neighbour of tile+1
             const bool have_next = tile + 2 < t_end && !(STAMPS && (a.dbg & 4));
+            const bool reuse_cur = reuse_of(tile + 1), reuse_nxt = reuse_of(tile + 2);
             if (have_next) {
                 const TileGeo g2 = geo(tile + 2);
                 if (is_interior(g2)) {
                     const bf16_t* xt = tile_ptr(g2);
                     oknxt = 0xffffffffu;
 #pragma unroll
-                    for (int k = 0; k < XVP; ++k) {
+                    for (int k = 0; k < KMAIN; ++k) {
                         load_interior(xt, k, nxt[k]);
                         put_one(sXn, k, cur[k], okcur);
                         __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (!reuse_nxt) {
+#pragma unroll
+                        for (int k = KMAIN; k < XVP; ++k) load_interior(xt, k, nxt[k]);
                     }
                 } else {
                     const bf16_t* xb = image_ptr(g2);
                     oknxt = 0;
 #pragma unroll
-                    for (int k = 0; k < XVP; ++k) {
+                    for (int k = 0; k < KMAIN; ++k) {
                         load_border(g2, xb, k, nxt[k], oknxt);
                         put_one(sXn, k, cur[k], okcur);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    if (!reuse_nxt) {
+#pragma unroll
+                        for (int k = KMAIN; k < XVP; ++k) load_border(g2, xb, k, nxt[k], oknxt);
+                    }
                 }
             } else if (tile + 1 < t_end) {
 #pragma unroll
-                for (int k = 0; k < XVP; ++k) put_one(sXn, k, cur[k], okcur);
+                for (int k = 0; k < KMAIN; ++k) put_one(sXn, k, cur[k], okcur);
+            }
+            if (tile + 1 < t_end) {   // the edge columns of tile+1: copied from the neighbour or published from the loaded data
+                if (reuse_cur) {
+#pragma unroll
+                    for (int k = KMAIN; k < XVP; ++k) copy_edge(sXn, sXc, k);
+                } else {
+#pragma unroll
+                    for (int k = KMAIN; k < XVP; ++k) put_one(sXn, k, cur[k], okcur);
+                }
             }
             stamp(0);  // loads of tile+2 interleaved with transform + LDS writes of tile+1
             if (STAMPS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -587,7 +635,7 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
 }
 
 static int g_ws_reverse = 0;
-static int g_ws_variant = getenv("WM_WS_VARIANT") ? atoi(getenv("WM_WS_VARIANT")) : 0;   // A/B knobs -- 1: 32x32x16 MFMA consumers, 2: no XCD-aware run assignment, 3: producers at s_setprio 3
+static int g_ws_variant = getenv("WM_WS_VARIANT") ? atoi(getenv("WM_WS_VARIANT")) : 0;   // A/B knobs -- 1: 32x32x16 MFMA consumers, 2: no XCD-aware run assignment, 3: producers at s_setprio 3, 8: no halo-edge reuse
 extern "C" void wm_debug_ws_variant(int v) { g_ws_variant = v; }
 
 extern "C" void wm_debug_ws_direction(int reverse) { g_ws_reverse = reverse; }
@@ -597,7 +645,7 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void*
                            const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
                            hipStream_t s) {
     WsArgs a;
-    a.dbg = g_ws_variant == 3 ? 8 : 0; a.xcd_map = g_ws_variant != 2;
+    a.dbg = g_ws_variant == 3 ? 8 : (g_ws_variant == 8 ? 64 : 0); a.xcd_map = g_ws_variant != 2;
     a.x = (const bf16_t*)x; a.ldx = ldx; a.wp = (const bf16_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
     a.in_shift = in_shift; a.y = (bf16_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY; a.tiles_per_wg = tiles_per_wg;
