@@ -161,6 +161,14 @@ size_t wm_conv3x3_wgrad_ws_bytes(int B, int H, int W, int CinX, int CoutY);
 int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift,
                      const void* dy, int lddy, int CoutY, float* ws, float* dw, int accumulate, int B,
                      int H, int W, int Cin, int Cout, const int* perm_dev, int dtype, void* stream);
+/* The same with the BatchNorm-backward APPLY pass fused, for bf16 image-fed first layers (CinX <= 16) whose input needs
+ * no gradient: dy is formed from g (gradient wrt the ReLU output, stride ldg), y (the raw conv output, stride ldy),
+ * stats4 = f32[4][CoutY] = scale | shift | mean | invstd and coef = wm_bn_bwd_finalize's f32[3][CoutY] while the tile is
+ * staged, and never written to memory (no wm_bn_bwd_apply, no dy tensor). */
+int wm_conv3x3_wgrad_bnfused_supported(int CinX, int CoutY, int dtype);
+int wm_conv3x3_wgrad_bnfused(const void* x, int ldx, int CinX, const void* g, int ldg, const void* y, int ldy, int CoutY,
+                             const float* stats4, const float* coef, float* ws, float* dw, int accumulate, int B, int H, int W,
+                             int Cin, int Cout, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm2d (training)
  * replaces nn.BatchNorm2d + nn.ReLU of conv_bn_relu.py:12-14 / UNet.py:67-97.

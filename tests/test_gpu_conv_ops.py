@@ -401,3 +401,32 @@ def test_linear_head_kernels_match_torch(shape):
         torch.testing.assert_close(db, base_b + g.sum(0), rtol=1e-5, atol=1e-5)
         ref = torch.zeros(B, CP, device="cuda"); ref[:, :I] = (g @ w) / 64.0
         torch.testing.assert_close(gvec, ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", [(2, 40, 36), (1, 17, 50), (3, 64, 64)])
+def test_wgrad_with_fused_bn_backward_apply(case):
+    """wm_conv3x3_wgrad_bnfused (dy formed inside the weight-gradient kernel from g, y and the BatchNorm constants) is
+    bit-identical to wm_bn_bwd_apply followed by wm_conv3x3_wgrad: same arithmetic, same bf16 rounding of dy."""
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W = case
+    C = 64
+    x = nhwc(detgen.uniform((B, 3, H, W), 111), torch.bfloat16, 16)
+    y = nhwc(detgen.normal((B, C, H, W), 112), torch.bfloat16)
+    g = nhwc(detgen.normal((B, C, H, W), 113), torch.bfloat16)
+    gamma = detgen.normal((C,), 114, mean=1.0, std=0.3).cuda(); beta = detgen.normal((C,), 115, std=0.3).cuda()
+    yf = y.float()
+    mean = yf.mean((0, 1, 2)); invstd = torch.rsqrt(yf.var((0, 1, 2), unbiased=False) + 1e-5)
+    scale = gamma * invstd
+    stats = torch.stack([scale, beta - mean * scale, mean, invstd]).contiguous()
+    dg0 = torch.zeros(C, device="cuda"); db0 = torch.zeros(C, device="cuda")
+    dy = ops.bn_bwd(g, None, y, stats, C, gamma, dg0, db0, False, None)
+    dw0 = torch.zeros(C, 3, 3, 3, device="cuda")
+    ops.conv3x3_wgrad(x, 16, None, None, dy, dw0, False)
+    dg1 = torch.zeros(C, device="cuda"); db1 = torch.zeros(C, device="cuda")
+    coef = ops.bn_bwd_coef(g, None, y, stats, C, gamma, dg1, db1, False)
+    dw1 = torch.full((C, 3, 3, 3), 0.25, device="cuda")
+    ops.conv3x3_wgrad_bnfused(x, g, y, stats, coef, dw1, False)
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert torch.equal(dw0, dw1)
+    ops.conv3x3_wgrad_bnfused(x, g, y, stats, coef, dw1, True)      # accumulate
+    torch.testing.assert_close(dw1, 2 * dw0, rtol=1e-6, atol=1e-6 * dw0.abs().max().item())

@@ -26,7 +26,8 @@
 
 // wave-specialised bf16 kernel (wgrad_ws.hip)
 void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy,
-                        int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s);
+                        int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s, const void* yb = nullptr,
+                        int ldyb = 0, const float* bstats4 = nullptr, int bstats_ld = 0, const float* bcoef = nullptr);
 
 namespace {
 
@@ -330,6 +331,34 @@ extern "C" int wm_conv3x3_wgrad_nslabs(int B, int H, int W) { return nslabs_for(
 
 extern "C" size_t wm_conv3x3_wgrad_ws_bytes(int B, int H, int W, int CinX, int CoutY) {
     return (size_t)nslabs_for(B, H, W) * 9 * (wm_cdiv(CinX, CB) * CB) * (wm_cdiv(CoutY, CB) * CB) * sizeof(float);
+}
+
+// weight gradient with the BatchNorm-backward APPLY pass fused (bf16, image-fed first layers: CinX <= 16): the layer's dy is
+// never materialised -- it is formed from g (gradient wrt the ReLU output), y (raw conv output), the BatchNorm constants
+// stats4 = [scale | shift | mean | invstd] (4 rows of CP) and coef = wm_bn_bwd_finalize's [3][CP] while the tile is staged
+extern "C" int wm_conv3x3_wgrad_bnfused_supported(int CinX, int CoutY, int dtype) {
+    static const bool off = getenv("WM_NO_WGRAD_FUSE") != nullptr;
+    return (!off && dtype == WM_BF16 && CinX <= 16 && CoutY % 64 == 0) ? 1 : 0;
+}
+
+extern "C" int wm_conv3x3_wgrad_bnfused(const void* x, int ldx, int CinX, const void* g, int ldg, const void* y, int ldy, int CoutY,
+                                        const float* stats4, const float* coef, float* ws, float* dw, int accumulate, int B, int H,
+                                        int W, int Cin, int Cout, int dtype, void* stream) {
+    WM_REQUIRE(x && g && y && stats4 && coef && ws && dw, WM_E_BADARG, "wm_conv3x3_wgrad_bnfused: null pointer");
+    WM_REQUIRE(wm_conv3x3_wgrad_bnfused_supported(CinX, CoutY, dtype), WM_E_SHAPE, "wm_conv3x3_wgrad_bnfused: unsupported shape CinX=%d CoutY=%d dtype=%d", CinX, CoutY, dtype);
+    WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && CinX >= Cin && CoutY >= Cout && ldx >= CinX && ldg >= CoutY && ldy >= CoutY &&
+               ldx % 8 == 0 && ldg % 8 == 0 && ldy % 8 == 0, WM_E_SHAPE, "wm_conv3x3_wgrad_bnfused: bad shape / strides");
+    hipStream_t s = (hipStream_t)stream;
+    wm_launch_wgrad_ws(x, ldx, CinX, nullptr, nullptr, g, ldg, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, y, ldy, stats4, CoutY, coef);
+    WM_LAUNCH_CHECK("wm_conv3x3_wgrad_bnfused");
+    const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
+    const size_t slab_elems = (size_t)9 * CinP * CoutP;
+    const size_t rb = (slab_elems / 4 + RQUADS - 1) / RQUADS;
+    const int blocks = (int)(rb > 2048 ? 2048 : rb);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout,
+                       (const int*)nullptr, accumulate);
+    WM_LAUNCH_CHECK("wm_conv3x3_wgrad_bnfused(reduce)");
+    return WM_OK;
 }
 
 extern "C" int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift,

@@ -19,7 +19,9 @@ constexpr int D_BYTES = TH * TW * CB * 2;
 struct WsWgArgs {
     const bf16_t* x; int ldx; int CinX;
     const float* in_scale; const float* in_shift;
-    const bf16_t* dy; int lddy; int CoutY;
+    const bf16_t* dy; int lddy; int CoutY;   // DYF: the gradient wrt the layer's ReLU output (g), not dy
+    // DYF (fused BatchNorm-backward apply): the layer's raw conv output and its BatchNorm constants
+    const bf16_t* yb; int ldyb; const float* bscale; const float* bshift; const float* bmean; const float* binvstd; const float* bcoef;
     float* ws;           // [gridDim.x][9][CinP][CoutP]
     int B, H, W, tilesX, tilesY, ntiles, ciBlocks, coBlocks;
 };
@@ -44,7 +46,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
 __device__ __forceinline__ int swz16(int col) { return (((col >> 1) & 1) << 5) | (((col >> 3) & 1) << 6); }
 __device__ __forceinline__ int slot16(int col) { return col ^ (((col >> 3) & 1) << 2); }
 
-template <int CI, bool XFORM>
+// DYF: dy is not read but formed on the fly from (g, y) -- the apply pass of the BatchNorm backward, fused for layers whose dy
+// has no other consumer (no input gradient wanted): dy = ca * (g*[scale*y+shift > 0] - c1 - (y-mean)*invstd * c2), same
+// arithmetic and bf16 rounding as bn_bwd_kernel<APPLY>
+template <int CI, bool XFORM, bool DYF = false>
 __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
     static_assert(CI == 64 || CI == 16, "input-channel block");
     constexpr int VPX = CI / 8;                                   // 16-byte vectors per x pixel
@@ -94,11 +99,22 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
             dst = *reinterpret_cast<const bf16x8*>(a.x + ((size_t)(g.b * a.H + gyc) * a.W + gxc) * a.ldx + cxl);
             okbits |= ((cxok && gy == gyc && gx == gxc) ? 1u : 0u) << k;
         };
-        auto load_d = [&](const TileGeo& g, int k, bf16x8& dst, unsigned& okbits) {
+        float bsc[8], bsh[8], bmu[8], bis[8], bca[8], bc1[8], bc2[8];
+        if (DYF) {
+            const int CP = a.coBlocks * CB;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                bsc[e] = a.bscale[cdl + e]; bsh[e] = a.bshift[cdl + e]; bmu[e] = a.bmean[cdl + e]; bis[e] = a.binvstd[cdl + e];
+                bca[e] = a.bcoef[cdl + e]; bc1[e] = a.bcoef[CP + cdl + e]; bc2[e] = a.bcoef[2 * CP + cdl + e];
+            }
+        }
+        auto load_d = [&](const TileGeo& g, int k, bf16x8& dst, bf16x8& ydst, unsigned& okbits) {
             const int pix = (ptid + 256 * k) >> 3;
             const int gy = g.ty0 + (pix >> 4), gx = g.tx0 + (pix & 15);
             const int gyc = min(gy, a.H - 1), gxc = min(gx, a.W - 1);
-            dst = *reinterpret_cast<const bf16x8*>(a.dy + ((size_t)(g.b * a.H + gyc) * a.W + gxc) * a.lddy + cdl);
+            const size_t pofs = (size_t)(g.b * a.H + gyc) * a.W + gxc;
+            dst = *reinterpret_cast<const bf16x8*>(a.dy + pofs * a.lddy + cdl);
+            if (DYF) ydst = *reinterpret_cast<const bf16x8*>(a.yb + pofs * a.ldyb + cdl);
             okbits |= ((cdok && gy == gyc && gx == gxc) ? 1u : 0u) << k;
         };
         auto put_x = [&](unsigned char* base, int k, const bf16x8& src, bool ok) {
@@ -121,35 +137,54 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
             const int off = CI == 64 ? (py * HW + px) * 128 + ((vx * 16) ^ swz16(px)) : (py * HW + slot16(px)) * 32 + vx * 16;
             if (pix < NPIX) *reinterpret_cast<u32x4*>(base + off) = w;
         };
-        auto put_d = [&](unsigned char* base, int k, const bf16x8& src, bool ok) {
+        auto put_d = [&](unsigned char* base, int k, const bf16x8& src, const bf16x8& ysrc, bool ok) {
             const int pix = (ptid + 256 * k) >> 3;
             u32x4 w = __builtin_bit_cast(u32x4, src);
+            if (DYF) {
+                const u32x4 yw = __builtin_bit_cast(u32x4, ysrc);
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq) {
+                    float dd[2];
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        const int e = 2 * pq + hlf;
+                        const float gg = __builtin_bit_cast(float, hlf ? (w[pq] & 0xffff0000u) : (w[pq] << 16));
+                        const float yy = __builtin_bit_cast(float, hlf ? (yw[pq] & 0xffff0000u) : (yw[pq] << 16));
+                        const float z = bsc[e] * yy + bsh[e];
+                        const float gz = z > 0.f ? gg : 0.f;
+                        const float xh = (yy - bmu[e]) * bis[e];
+                        dd[hlf] = bca[e] * (gz - bc1[e] - xh * bc2[e]);
+                    }
+                    const bf16x2 pk = {(bf16_t)dd[0], (bf16_t)dd[1]};
+                    w[pq] = __builtin_bit_cast(unsigned, pk);
+                }
+            }
             const unsigned keep = ok ? 0xffffffffu : 0u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) w[q] &= keep;
             *reinterpret_cast<u32x4*>(base + XB + pix * 128 + ((vd * 16) ^ swz16(pix & 15))) = w;
         };
-        bf16x8 x0[XV], x1[XV], d0[DVP], d1[DVP];
+        bf16x8 x0[XV], x1[XV], d0[DVP], d1[DVP], y0[DVP], y1[DVP];
         unsigned okx0 = 0, okx1 = 0, okd0 = 0, okd1 = 0;
         if (t_begin < t_end) {
             const TileGeo g0 = geo(t_begin);
 #pragma unroll
             for (int k = 0; k < XV; ++k) load_x(g0, k, x0[k], okx0);
 #pragma unroll
-            for (int k = 0; k < DVP; ++k) load_d(g0, k, d0[k], okd0);
+            for (int k = 0; k < DVP; ++k) load_d(g0, k, d0[k], y0[k], okd0);
         }
         if (t_begin + 1 < t_end) {
             const TileGeo g1 = geo(t_begin + 1);
 #pragma unroll
             for (int k = 0; k < XV; ++k) load_x(g1, k, x1[k], okx1);
 #pragma unroll
-            for (int k = 0; k < DVP; ++k) load_d(g1, k, d1[k], okd1);
+            for (int k = 0; k < DVP; ++k) load_d(g1, k, d1[k], y1[k], okd1);
         }
         if (t_begin < t_end) {
 #pragma unroll
             for (int k = 0; k < XV; ++k) put_x(smem, k, x0[k], (okx0 >> k) & 1u);
 #pragma unroll
-            for (int k = 0; k < DVP; ++k) put_d(smem, k, d0[k], (okd0 >> k) & 1u);
+            for (int k = 0; k < DVP; ++k) put_d(smem, k, d0[k], y0[k], (okd0 >> k) & 1u);
         }
         __syncthreads();
         for (int tile = t_begin; tile < t_end; ++tile) {
@@ -157,20 +192,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
 #pragma unroll
             for (int k = 0; k < XV; ++k) x0[k] = x1[k];
 #pragma unroll
-            for (int k = 0; k < DVP; ++k) d0[k] = d1[k];
+            for (int k = 0; k < DVP; ++k) { d0[k] = d1[k]; if (DYF) y0[k] = y1[k]; }
             okx0 = okx1; okd0 = okd1; okx1 = 0; okd1 = 0;
             if (tile + 2 < t_end) {
                 const TileGeo g2 = geo(tile + 2);
 #pragma unroll
                 for (int k = 0; k < XV; ++k) load_x(g2, k, x1[k], okx1);
 #pragma unroll
-                for (int k = 0; k < DVP; ++k) load_d(g2, k, d1[k], okd1);
+                for (int k = 0; k < DVP; ++k) load_d(g2, k, d1[k], y1[k], okd1);
             }
             if (tile + 1 < t_end) {
 #pragma unroll
                 for (int k = 0; k < XV; ++k) put_x(nb, k, x0[k], (okx0 >> k) & 1u);
 #pragma unroll
-                for (int k = 0; k < DVP; ++k) put_d(nb, k, d0[k], (okd0 >> k) & 1u);
+                for (int k = 0; k < DVP; ++k) put_d(nb, k, d0[k], y0[k], (okd0 >> k) & 1u);
             }
             __syncthreads();
         }
@@ -260,18 +295,27 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
 }  // namespace
 
 void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy,
-                        int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s) {
+                        int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s, const void* yb = nullptr,
+                        int ldyb = 0, const float* bstats4 = nullptr, int bstats_ld = 0, const float* bcoef = nullptr) {
     WsWgArgs a;
     a.x = (const bf16_t*)x; a.ldx = ldx; a.CinX = CinX; a.in_scale = in_scale; a.in_shift = in_shift;
     a.dy = (const bf16_t*)dy; a.lddy = lddy; a.CoutY = CoutY; a.ws = ws; a.B = B; a.H = H; a.W = W;
+    a.yb = (const bf16_t*)yb; a.ldyb = ldyb;
+    a.bscale = bstats4; a.bshift = bstats4 ? bstats4 + bstats_ld : nullptr; a.bmean = bstats4 ? bstats4 + 2 * bstats_ld : nullptr;
+    a.binvstd = bstats4 ? bstats4 + 3 * bstats_ld : nullptr; a.bcoef = bcoef;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
     a.ciBlocks = wm_cdiv(CinX, CB); a.coBlocks = wm_cdiv(CoutY, CB);
     const dim3 block(512);
     if (CinX <= 16) {   // one 16-channel input block; the slab keeps its 64-row pitch (rows >= 16 are never read back)
         a.ciBlocks = 1;
         const dim3 grid((unsigned)nslabs, (unsigned)a.coBlocks);
-        if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<16, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((wgrad_ws16_kernel<16, false>), grid, block, 0, s, a);
+        if (yb) {       // fused BatchNorm-backward apply (image-fed first layers whose input needs no gradient)
+            if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<16, true, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((wgrad_ws16_kernel<16, false, true>), grid, block, 0, s, a);
+        } else {
+            if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<16, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((wgrad_ws16_kernel<16, false>), grid, block, 0, s, a);
+        }
     } else {
         const dim3 grid((unsigned)nslabs, (unsigned)(a.ciBlocks * a.coBlocks));
         if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<64, true>), grid, block, 0, s, a);

@@ -94,6 +94,13 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
     # removes the bias); the reference's autograd produces rounding noise of ~1e-9 there.  The bias gradient view is
     # zero-initialised and never written, which is the exact value and saves a reduction + two launches per layer.
     dbias = None
+    # An image-fed first layer whose input needs no gradient: dy has ONE consumer, the weight gradient -- its kernel forms dy
+    # from (g, y) while staging the tile, so the apply pass (a write and a read of dy) disappears.
+    if (not need_input_grad and g is not None and x.scale is None and perm_dev is None and ctx.stats.is_contiguous()
+            and g.shape[-1] == y.shape[-1] and ops.conv3x3_wgrad_bnfused_supported(x.t.shape[-1], y.shape[-1], dtype)):
+        coef = ops.bn_bwd_coef(g, None, y, ctx.stats, Cout, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate)
+        ops.conv3x3_wgrad_bnfused(x.t, g, y, ctx.stats, coef, grads[conv.weight], accumulate)
+        return None
     dy = ops.bn_bwd(g, gvec, y, ctx.stats, Cout, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate, dbias)
     ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, perm_dev=perm_dev)
     if not need_input_grad:

@@ -251,32 +251,65 @@ def bn_finalize(partials, C, CP, count, gamma, beta, running_mean, running_var, 
     return out
 
 
-def bn_bwd(g, gvec, y, stats, C, gamma, dgamma, dbeta, accumulate, dbias):
-    """ReLU+BN backward.  g [B,H,W,ld] or None with gvec [B,CP]; y raw conv output [B,H,W,CP];
-    stats = [4,CP] (scale, shift, mean, invstd).  Returns dy [B,H,W,CP]; writes dgamma/dbeta/dbias."""
+def bn_bwd_coef(g, gvec, y, stats, C, gamma, dgamma, dbeta, accumulate):
+    """first half of the ReLU+BN backward: the reduce pass + finalisation.  Writes dgamma / dbeta, returns coef [3,CP]
+    (gamma*invstd, mean(gz), mean(gz*xhat)) for the apply pass."""
     B, H, W, CP = y.shape
     hw = H * W
     L = _lib.lib()
     nparts = L.wm_bn_bwd_nparts(c_size_t(B * hw))
     dev = y.device
     part = torch.empty(nparts, 2, CP, device=dev, dtype=torch.float32)
-    did = c_int(dtype_id(y))
     ldg = c_int(0 if g is None else g.shape[-1])
     rc = L.wm_bn_bwd_reduce(_p(g), ldg, _p(gvec), _p(y), c_int(CP), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
-                            _p(part), c_int(B), c_size_t(hw), c_int(CP), did, _stream())
+                            _p(part), c_int(B), c_size_t(hw), c_int(CP), c_int(dtype_id(y)), _stream())
     _lib.check(rc, "wm_bn_bwd_reduce")
     coef = torch.empty(3, CP, device=dev, dtype=torch.float32)
     rc = L.wm_bn_bwd_finalize(_p(part), c_int(nparts), c_int(C), c_int(CP), c_double(B * hw), _p(gamma), _p(stats[3]),
                               _p(dgamma), _p(dbeta), c_int(1 if accumulate else 0), _p(coef), _stream())
     _lib.check(rc, "wm_bn_bwd_finalize")
+    return coef
+
+
+def bn_bwd(g, gvec, y, stats, C, gamma, dgamma, dbeta, accumulate, dbias):
+    """ReLU+BN backward.  g [B,H,W,ld] or None with gvec [B,CP]; y raw conv output [B,H,W,CP];
+    stats = [4,CP] (scale, shift, mean, invstd).  Returns dy [B,H,W,CP]; writes dgamma/dbeta/dbias."""
+    B, H, W, CP = y.shape
+    hw = H * W
+    L = _lib.lib()
+    dev = y.device
+    coef = bn_bwd_coef(g, gvec, y, stats, C, gamma, dgamma, dbeta, accumulate)
+    nparts = L.wm_bn_bwd_nparts(c_size_t(B * hw))
+    ldg = c_int(0 if g is None else g.shape[-1])
     dy = torch.empty_like(y)
     bpart = torch.empty(nparts, CP, device=dev, dtype=torch.float32) if dbias is not None else None
     rc = L.wm_bn_bwd_apply(_p(g), ldg, _p(gvec), _p(y), c_int(CP), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
-                           _p(coef), _p(dy), c_int(CP), _p(bpart), c_int(B), c_size_t(hw), c_int(CP), did, _stream())
+                           _p(coef), _p(dy), c_int(CP), _p(bpart), c_int(B), c_size_t(hw), c_int(CP), c_int(dtype_id(y)), _stream())
     _lib.check(rc, "wm_bn_bwd_apply")
     if dbias is not None:
         colsum(bpart, dbias.numel(), CP, dbias, accumulate)
     return dy
+
+
+def conv3x3_wgrad_bnfused_supported(CinX, CoutY, dtype):
+    return bool(_lib.lib().wm_conv3x3_wgrad_bnfused_supported(c_int(CinX), c_int(CoutY), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32)))
+
+
+def conv3x3_wgrad_bnfused(x, g, y, stats, coef, dw, accumulate):
+    """weight gradient of an image-fed first layer with the BatchNorm-backward apply pass fused: dy is formed from
+    (g, y, stats [4,CP] contiguous, coef [3,CP]) while the tile is staged and never written to memory."""
+    B, H, W, ldx = x.shape
+    CoutY = y.shape[-1]
+    L = _lib.lib()
+    L.wm_conv3x3_wgrad_ws_bytes.restype = c_size_t
+    nbytes = L.wm_conv3x3_wgrad_ws_bytes(c_int(B), c_int(H), c_int(W), c_int(ldx), c_int(CoutY))
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    Cout, Cin = dw.shape[0], dw.shape[1]
+    assert dw.is_contiguous() and stats.is_contiguous() and coef.is_contiguous()
+    rc = L.wm_conv3x3_wgrad_bnfused(_p(x), c_int(ldx), c_int(ldx), _p(g), c_int(g.shape[-1]), _p(y), c_int(CoutY), c_int(CoutY),
+                                    _p(stats), _p(coef), _p(ws), _p(dw), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W),
+                                    c_int(Cin), c_int(Cout), c_int(dtype_id(x)), _stream())
+    _lib.check(rc, "wm_conv3x3_wgrad_bnfused")
 
 
 def linear_head_fwd(pooled, w, bias, I):
