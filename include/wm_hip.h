@@ -169,6 +169,17 @@ int wm_conv3x3_wgrad_bnfused_supported(int CinX, int CoutY, int dtype);
 int wm_conv3x3_wgrad_bnfused(const void* x, int ldx, int CinX, const void* g, int ldg, const void* y, int ldy, int CoutY,
                              const float* stats4, const float* coef, float* ws, float* dw, int accumulate, int B, int H, int W,
                              int Cin, int Cout, int dtype, void* stream);
+/* The pair for a ConvBNRelu whose output was globally pooled (hidden_models/decoder.py:16-24, discriminator.py:14-22:
+ * the gradient wrt its ReLU output is one row per sample, gvec f32[B][CoutY], already divided by H*W).  Both kernels
+ * read the layer's raw conv output y instead of dy and apply the BatchNorm backward while staging (bf16, CinX = 64,
+ * CoutY in {64, 32}); results are bit-identical to wm_bn_bwd_apply followed by wm_conv3x3_wgrad / wm_conv3x3_fwd.
+ * wpt: the transposed packed filter (wm_pack_w3x3 with transpose = 1), dx: [B,H,W,CinP] dense. */
+int wm_conv3x3_gvfused_supported(int CinX, int CoutY, int dtype);
+int wm_conv3x3_wgrad_gvfused(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const float* gvec,
+                             const void* y, int ldy, int CoutY, const float* stats4, const float* coef, float* ws, float* dw,
+                             int accumulate, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
+int wm_conv3x3_dgrad_gvfused(const void* y, int ldy, int CoutY, const void* wpt, const float* gvec, const float* stats4,
+                             const float* coef, void* dx, int B, int H, int W, int CinP, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm2d (training)
  * replaces nn.BatchNorm2d + nn.ReLU of conv_bn_relu.py:12-14 / UNet.py:67-97.

@@ -30,7 +30,8 @@ int wm_launch_conv3x3_stream(const void* x, int ldx, const void* wp, const float
 // persistent wave-specialised kernel for bf16 Cin in {64,32,16}, Cout in {64,32} (conv3x3_ws.hip)
 int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void* wp, const float* bias, int nbias, const float* in_scale,
                          const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
-                         hipStream_t s);
+                         hipStream_t s, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
+                         const float* bw_gvec = nullptr);
 
 namespace {
 
@@ -380,6 +381,24 @@ extern "C" int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const floa
     if (dtype == WM_BF16) launch_conv<bf16_t>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s);
     else launch_conv<float>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s);
     WM_LAUNCH_CHECK("wm_conv3x3_fwd");
+    return WM_OK;
+}
+
+// input gradient of a ConvBNRelu whose output was globally pooled, with the BatchNorm-backward apply pass fused: the
+// kernel reads the layer's raw conv output y and forms dy from (gvec[b], y, stats4, coef) while staging each tile
+extern "C" int wm_conv3x3_dgrad_gvfused(const void* y, int ldy, int CoutY, const void* wpt, const float* gvec, const float* stats4,
+                                        const float* coef, void* dx, int B, int H, int W, int CinP, int dtype, void* stream) {
+    WM_REQUIRE(y && wpt && gvec && stats4 && coef && dx, WM_E_BADARG, "wm_conv3x3_dgrad_gvfused: null pointer");
+    WM_REQUIRE(B > 0 && H > 0 && W > 0, WM_E_BADARG, "wm_conv3x3_dgrad_gvfused: bad shape");
+    WM_REQUIRE(dtype == WM_BF16 && (CoutY == 64 || CoutY == 32) && CinP == 64 && use_ws(CoutY, CinP, dtype), WM_E_SHAPE,
+               "wm_conv3x3_dgrad_gvfused: unsupported shape CoutY=%d CinP=%d dtype=%d", CoutY, CinP, dtype);
+    WM_REQUIRE(ldy >= CoutY && ldy % 8 == 0 && (((uintptr_t)y | (uintptr_t)wpt | (uintptr_t)dx) & 15) == 0, WM_E_SHAPE,
+               "wm_conv3x3_dgrad_gvfused: bad stride / alignment");
+    const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
+    const int rc = wm_launch_conv3x3_ws(y, ldy, CoutY, CinP, wpt, nullptr, 0, nullptr, nullptr, dx, nullptr, B, H, W, ws_wgs(ntiles),
+                                        ws_tiles_per_wg(ntiles), (hipStream_t)stream, stats4, CoutY, coef, gvec);
+    WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_dgrad_gvfused: no kernel for this shape");
+    WM_LAUNCH_CHECK("wm_conv3x3_dgrad_gvfused");
     return WM_OK;
 }
 

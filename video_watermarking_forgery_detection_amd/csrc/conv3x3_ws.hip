@@ -35,6 +35,7 @@ struct WsArgs {
     int B, H, W, tilesX, tilesY, ntiles, tiles_per_wg;
     int dbg;      // STAMPS build only: 1 = skip the MFMA loop, 2 = skip the stores, 4 = skip the halo loads
     int xcd_map;
+    const float* bw_stats4; int bw_ld; const float* bw_coef; const float* bw_gvec;   // BNBWD: [scale|shift|mean|invstd][bw_ld], coef [3][bw_ld], gvec [B][bw_ld]
     int reverse;  // walk the workgroup's run of tiles backwards (Infinity Cache reuse of the previous kernel's tail)
 };
 
@@ -55,7 +56,10 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 // STAMPS: diagnostic build only (tools/phase_ws.py) -- per-role cycle totals of the phases of the tile loop
 // M16: consumers use v_mfma_f32_16x16x32_bf16 (needs CIN % 32 == 0) instead of 32x32x16: same FLOPs per cycle, but the
 // chip holds a higher clock on it under load (MI355X_MICROARCH.md, DVFS give-back item 7); A/B: tools/ab_step.py
-template <int CIN, int COUT, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false>
+// BNBWD (dgrad of a layer whose output was globally pooled): the input tensor is that layer's raw conv output y, and the
+// producers turn it into dy = ca * (gvec[b]*[scale*y+shift > 0] - c1 - (y-mean)*invstd * c2) while staging -- the
+// BatchNorm-backward APPLY pass, fused (the folded form of wm_common.h: bit-identical to bn_bwd_kernel<bf16, APPLY, GVEC>)
+template <int CIN, int COUT, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false, bool BNBWD = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned long long* __restrict__ stamps = nullptr) {
     static_assert(CIN == 64 || CIN == 32 || CIN == 16, "input channels");
     static_assert(!M16 || CIN % 32 == 0, "the 16x16x32 MFMA consumes 32 input channels per step");
@@ -151,6 +155,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 sh2[e] = f32x2{a.in_shift[vec * 8 + 2 * e], a.in_shift[vec * 8 + 2 * e + 1]};
             }
         }
+        static_assert(!(BNBWD && XFORM), "one input transform at a time");
+        float kb[4][8], k3g[8];   // BNBWD: scale, shift, k2, k3 of this thread's 8 channels (wm_bn_fold); k3g = k3 + ca*gvec[sample being published]
+        int gvb = -1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) k3g[e] = 0.f;
+        if (BNBWD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = vec * 8 + e;
+                kb[0][e] = a.bw_stats4[c]; kb[1][e] = a.bw_stats4[a.bw_ld + c];
+                wm_bn_fold(a.bw_stats4[2 * a.bw_ld + c], a.bw_stats4[3 * a.bw_ld + c], a.bw_coef[c], a.bw_coef[a.bw_ld + c],
+                           a.bw_coef[2 * a.bw_ld + c], kb[2][e], kb[3][e]);
+            }
+        }
+        auto load_gvec = [&](int b) {   // wave-uniform: a run of tiles rarely crosses a sample
+            if (BNBWD && b != gvb) {
+                gvb = b;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) k3g[e] = wm_bn_fold_g(a.bw_coef[vec * 8 + e], a.bw_gvec[(size_t)b * a.bw_ld + vec * 8 + e], kb[3][e]);
+            }
+        };
         // tile-invariant per-vector geometry: halo pixel (py, px), its offset inside an interior tile, its LDS slot
         // EDGE (CIN = 64): the vector slots are ordered so that k < KMAIN covers halo columns 2..17 (18 x 16 pixels x 8 vectors
         // = 9 x 256 exactly) and k >= KMAIN the columns 0..1, which a tile shares with its left neighbour: when the previous
@@ -231,6 +256,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                     w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
                 }
             }
+            if (BNBWD) {
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq) {
+                    const float d0 = wm_bn_fold_dy(__builtin_bit_cast(float, w[pq] << 16), kb[0][2 * pq], kb[1][2 * pq], kb[2][2 * pq], kb[3][2 * pq], k3g[2 * pq]);
+                    const float d1 = wm_bn_fold_dy(__builtin_bit_cast(float, w[pq] & 0xffff0000u), kb[0][2 * pq + 1], kb[1][2 * pq + 1], kb[2][2 * pq + 1],
+                                                   kb[3][2 * pq + 1], k3g[2 * pq + 1]);
+                    const bf16x2 pk = {(bf16_t)d0, (bf16_t)d1};
+                    w[pq] = __builtin_bit_cast(unsigned, pk);
+                }
+            }
             const unsigned keep = 0u - ((okbits >> k) & 1u);
 #pragma unroll
             for (int q = 0; q < 4; ++q) w[q] &= keep;
@@ -241,6 +276,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         if (t_begin < t_end) load_tile(geo(t_begin), dA, okA, false);
         if (t_begin + 1 < t_end) load_tile(geo(t_begin + 1), dB, okB, reuse_of(t_begin + 1));
         if (t_begin < t_end) {
+            load_gvec(geo(t_begin).b);
 #pragma unroll
             for (int k = 0; k < XVP; ++k) put_one(sX0, k, dA[k], okA);
         }
@@ -254,6 +290,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             const bf16_t* sXc = sX0 + ((tile - t_begin) & 1) * (NPIX * CIN);   // the tile the consumers are on: left neighbour of tile+1
             const bool have_next = tile + 2 < t_end && !(STAMPS && (a.dbg & 4));
             const bool reuse_cur = reuse_of(tile + 1), reuse_nxt = reuse_of(tile + 2);
+            if (BNBWD && tile + 1 < t_end) load_gvec(geo(tile + 1).b);
             if (have_next) {
                 const TileGeo g2 = geo(tile + 2);
                 if (is_interior(g2)) {
@@ -627,7 +664,7 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
     a.in_shift = in_shift; a.y = (bf16_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
     const int wgs = a.ntiles < 256 ? a.ntiles : 256;
-    a.tiles_per_wg = wm_cdiv(a.ntiles, wgs); a.reverse = 0;
+    a.tiles_per_wg = wm_cdiv(a.ntiles, wgs); a.reverse = 0; a.bw_stats4 = nullptr; a.bw_ld = 0; a.bw_coef = nullptr; a.bw_gvec = nullptr;
     const dim3 grid((unsigned)wm_cdiv(a.ntiles, a.tiles_per_wg)), block(512);
     if (in_scale && stat) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, true, true, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
     else hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
@@ -643,14 +680,22 @@ extern "C" void wm_debug_ws_direction(int reverse) { g_ws_reverse = reverse; }
 // launcher used by conv3x3.hip
 int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void* wp, const float* bias, int nbias, const float* in_scale,
                            const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
-                           hipStream_t s) {
+                           hipStream_t s, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
+                           const float* bw_gvec = nullptr) {
     WsArgs a;
     a.dbg = g_ws_variant == 3 ? 8 : (g_ws_variant == 8 ? 64 : 0); a.xcd_map = g_ws_variant != 2;
     a.x = (const bf16_t*)x; a.ldx = ldx; a.wp = (const bf16_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
     a.in_shift = in_shift; a.y = (bf16_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY; a.tiles_per_wg = tiles_per_wg;
     a.reverse = g_ws_reverse;
+    a.bw_stats4 = bw_stats4; a.bw_ld = bw_ld; a.bw_coef = bw_coef; a.bw_gvec = bw_gvec;
     const dim3 grid((unsigned)wgs), block(512);
+    if (bw_stats4) {   // dgrad with the BatchNorm-backward apply (per-sample gradient rows) fused: 64 or 32 -> 64
+        if ((Cin != 64 && Cin != 32) || CoutP != 64 || in_scale || stat) return WM_E_SHAPE;
+        if (Cin == 64) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, true>), grid, block, 0, s, a, nullptr);
+        else hipLaunchKernelGGL((conv3x3_ws_kernel<32, 64, false, false, true, false, true>), grid, block, 0, s, a, nullptr);
+        return WM_OK;
+    }
     const bool xf = in_scale != nullptr, st = stat != nullptr;
 #define WM_WS_LAUNCH2(CIN_, COUT_, M16_)                                                                                     \
     do {                                                                                                                     \

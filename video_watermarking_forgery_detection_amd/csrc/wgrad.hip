@@ -27,7 +27,8 @@
 // wave-specialised bf16 kernel (wgrad_ws.hip)
 void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy,
                         int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s, const void* yb = nullptr,
-                        int ldyb = 0, const float* bstats4 = nullptr, int bstats_ld = 0, const float* bcoef = nullptr);
+                        int ldyb = 0, const float* bstats4 = nullptr, int bstats_ld = 0, const float* bcoef = nullptr,
+                        const float* gvec = nullptr);
 
 namespace {
 
@@ -358,6 +359,33 @@ extern "C" int wm_conv3x3_wgrad_bnfused(const void* x, int ldx, int CinX, const 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout,
                        (const int*)nullptr, accumulate);
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad_bnfused(reduce)");
+    return WM_OK;
+}
+
+static int g_gv_fuse = getenv("WM_NO_GV_FUSE") ? 0 : 1;
+extern "C" void wm_debug_gv_fuse(int on) { g_gv_fuse = on; }   // A/B knob (tools/ab_step.py)
+
+extern "C" int wm_conv3x3_gvfused_supported(int CinX, int CoutY, int dtype) {
+    return (g_gv_fuse && dtype == WM_BF16 && CinX == 64 && (CoutY == 64 || CoutY == 32)) ? 1 : 0;
+}
+
+extern "C" int wm_conv3x3_wgrad_gvfused(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const float* gvec,
+                                        const void* y, int ldy, int CoutY, const float* stats4, const float* coef, float* ws, float* dw,
+                                        int accumulate, int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    WM_REQUIRE(x && in_scale && in_shift && gvec && y && stats4 && coef && ws && dw, WM_E_BADARG, "wm_conv3x3_wgrad_gvfused: null pointer");
+    WM_REQUIRE(wm_conv3x3_gvfused_supported(CinX, CoutY, dtype), WM_E_SHAPE, "wm_conv3x3_wgrad_gvfused: unsupported shape CinX=%d CoutY=%d dtype=%d", CinX, CoutY, dtype);
+    WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && CinX >= Cin && CoutY >= Cout && ldx >= CinX && ldy >= CoutY &&
+               ldx % 8 == 0 && ldy % 8 == 0, WM_E_SHAPE, "wm_conv3x3_wgrad_gvfused: bad shape / strides");
+    hipStream_t s = (hipStream_t)stream;
+    wm_launch_wgrad_ws(x, ldx, CinX, in_scale, in_shift, nullptr, 0, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, y, ldy, stats4, CoutY, coef, gvec);
+    WM_LAUNCH_CHECK("wm_conv3x3_wgrad_gvfused");
+    const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
+    const size_t slab_elems = (size_t)9 * CinP * CoutP;
+    const size_t rb = (slab_elems / 4 + RQUADS - 1) / RQUADS;
+    const int blocks = (int)(rb > 2048 ? 2048 : rb);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout,
+                       (const int*)nullptr, accumulate);
+    WM_LAUNCH_CHECK("wm_conv3x3_wgrad_gvfused(reduce)");
     return WM_OK;
 }
 

@@ -22,6 +22,7 @@ struct WsWgArgs {
     const bf16_t* dy; int lddy; int CoutY;   // DYF: the gradient wrt the layer's ReLU output (g), not dy
     // DYF (fused BatchNorm-backward apply): the layer's raw conv output and its BatchNorm constants
     const bf16_t* yb; int ldyb; const float* bscale; const float* bshift; const float* bmean; const float* binvstd; const float* bcoef;
+    const float* gvec; int ldgv;   // DYF == 2: g is one row per sample (the layer's output was globally pooled); dy/lddy unused
     float* ws;           // [gridDim.x][9][CinP][CoutP]
     int B, H, W, tilesX, tilesY, ntiles, ciBlocks, coBlocks;
 };
@@ -49,17 +50,32 @@ __device__ __forceinline__ int slot16(int col) { return col ^ (((col >> 3) & 1) 
 // DYF: dy is not read but formed on the fly from (g, y) -- the apply pass of the BatchNorm backward, fused for layers whose dy
 // has no other consumer (no input gradient wanted): dy = ca * (g*[scale*y+shift > 0] - c1 - (y-mean)*invstd * c2), same
 // arithmetic and bf16 rounding as bn_bwd_kernel<APPLY>
-template <int CI, bool XFORM, bool DYF = false>
+// DYF == 2: the same with g[b, pixel, c] = gvec[b][c] (a globally pooled layer): the producers read y only
+template <int CI, bool XFORM, int DYF = 0>
 __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
     static_assert(CI == 64 || CI == 16, "input-channel block");
     constexpr int VPX = CI / 8;                                   // 16-byte vectors per x pixel
     constexpr int XV = (NPIX * VPX + 255) / 256;                  // x halo vectors per producer thread
     constexpr int XB = NPIX * CI * 2;                             // x halo tile bytes
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (XB + D_BYTES)];
+    __shared__ __attribute__((aligned(16))) float sK[DYF == 2 ? CB * 8 : 8];   // DYF == 2: scale, shift, k2, k3, ca of each of the block's 64 channels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
     const int cc = blockIdx.y / a.coBlocks, oc = blockIdx.y % a.coBlocks;
     const int ci0 = cc * CI, co0 = oc * CB;
+    if (DYF == 2) {   // (the producers have no registers to spare for the constants: they fetch them channel by channel while transforming)
+        if (tid < CB) {
+            const int c = co0 + tid;
+            const bool okc = c < a.CoutY;
+            const int cl = okc ? c : 0;
+            float k2, k3;
+            wm_bn_fold(a.bmean[cl], a.binvstd[cl], a.bcoef[cl], a.bcoef[a.ldgv + cl], a.bcoef[2 * a.ldgv + cl], k2, k3);
+            const float v[8] = {a.bscale[cl], a.bshift[cl], k2, k3, a.bcoef[cl], 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sK[tid * 8 + i] = okc ? v[i] : 0.f;
+        }
+        __syncthreads();
+    }
     const int G = gridDim.x;
     const int run = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const int t_begin = (int)(((long)run * a.ntiles) / G);
@@ -100,8 +116,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
             okbits |= ((cxok && gy == gyc && gx == gxc) ? 1u : 0u) << k;
         };
         float bsc[8], bsh[8], bmu[8], bis[8], bca[8], bc1[8], bc2[8];
-        if (DYF) {
-            const int CP = a.coBlocks * CB;
+        if (DYF == 1) {
+            const int CP = a.ldgv;   // row pitch of the constants (= the layer's physical channel count)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 bsc[e] = a.bscale[cdl + e]; bsh[e] = a.bshift[cdl + e]; bmu[e] = a.bmean[cdl + e]; bis[e] = a.binvstd[cdl + e];
@@ -113,8 +129,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
             const int gy = g.ty0 + (pix >> 4), gx = g.tx0 + (pix & 15);
             const int gyc = min(gy, a.H - 1), gxc = min(gx, a.W - 1);
             const size_t pofs = (size_t)(g.b * a.H + gyc) * a.W + gxc;
-            dst = *reinterpret_cast<const bf16x8*>(a.dy + pofs * a.lddy + cdl);
-            if (DYF) ydst = *reinterpret_cast<const bf16x8*>(a.yb + pofs * a.ldyb + cdl);
+            if (DYF == 2) dst = *reinterpret_cast<const bf16x8*>(a.yb + pofs * a.ldyb + cdl);
+            else dst = *reinterpret_cast<const bf16x8*>(a.dy + pofs * a.lddy + cdl);
+            if (DYF == 1) ydst = *reinterpret_cast<const bf16x8*>(a.yb + pofs * a.ldyb + cdl);
             okbits |= ((cdok && gy == gyc && gx == gxc) ? 1u : 0u) << k;
         };
         auto put_x = [&](unsigned char* base, int k, const bf16x8& src, bool ok) {
@@ -140,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
         auto put_d = [&](unsigned char* base, int k, const bf16x8& src, const bf16x8& ysrc, bool ok) {
             const int pix = (ptid + 256 * k) >> 3;
             u32x4 w = __builtin_bit_cast(u32x4, src);
-            if (DYF) {
+            if (DYF == 1) {
                 const u32x4 yw = __builtin_bit_cast(u32x4, ysrc);
 #pragma unroll
                 for (int pq = 0; pq < 4; ++pq) {
@@ -164,6 +181,27 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
             for (int q = 0; q < 4; ++q) w[q] &= keep;
             *reinterpret_cast<u32x4*>(base + XB + pix * 128 + ((vd * 16) ^ swz16(pix & 15))) = w;
         };
+        // DYF == 2: the 8 staged y vectors of a tile -> dy, in place, one channel at a time (its constants come from the LDS,
+        // its gradient from the sample's gvec row: 8 registers live instead of 64)
+        auto gv_apply = [&](bf16x8 (&d)[DVP], int b) {
+            if (DYF != 2) return;
+            const float* gv = a.gvec + (size_t)b * a.ldgv + cdl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int pq = e >> 1, hlf = e & 1;
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(sK + (vd * 8 + e) * 8);   // scale, shift, k2, k3 (wm_bn_fold)
+                const float k3g = wm_bn_fold_g(sK[(vd * 8 + e) * 8 + 4], gv[e], ka[3]);
+#pragma unroll
+                for (int k = 0; k < DVP; ++k) {
+                    u32x4 w = __builtin_bit_cast(u32x4, d[k]);
+                    const float yy = __builtin_bit_cast(float, hlf ? (w[pq] & 0xffff0000u) : (w[pq] << 16));
+                    const float dd = wm_bn_fold_dy(yy, ka[0], ka[1], ka[2], ka[3], k3g);
+                    const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)dd);
+                    w[pq] = hlf ? ((w[pq] & 0xffffu) | (bits << 16)) : ((w[pq] & 0xffff0000u) | bits);
+                    d[k] = __builtin_bit_cast(bf16x8, w);
+                }
+            }
+        };
         bf16x8 x0[XV], x1[XV], d0[DVP], d1[DVP], y0[DVP], y1[DVP];
         unsigned okx0 = 0, okx1 = 0, okd0 = 0, okd1 = 0;
         if (t_begin < t_end) {
@@ -181,6 +219,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
             for (int k = 0; k < DVP; ++k) load_d(g1, k, d1[k], y1[k], okd1);
         }
         if (t_begin < t_end) {
+            gv_apply(d0, geo(t_begin).b);
 #pragma unroll
             for (int k = 0; k < XV; ++k) put_x(smem, k, x0[k], (okx0 >> k) & 1u);
 #pragma unroll
@@ -192,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
 #pragma unroll
             for (int k = 0; k < XV; ++k) x0[k] = x1[k];
 #pragma unroll
-            for (int k = 0; k < DVP; ++k) { d0[k] = d1[k]; if (DYF) y0[k] = y1[k]; }
+            for (int k = 0; k < DVP; ++k) { d0[k] = d1[k]; if (DYF == 1) y0[k] = y1[k]; }
             okx0 = okx1; okd0 = okd1; okx1 = 0; okd1 = 0;
             if (tile + 2 < t_end) {
                 const TileGeo g2 = geo(tile + 2);
@@ -204,6 +243,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
             if (tile + 1 < t_end) {
 #pragma unroll
                 for (int k = 0; k < XV; ++k) put_x(nb, k, x0[k], (okx0 >> k) & 1u);
+                gv_apply(d0, geo(tile + 1).b);
 #pragma unroll
                 for (int k = 0; k < DVP; ++k) put_d(nb, k, d0[k], y0[k], (okd0 >> k) & 1u);
             }
@@ -296,13 +336,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
 
 void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy,
                         int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s, const void* yb = nullptr,
-                        int ldyb = 0, const float* bstats4 = nullptr, int bstats_ld = 0, const float* bcoef = nullptr) {
+                        int ldyb = 0, const float* bstats4 = nullptr, int bstats_ld = 0, const float* bcoef = nullptr,
+                        const float* gvec = nullptr) {
     WsWgArgs a;
     a.x = (const bf16_t*)x; a.ldx = ldx; a.CinX = CinX; a.in_scale = in_scale; a.in_shift = in_shift;
     a.dy = (const bf16_t*)dy; a.lddy = lddy; a.CoutY = CoutY; a.ws = ws; a.B = B; a.H = H; a.W = W;
     a.yb = (const bf16_t*)yb; a.ldyb = ldyb;
     a.bscale = bstats4; a.bshift = bstats4 ? bstats4 + bstats_ld : nullptr; a.bmean = bstats4 ? bstats4 + 2 * bstats_ld : nullptr;
-    a.binvstd = bstats4 ? bstats4 + 3 * bstats_ld : nullptr; a.bcoef = bcoef;
+    a.binvstd = bstats4 ? bstats4 + 3 * bstats_ld : nullptr; a.bcoef = bcoef; a.gvec = gvec; a.ldgv = bstats_ld;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
     a.ciBlocks = wm_cdiv(CinX, CB); a.coBlocks = wm_cdiv(CoutY, CB);
     const dim3 block(512);
@@ -310,15 +351,17 @@ void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale,
         a.ciBlocks = 1;
         const dim3 grid((unsigned)nslabs, (unsigned)a.coBlocks);
         if (yb) {       // fused BatchNorm-backward apply (image-fed first layers whose input needs no gradient)
-            if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<16, true, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((wgrad_ws16_kernel<16, false, true>), grid, block, 0, s, a);
+            if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<16, true, 1>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((wgrad_ws16_kernel<16, false, 1>), grid, block, 0, s, a);
         } else {
             if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<16, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((wgrad_ws16_kernel<16, false>), grid, block, 0, s, a);
         }
     } else {
         const dim3 grid((unsigned)nslabs, (unsigned)(a.ciBlocks * a.coBlocks));
-        if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<64, true>), grid, block, 0, s, a);
+        if (gvec) {     // fused BatchNorm-backward apply of a globally pooled layer (its input is always an activated tensor)
+            hipLaunchKernelGGL((wgrad_ws16_kernel<64, true, 2>), grid, block, 0, s, a);
+        } else if (in_scale) hipLaunchKernelGGL((wgrad_ws16_kernel<64, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((wgrad_ws16_kernel<64, false>), grid, block, 0, s, a);
     }
 }

@@ -101,11 +101,19 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
         coef = ops.bn_bwd_coef(g, None, y, ctx.stats, Cout, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate)
         ops.conv3x3_wgrad_bnfused(x.t, g, y, ctx.stats, coef, grads[conv.weight], accumulate)
         return None
+    # A globally pooled layer (the gradient wrt its ReLU output is one row per sample): both consumers of dy -- the weight
+    # gradient and the input gradient -- form it from (gvec, y) while staging their tiles; no apply pass, no dy tensor.
+    rows = dgrad_channels or round_up(x.t.shape[-1], 32)
+    if (gvec is not None and need_input_grad and x.scale is not None and perm_dev is None and ctx.perm is None and rows == 64
+            and x.t.shape[-1] == 64 and ctx.stats.is_contiguous() and ops.conv3x3_gvfused_supported(64, y.shape[-1], dtype)):
+        coef = ops.bn_bwd_coef(None, gvec, y, ctx.stats, Cout, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate)
+        ops.conv3x3_wgrad_gvfused(x.t, x.scale, x.shift, gvec, y, ctx.stats, coef, grads[conv.weight], accumulate)
+        wpt = _packed(conv, y.shape[-1], rows, dtype, None, True)
+        return ops.conv3x3_dgrad_gvfused(y, wpt, gvec, ctx.stats, coef)
     dy = ops.bn_bwd(g, gvec, y, ctx.stats, Cout, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate, dbias)
     ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, perm_dev=perm_dev)
     if not need_input_grad:
         return None
-    rows = dgrad_channels or round_up(x.t.shape[-1], 32)
     wpt = _packed(conv, y.shape[-1], rows, dtype, ctx.perm, True)
     gx, _ = ops.conv3x3_fwd(dy, wpt, None, None, None, want_stats=False)
     return gx

@@ -312,6 +312,39 @@ def conv3x3_wgrad_bnfused(x, g, y, stats, coef, dw, accumulate):
     _lib.check(rc, "wm_conv3x3_wgrad_bnfused")
 
 
+def conv3x3_gvfused_supported(CinX, CoutY, dtype):
+    return bool(_lib.lib().wm_conv3x3_gvfused_supported(c_int(CinX), c_int(CoutY), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32)))
+
+
+def conv3x3_wgrad_gvfused(x, in_scale, in_shift, gvec, y, stats, coef, dw, accumulate):
+    """weight gradient of a globally pooled ConvBNRelu with the BatchNorm-backward apply pass fused: dy is formed from
+    (gvec [B,CP], y, stats [4,CP] contiguous, coef [3,CP]) while the tile is staged."""
+    B, H, W, ldx = x.shape
+    CoutY = y.shape[-1]
+    L = _lib.lib()
+    L.wm_conv3x3_wgrad_ws_bytes.restype = c_size_t
+    nbytes = L.wm_conv3x3_wgrad_ws_bytes(c_int(B), c_int(H), c_int(W), c_int(ldx), c_int(CoutY))
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    Cout, Cin = dw.shape[0], dw.shape[1]
+    assert dw.is_contiguous() and stats.is_contiguous() and coef.is_contiguous() and gvec.is_contiguous() and gvec.shape[-1] == CoutY
+    rc = L.wm_conv3x3_wgrad_gvfused(_p(x), c_int(ldx), c_int(ldx), _p(in_scale), _p(in_shift), _p(gvec), _p(y), c_int(CoutY), c_int(CoutY),
+                                    _p(stats), _p(coef), _p(ws), _p(dw), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W),
+                                    c_int(Cin), c_int(Cout), c_int(dtype_id(x)), _stream())
+    _lib.check(rc, "wm_conv3x3_wgrad_gvfused")
+
+
+def conv3x3_dgrad_gvfused(y, wpt, gvec, stats, coef):
+    """input gradient of the same layer: conv3x3 of the on-the-fly dy with the transposed packed filter wpt [9,CinP,CoutY]"""
+    B, H, W, CoutY = y.shape
+    CinP = wpt.shape[1]
+    assert wpt.shape[2] == CoutY and stats.is_contiguous() and coef.is_contiguous() and gvec.is_contiguous()
+    dx = torch.empty(B, H, W, CinP, device=y.device, dtype=y.dtype)
+    rc = _lib.lib().wm_conv3x3_dgrad_gvfused(_p(y), c_int(CoutY), c_int(CoutY), _p(wpt), _p(gvec), _p(stats), _p(coef), _p(dx), c_int(B),
+                                             c_int(H), c_int(W), c_int(CinP), c_int(dtype_id(y)), _stream())
+    _lib.check(rc, "wm_conv3x3_dgrad_gvfused")
+    return dx
+
+
 def linear_head_fwd(pooled, w, bias, I):
     """pooled [B,ldp] f32 (first I columns used), w [O,I], bias [O] -> [B,O]"""
     _need_cuda(pooled, w)
