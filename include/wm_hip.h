@@ -180,6 +180,16 @@ int wm_conv3x3_wgrad_gvfused(const void* x, int ldx, int CinX, const float* in_s
                              int accumulate, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
 int wm_conv3x3_dgrad_gvfused(const void* y, int ldy, int CoutY, const void* wpt, const float* gvec, const float* stats4,
                              const float* coef, void* dx, int B, int H, int W, int CinP, int dtype, void* stream);
+/* Input gradient (bf16, CoutY in {64,32} -> CinP = 64) whose epilogue also reduces the BatchNorm-backward sums of the
+ * ConvBNRelu that FEEDS this layer (conv_bn_relu.py:11-15 stacked as in decoder.py:16-24): dx is that layer's g, and with
+ * its raw output ry [B,H,W,64] and r_scale / r_shift the kernel emits partials f32[wm_conv3x3_nparts(..)][2][64] =
+ * sum(gz), sum(gz*y) per channel (gz = bf16(dx)*[r_scale*ry + r_shift > 0]) -- wm_bn_bwd_reduce over (dx, ry) is not
+ * needed; finish with wm_bn_bwd_finalize_raw.  src = this layer's dy, or (gvec, stats4, coef non-NULL) this layer's raw
+ * output with the apply pass fused as in wm_conv3x3_dgrad_gvfused. */
+int wm_conv3x3_dgrad_bwdstats_supported(int CoutY, int CinP, int dtype);
+int wm_conv3x3_dgrad_bwdstats(const void* src, int lds, int CoutY, const void* wpt, const float* gvec, const float* stats4,
+                              const float* coef, const void* ry, const float* r_scale, const float* r_shift, void* dx,
+                              float* partials, int B, int H, int W, int CinP, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm2d (training)
  * replaces nn.BatchNorm2d + nn.ReLU of conv_bn_relu.py:12-14 / UNet.py:67-97.
@@ -205,6 +215,10 @@ int wm_bn_bwd_reduce(const void* g, int ldg, const float* gvec, const void* y, i
 int wm_bn_bwd_finalize(const float* partials, int nparts, int C, int CP, double count,
                        const float* gamma, const float* invstd, float* dgamma, float* dbeta,
                        int accumulate, float* coef /* [3][CP]: a=gamma*invstd, c1, c2 */, void* stream);
+/* the same for partial rows that hold sum(gz), sum(gz*y) (wm_conv3x3_dgrad_bwdstats): xhat is applied here */
+int wm_bn_bwd_finalize_raw(const float* partials, int nparts, int C, int CP, double count, const float* gamma,
+                           const float* mean, const float* invstd, float* dgamma, float* dbeta, int accumulate,
+                           float* coef, void* stream);
 int wm_bn_bwd_apply(const void* g, int ldg, const float* gvec, const void* y, int ldy,
                     const float* scale, const float* shift, const float* mean, const float* invstd,
                     const float* coef, void* dy, int lddy, float* dbias_partials, int B, size_t hw,

@@ -497,3 +497,81 @@ def test_pooled_layer_fusion_keeps_the_training_step():
         assert outs[0][0][k] == outs[1][0][k], k
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", [(2, 40, 36, 64, False), (1, 17, 50, 64, True), (3, 64, 64, 30, True), (17, 16, 16, 64, False)])
+def test_dgrad_that_reduces_the_feeding_layers_bn_backward_sums(case):
+    """wm_conv3x3_dgrad_bwdstats: dx bit-identical to the plain dgrad (and to the apply-fused one), and the partial rows it
+    emits finish (wm_bn_bwd_finalize_raw) into the same dgamma / dbeta / coef as wm_bn_bwd_reduce over (dx, ry)."""
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, C, pooled = case
+    CP = 32 * ((C + 31) // 32)
+    dy = nhwc(detgen.normal((B, C, H, W), 141), torch.bfloat16, CP)
+    w = detgen.normal((C, 64, 3, 3), 142, std=0.05).cuda()
+    wpt = ops.pack_w3x3(w, CP, 64, torch.bfloat16, transpose=True)
+    ry = nhwc(detgen.normal((B, 64, H, W), 143, mean=0.4), torch.bfloat16)
+    gamma = detgen.normal((64,), 144, mean=1.0, std=0.3).cuda(); beta = detgen.normal((64,), 145, std=0.3).cuda()
+    yf = ry.float()
+    mean = yf.mean((0, 1, 2)); invstd = torch.rsqrt(yf.var((0, 1, 2), unbiased=False) + 1e-5)
+    scale = gamma * invstd
+    rstats = torch.stack([scale, beta - mean * scale, mean, invstd]).contiguous()
+    assert ops.conv3x3_dgrad_bwdstats_supported(CP, 64, torch.bfloat16)
+    if pooled:   # this layer is the pooled one: src = its raw output, the apply pass fused as well
+        gvec = torch.zeros(B, CP, device="cuda"); gvec[:, :C] = detgen.normal((B, C), 146).cuda() / (H * W)
+        g2 = detgen.normal((C,), 147, mean=1.0, std=0.3).cuda()
+        st = torch.zeros(4, CP, device="cuda")
+        y2 = dy.float()[..., :C]
+        m2 = y2.mean((0, 1, 2)); i2 = torch.rsqrt(y2.var((0, 1, 2), unbiased=False) + 1e-5)
+        st[0, :C] = g2 * i2; st[1, :C] = -m2 * g2 * i2; st[2, :C] = m2; st[3, :C] = i2
+        coef = ops.bn_bwd_coef(None, gvec, dy, st, C, g2, torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), False)
+        dx0 = ops.conv3x3_dgrad_gvfused(dy, wpt, gvec, st, coef)
+        dx1, part = ops.conv3x3_dgrad_bwdstats(dy, wpt, ry, rstats[0], rstats[1], gvec, st, coef)
+    else:
+        dx0, _ = ops.conv3x3_fwd(dy, wpt, None, None, None, want_stats=False)
+        dx1, part = ops.conv3x3_dgrad_bwdstats(dy, wpt, ry, rstats[0], rstats[1])
+    assert dx0.float().abs().max().item() > 0
+    assert torch.equal(dx0, dx1)
+    dg0 = torch.zeros(64, device="cuda"); db0 = torch.zeros(64, device="cuda")
+    c0 = ops.bn_bwd_coef(dx0, None, ry, rstats, 64, gamma, dg0, db0, False)
+    dg1 = torch.full((64,), 0.5, device="cuda"); db1 = torch.full((64,), -0.5, device="cuda")
+    c1 = ops.bn_bwd_coef_raw(part, ry, rstats, 64, gamma, dg1, db1, False)
+    # same addends; f32 partial sums in another order, and sum(gz*xhat) as invstd*(sum(gz*y) - mean*sum(gz))
+    sc = dg0.abs().max().item() + db0.abs().max().item()
+    torch.testing.assert_close(db1, db0, rtol=1e-4, atol=1e-5 * sc)
+    torch.testing.assert_close(dg1, dg0, rtol=1e-4, atol=1e-5 * sc)
+    torch.testing.assert_close(c1, c0, rtol=1e-4, atol=1e-5 * c0.abs().max().item())
+    # accumulate (the finalisation treats the partial rows as scratch: emit them again)
+    part = ops.conv3x3_dgrad_bwdstats(dy, wpt, ry, rstats[0], rstats[1], *((gvec, st, coef) if pooled else ()))[1]
+    ops.bn_bwd_coef_raw(part, ry, rstats, 64, gamma, dg1, db1, True)
+    torch.testing.assert_close(dg1, 2 * dg0, rtol=1e-4, atol=2e-5 * sc)
+
+
+def test_fused_bn_backward_reduce_keeps_the_training_step():
+    """the HiDDeN step with the BatchNorm-backward reduce passes folded into the dgrad epilogues: same losses, and parameters
+    within f32 summation-order noise of the step with separate reduce passes"""
+    import ctypes
+    from video_watermarking_forgery_detection_amd import _lib
+    from video_watermarking_forgery_detection_amd.hidden_models import Hidden
+    from video_watermarking_forgery_detection_amd import noise_layers as NL
+    from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
+    L = _lib.lib()
+    outs = []
+    try:
+        for on in (1, 0):
+            L.wm_debug_bwdst(ctypes.c_int(on))
+            torch.manual_seed(10)
+            h = Hidden(HiDDenConfiguration(H=64, W=64), torch.device("cuda"), NL.Jpeg(50), None, compute_dtype=torch.bfloat16)
+            images = detgen.uniform((4, 3, 64, 64), 151).cuda(); messages = (detgen.uniform((4, 30), 152) > 0.5).float().cuda()
+            losses, _ = h.train_on_batch([images, messages])
+            outs.append((losses, [p.grad.detach().clone() for p in list(h.encoder_decoder.parameters()) + list(h.discriminator.parameters())]))
+    finally:
+        L.wm_debug_bwdst(ctypes.c_int(1))
+    for k in outs[0][0]:
+        assert abs(outs[0][0][k] - outs[1][0][k]) <= 1e-6 * max(1.0, abs(outs[1][0][k])), k
+    worst = 0.0
+    for a, b in zip(outs[0][1], outs[1][1]):
+        den = b.abs().max().item()
+        if den > 0:
+            worst = max(worst, (a - b).abs().max().item() / den)
+    # bf16 dy downstream of a coefficient that moved by 1e-7 can flip a rounding here and there
+    assert worst < 2e-2, worst

@@ -195,11 +195,13 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const T* __restrict__ g, int
     }
 }
 
-// partials [nparts][2][CP] -> dgamma, dbeta, coef[3][CP]
+// partials [nparts][2][CP] -> dgamma, dbeta, coef[3][CP].  raw_mean != nullptr: the second row holds sum(gz*y) (reduced by a
+// dgrad epilogue, conv3x3_ws.hip BWDST) instead of sum(gz*xhat): xhat = (y-mean)*invstd is applied here, in double
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, int CP,
                                                               double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ invstd, float* dgamma,
-                                                              float* dbeta, int accumulate, float* coef) {
+                                                              float* dbeta, int accumulate, float* coef,
+                                                              const float* __restrict__ raw_mean) {
     // 8 channels x 32 row slices per workgroup: every thread's <= 8 row loads are independent and in flight together
     __shared__ double s1[32][8], s2[32][8];
     const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     __syncthreads();
     if (sl == 0 && c < CP) {
         for (int k = 1; k < 32; ++k) { a1 += s1[k][cl]; a2 += s2[k][cl]; }
+        if (raw_mean && c < C) a2 = (a2 - (double)raw_mean[c] * a1) * (double)invstd[c];
         if (c < C) {
             if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)a1;
             if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)a2;
@@ -357,8 +360,19 @@ extern "C" int wm_bn_bwd_finalize(const float* partials, int nparts, int C, int 
     WM_REQUIRE(partials && gamma && invstd && coef, WM_E_BADARG, "wm_bn_bwd_finalize: null pointer");
     nparts = tree_reduce_rows(const_cast<float*>(partials), nparts, 2 * CP, (hipStream_t)stream);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(wm_cdiv(CP, 8)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C,
-                       CP, count, gamma, invstd, dgamma, dbeta, accumulate, coef);
+                       CP, count, gamma, invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr);
     WM_LAUNCH_CHECK("wm_bn_bwd_finalize");
+    return WM_OK;
+}
+
+extern "C" int wm_bn_bwd_finalize_raw(const float* partials, int nparts, int C, int CP, double count, const float* gamma,
+                                      const float* mean, const float* invstd, float* dgamma, float* dbeta, int accumulate,
+                                      float* coef, void* stream) {
+    WM_REQUIRE(partials && gamma && mean && invstd && coef, WM_E_BADARG, "wm_bn_bwd_finalize_raw: null pointer");
+    nparts = tree_reduce_rows(const_cast<float*>(partials), nparts, 2 * CP, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(wm_cdiv(CP, 8)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C,
+                       CP, count, gamma, invstd, dgamma, dbeta, accumulate, coef, mean);
+    WM_LAUNCH_CHECK("wm_bn_bwd_finalize_raw");
     return WM_OK;
 }
 

@@ -31,7 +31,8 @@ int wm_launch_conv3x3_stream(const void* x, int ldx, const void* wp, const float
 int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void* wp, const float* bias, int nbias, const float* in_scale,
                          const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
                          hipStream_t s, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
-                         const float* bw_gvec = nullptr);
+                         const float* bw_gvec = nullptr, const void* ry = nullptr, const float* r_scale = nullptr,
+                         const float* r_shift = nullptr);
 
 namespace {
 
@@ -399,6 +400,32 @@ extern "C" int wm_conv3x3_dgrad_gvfused(const void* y, int ldy, int CoutY, const
                                         ws_tiles_per_wg(ntiles), (hipStream_t)stream, stats4, CoutY, coef, gvec);
     WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_dgrad_gvfused: no kernel for this shape");
     WM_LAUNCH_CHECK("wm_conv3x3_dgrad_gvfused");
+    return WM_OK;
+}
+
+// input gradient whose epilogue also reduces the BatchNorm-backward sums of the layer it feeds.  src: dy [B,H,W,lds] of this
+// layer, or (gvec != NULL) this layer's raw output y with the apply pass fused as in wm_conv3x3_dgrad_gvfused.
+static int g_bwdst = getenv("WM_NO_BWDST") ? 0 : 1;
+extern "C" void wm_debug_bwdst(int on) { g_bwdst = on; }   // A/B knob (tools/ab_step.py)
+extern "C" int wm_conv3x3_dgrad_bwdstats_supported(int CoutY, int CinP, int dtype) {
+    return (g_bwdst && dtype == WM_BF16 && (CoutY == 64 || CoutY == 32) && CinP == 64 && use_ws(CoutY, CinP, dtype)) ? 1 : 0;
+}
+extern "C" int wm_conv3x3_dgrad_bwdstats(const void* src, int lds, int CoutY, const void* wpt, const float* gvec, const float* stats4,
+                                         const float* coef, const void* ry, const float* r_scale, const float* r_shift, void* dx,
+                                         float* partials, int B, int H, int W, int CinP, int dtype, void* stream) {
+    WM_REQUIRE(src && wpt && ry && r_scale && r_shift && dx && partials, WM_E_BADARG, "wm_conv3x3_dgrad_bwdstats: null pointer");
+    WM_REQUIRE((gvec == nullptr) == (stats4 == nullptr) && (gvec == nullptr) == (coef == nullptr), WM_E_BADARG,
+               "wm_conv3x3_dgrad_bwdstats: gvec, stats4 and coef come together");
+    WM_REQUIRE(B > 0 && H > 0 && W > 0, WM_E_BADARG, "wm_conv3x3_dgrad_bwdstats: bad shape");
+    WM_REQUIRE(wm_conv3x3_dgrad_bwdstats_supported(CoutY, CinP, dtype), WM_E_SHAPE,
+               "wm_conv3x3_dgrad_bwdstats: unsupported shape CoutY=%d CinP=%d dtype=%d", CoutY, CinP, dtype);
+    WM_REQUIRE(lds >= CoutY && lds % 8 == 0 && (((uintptr_t)src | (uintptr_t)wpt | (uintptr_t)dx | (uintptr_t)ry) & 15) == 0, WM_E_SHAPE,
+               "wm_conv3x3_dgrad_bwdstats: bad stride / alignment");
+    const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
+    const int rc = wm_launch_conv3x3_ws(src, lds, CoutY, CinP, wpt, nullptr, 0, nullptr, nullptr, dx, partials, B, H, W, ws_wgs(ntiles),
+                                        ws_tiles_per_wg(ntiles), (hipStream_t)stream, stats4, CoutY, coef, gvec, ry, r_scale, r_shift);
+    WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_dgrad_bwdstats: no kernel for this shape");
+    WM_LAUNCH_CHECK("wm_conv3x3_dgrad_bwdstats");
     return WM_OK;
 }
 

@@ -36,6 +36,7 @@ struct WsArgs {
     int dbg;      // STAMPS build only: 1 = skip the MFMA loop, 2 = skip the stores, 4 = skip the halo loads
     int xcd_map;
     const float* bw_stats4; int bw_ld; const float* bw_coef; const float* bw_gvec;   // BNBWD: [scale|shift|mean|invstd][bw_ld], coef [3][bw_ld], gvec [B][bw_ld]
+    const bf16_t* ry; const float* r_scale; const float* r_shift;   // BWDST: raw output [B,H,W,COUT] and scale / shift of the layer whose output gradient this kernel writes
     int reverse;  // walk the workgroup's run of tiles backwards (Infinity Cache reuse of the previous kernel's tail)
 };
 
@@ -59,7 +60,11 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 // BNBWD (dgrad of a layer whose output was globally pooled): the input tensor is that layer's raw conv output y, and the
 // producers turn it into dy = ca * (gvec[b]*[scale*y+shift > 0] - c1 - (y-mean)*invstd * c2) while staging -- the
 // BatchNorm-backward APPLY pass, fused (the folded form of wm_common.h: bit-identical to bn_bwd_kernel<bf16, APPLY, GVEC>)
-template <int CIN, int COUT, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false, bool BNBWD = false>
+// BWDST (dgrad whose output is the gradient g wrt a ConvBNRelu's ReLU output): the consumers also reduce that layer's
+// BatchNorm-backward sums from the tile they hold -- per channel sum(gz) and sum(gz*y), gz = g*[scale*y+shift > 0], g rounded
+// to bf16 as stored, y = that layer's raw conv output read at the tile's pixels -- into the partial rows `stat`: the separate
+// reduce pass over (g, y) disappears (its y read moves here, its g read is gone)
+template <int CIN, int COUT, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false, bool BNBWD = false, bool BWDST = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned long long* __restrict__ stamps = nullptr) {
     static_assert(CIN == 64 || CIN == 32 || CIN == 16, "input channels");
     static_assert(!M16 || CIN % 32 == 0, "the 16x16x32 MFMA consumes 32 input channels per step");
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             iter(tile, dA, okA, dB, okB);
             if (tile + 1 < t_end) iter(tile + 1, dB, okB, dA, okA);
         }
-        if (STATS) __syncthreads();
+        if (STATS || BWDST) __syncthreads();
         if (STAMPS && stamps && tid == 256) {
             unsigned long long rt_end;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_end)::"memory");
@@ -382,7 +387,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         for (int ks = 0; ks < KS2; ++ks) boff[ks] = (p * CIN + swz<CIN>(p, ks * 4 + q) * 8) * 2;
 
         f32x4 acc[4][NFR];   // [pixel fragment mf = tile row][channel fragment nf]
+        static_assert(!BWDST || (!STATS && COUT == 64), "BWDST: 64-channel dgrads");
         struct Drain { bf16_t* yp; float mk; bool inb; };
+        float rsc[CPL], rsh[CPL];
+        if (BWDST) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) { rsc[c] = a.r_scale[CPL * q + c]; rsh[c] = a.r_shift[CPL * q + c]; }
+        }
+        unsigned ryv[2][NPAIR];   // BWDST: the layer's y at the two pixels of the half being drained, this lane's channels
+        auto load_ry = [&](const Drain (&d)[2]) {
+            if (BWDST) {
+#pragma unroll
+                for (int ml = 0; ml < 2; ++ml) {
+                    const bf16_t* src = a.ry + (d[ml].inb ? (d[ml].yp - a.y) : (ptrdiff_t)(CPL * q));
+#pragma unroll
+                    for (int v = 0; v < NPAIR / 4; ++v) {
+                        const u32x4 t = *reinterpret_cast<const u32x4*>(src + 8 * v);
+                        ryv[ml][4 * v] = t[0]; ryv[ml][4 * v + 1] = t[1]; ryv[ml][4 * v + 2] = t[2]; ryv[ml][4 * v + 3] = t[3];
+                    }
+                }
+            }
+        };
         auto drain_of = [&](const TileGeo& g, int mf) {
             Drain d;
             const int gy = g.ty0 + wave * 4 + mf, gx = g.tx0 + p;
@@ -406,6 +431,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 }
                 const bf16x2 p2 = {(bf16_t)v0, (bf16_t)v1};
                 pk[j] = __builtin_bit_cast(unsigned, p2);
+                if (BWDST) {   // scalar f32, as above
+                    const unsigned gm = d[ml].inb ? pk[j] : 0u;
+                    const float g0 = __builtin_bit_cast(float, gm << 16), g1 = __builtin_bit_cast(float, gm & 0xffff0000u);
+                    const float y0 = __builtin_bit_cast(float, ryv[ml][j] << 16), y1 = __builtin_bit_cast(float, ryv[ml][j] & 0xffff0000u);
+                    const float z0 = __builtin_fmaf(rsc[2 * j], y0, rsh[2 * j]), z1 = __builtin_fmaf(rsc[2 * j + 1], y1, rsh[2 * j + 1]);
+                    const float gz0 = z0 > 0.f ? g0 : 0.f, gz1 = z1 > 0.f ? g1 : 0.f;
+                    s1[2 * j] += gz0; s1[2 * j + 1] += gz1;
+                    s2[2 * j] = __builtin_fmaf(gz0, y0, s2[2 * j]);
+                    s2[2 * j + 1] = __builtin_fmaf(gz1, y1, s2[2 * j + 1]);
+                }
             } else if (d[ml].inb && !(STAMPS && (a.dbg & 2))) {
 #pragma unroll
                 for (int v = 0; v < NPAIR / 4; ++v)
@@ -420,11 +455,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 for (int nf = 0; nf < NFR; ++nf) acc[2 * half + ml][nf] = *reinterpret_cast<const f32x4*>(sBias + CPL * q + 4 * nf);
             if (STAMPS && (a.dbg & 1)) {
                 if (drain) {
+                    load_ry(d);
 #pragma unroll
                     for (int m = 0; m < NDR; ++m) drain_step(m, dh, d);
                 }
                 return;
             }
+            // BWDST: the y values of the half being drained are requested here and first used DS0 K-steps later
+            constexpr int DS0 = BWDST ? 6 : 0;
+            if (drain) load_ry(d);
             constexpr int PF = 2;   // a deeper ring measured the same
             bf16x8 pix[PF][2], fil[PF][NFR];
             auto load_frags = [&](int sidx, int buf) {
@@ -451,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                         acc[2 * half + ml][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fil[cb][nf], pix[cb][ml], acc[2 * half + ml][nf], 0, 0, 0);
                 if (drain) {
 #pragma unroll
-                    for (int m = sidx * NDR / NSTEP2; m < (sidx + 1) * NDR / NSTEP2; ++m) drain_step(m, dh, d);
+                    for (int m = max(sidx - DS0, 0) * NDR / (NSTEP2 - DS0); m < max(sidx + 1 - DS0, 0) * NDR / (NSTEP2 - DS0); ++m) drain_step(m, dh, d);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -475,6 +514,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 if (tile + 1 < t_end) {
                     pass(sX0 + (((tile - t_begin) & 1) ^ 1) * (NPIX * CIN), 0, true, 1, d1);
                 } else {
+                    load_ry(d1);
 #pragma unroll
                     for (int m = 0; m < NDR; ++m) drain_step(m, 1, d1);
                 }
@@ -488,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             o[0] = ph[0]; o[1] = ph[1]; o[2] = ph[2]; o[3] = ph[3];
             o[4] = now() - t_start; o[5] = rt_end - rt_start;
         }
-        if (STATS) {
+        if (STATS || BWDST) {
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 float u1 = s1[c], u2 = s2[c];
@@ -664,7 +704,7 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
     a.in_shift = in_shift; a.y = (bf16_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
     const int wgs = a.ntiles < 256 ? a.ntiles : 256;
-    a.tiles_per_wg = wm_cdiv(a.ntiles, wgs); a.reverse = 0; a.bw_stats4 = nullptr; a.bw_ld = 0; a.bw_coef = nullptr; a.bw_gvec = nullptr;
+    a.tiles_per_wg = wm_cdiv(a.ntiles, wgs); a.reverse = 0; a.bw_stats4 = nullptr; a.bw_ld = 0; a.bw_coef = nullptr; a.bw_gvec = nullptr; a.ry = nullptr; a.r_scale = nullptr; a.r_shift = nullptr;
     const dim3 grid((unsigned)wm_cdiv(a.ntiles, a.tiles_per_wg)), block(512);
     if (in_scale && stat) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, true, true, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
     else hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
@@ -681,7 +721,8 @@ extern "C" void wm_debug_ws_direction(int reverse) { g_ws_reverse = reverse; }
 int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void* wp, const float* bias, int nbias, const float* in_scale,
                            const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
                            hipStream_t s, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
-                           const float* bw_gvec = nullptr) {
+                           const float* bw_gvec = nullptr, const void* ry = nullptr, const float* r_scale = nullptr,
+                           const float* r_shift = nullptr) {
     WsArgs a;
     a.dbg = g_ws_variant == 3 ? 8 : (g_ws_variant == 8 ? 64 : 0); a.xcd_map = g_ws_variant != 2;
     a.x = (const bf16_t*)x; a.ldx = ldx; a.wp = (const bf16_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
@@ -689,7 +730,19 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void*
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY; a.tiles_per_wg = tiles_per_wg;
     a.reverse = g_ws_reverse;
     a.bw_stats4 = bw_stats4; a.bw_ld = bw_ld; a.bw_coef = bw_coef; a.bw_gvec = bw_gvec;
+    a.ry = (const bf16_t*)ry; a.r_scale = r_scale; a.r_shift = r_shift;
     const dim3 grid((unsigned)wgs), block(512);
+    if (ry) {   // dgrad that also reduces the BatchNorm-backward sums of the layer it feeds
+        if (CoutP != 64 || in_scale || !stat || (Cin != 64 && Cin != 32)) return WM_E_SHAPE;
+        if (bw_stats4) {
+            if (Cin == 64) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, true, true>), grid, block, 0, s, a, nullptr);
+            else hipLaunchKernelGGL((conv3x3_ws_kernel<32, 64, false, false, true, false, true, true>), grid, block, 0, s, a, nullptr);
+        } else {
+            if (Cin == 64) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, false, true>), grid, block, 0, s, a, nullptr);
+            else hipLaunchKernelGGL((conv3x3_ws_kernel<32, 64, false, false, true, false, false, true>), grid, block, 0, s, a, nullptr);
+        }
+        return WM_OK;
+    }
     if (bw_stats4) {   // dgrad with the BatchNorm-backward apply (per-sample gradient rows) fused: 64 or 32 -> 64
         if ((Cin != 64 && Cin != 32) || CoutP != 64 || in_scale || stat) return WM_E_SHAPE;
         if (Cin == 64) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, true>), grid, block, 0, s, a, nullptr);

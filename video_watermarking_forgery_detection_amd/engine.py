@@ -20,10 +20,11 @@ from . import ops
 
 class Act:
     """NHWC activation: logical value = t (if scale is None) or relu(scale*t+shift)."""
-    __slots__ = ("t", "C", "scale", "shift")
+    __slots__ = ("t", "C", "scale", "shift", "bwd")
 
     def __init__(self, t, C, scale=None, shift=None):
         self.t, self.C, self.scale, self.shift = t, C, scale, shift
+        self.bwd = None   # backward: (g, partials) left by the consumer's dgrad when it reduced this layer's BatchNorm sums
 
 
 def round_up(n, m):
@@ -40,7 +41,7 @@ def image_to_act(img, dtype):
 
 
 class CBRCtx:
-    __slots__ = ("x", "y", "stats", "perm", "training")
+    __slots__ = ("x", "y", "stats", "perm", "training", "out")
 
 
 def _packed(conv, CoutP, CinP, dtype, perm, transpose):
@@ -76,7 +77,8 @@ def cbr_forward(conv, bn, x, dtype, perm=None, training=True, momentum=0.1):
         stats[3, :Cout] = invstd
     ctx = CBRCtx()
     ctx.x, ctx.y, ctx.stats, ctx.perm, ctx.training = x, y, stats, perm, training
-    return Act(y, Cout, stats[0], stats[1]), ctx
+    ctx.out = Act(y, Cout, stats[0], stats[1])
+    return ctx.out, ctx
 
 
 def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, accumulate=False,
@@ -94,27 +96,46 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
     # removes the bias); the reference's autograd produces rounding noise of ~1e-9 there.  The bias gradient view is
     # zero-initialised and never written, which is the exact value and saves a reduction + two launches per layer.
     dbias = None
+    # The dgrad that produced g (the next layer's, below) may have reduced this layer's sums in its epilogue already
+    pre, ctx.out.bwd = ctx.out.bwd, None
+    gam, dgam, dbet = bn.weight.data, grads[bn.weight], grads[bn.bias]
+
+    def coef_of():
+        if pre is not None and g is not None and pre[0] is g:
+            return ops.bn_bwd_coef_raw(pre[1], y, ctx.stats, Cout, gam, dgam, dbet, accumulate)
+        return ops.bn_bwd_coef(g, gvec, y, ctx.stats, Cout, gam, dgam, dbet, accumulate)
+
     # An image-fed first layer whose input needs no gradient: dy has ONE consumer, the weight gradient -- its kernel forms dy
     # from (g, y) while staging the tile, so the apply pass (a write and a read of dy) disappears.
     if (not need_input_grad and g is not None and x.scale is None and perm_dev is None and ctx.stats.is_contiguous()
             and g.shape[-1] == y.shape[-1] and ops.conv3x3_wgrad_bnfused_supported(x.t.shape[-1], y.shape[-1], dtype)):
-        coef = ops.bn_bwd_coef(g, None, y, ctx.stats, Cout, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate)
-        ops.conv3x3_wgrad_bnfused(x.t, g, y, ctx.stats, coef, grads[conv.weight], accumulate)
+        ops.conv3x3_wgrad_bnfused(x.t, g, y, ctx.stats, coef_of(), grads[conv.weight], accumulate)
         return None
+    rows = dgrad_channels or round_up(x.t.shape[-1], 32)
+    # the input is itself a ConvBNRelu output: this layer's dgrad can reduce THAT layer's BatchNorm-backward sums on the way
+    feed_stats = (need_input_grad and x.scale is not None and perm_dev is None and ctx.perm is None and rows == 64
+                  and x.t.shape[-1] == 64 and x.t.is_contiguous() and ops.conv3x3_dgrad_bwdstats_supported(y.shape[-1], rows, dtype))
     # A globally pooled layer (the gradient wrt its ReLU output is one row per sample): both consumers of dy -- the weight
     # gradient and the input gradient -- form it from (gvec, y) while staging their tiles; no apply pass, no dy tensor.
-    rows = dgrad_channels or round_up(x.t.shape[-1], 32)
     if (gvec is not None and need_input_grad and x.scale is not None and perm_dev is None and ctx.perm is None and rows == 64
             and x.t.shape[-1] == 64 and ctx.stats.is_contiguous() and ops.conv3x3_gvfused_supported(64, y.shape[-1], dtype)):
-        coef = ops.bn_bwd_coef(None, gvec, y, ctx.stats, Cout, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate)
+        coef = coef_of()
         ops.conv3x3_wgrad_gvfused(x.t, x.scale, x.shift, gvec, y, ctx.stats, coef, grads[conv.weight], accumulate)
         wpt = _packed(conv, y.shape[-1], rows, dtype, None, True)
+        if feed_stats:
+            gx, part = ops.conv3x3_dgrad_bwdstats(y, wpt, x.t, x.scale, x.shift, gvec, ctx.stats, coef)
+            x.bwd = (gx, part)
+            return gx
         return ops.conv3x3_dgrad_gvfused(y, wpt, gvec, ctx.stats, coef)
-    dy = ops.bn_bwd(g, gvec, y, ctx.stats, Cout, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate, dbias)
+    dy = ops.bn_bwd(g, gvec, y, ctx.stats, Cout, gam, dgam, dbet, accumulate, dbias, coef=coef_of())
     ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, perm_dev=perm_dev)
     if not need_input_grad:
         return None
     wpt = _packed(conv, y.shape[-1], rows, dtype, ctx.perm, True)
+    if feed_stats:
+        gx, part = ops.conv3x3_dgrad_bwdstats(dy, wpt, x.t, x.scale, x.shift)
+        x.bwd = (gx, part)
+        return gx
     gx, _ = ops.conv3x3_fwd(dy, wpt, None, None, None, want_stats=False)
     return gx
 

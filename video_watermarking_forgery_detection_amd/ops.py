@@ -271,14 +271,28 @@ def bn_bwd_coef(g, gvec, y, stats, C, gamma, dgamma, dbeta, accumulate):
     return coef
 
 
-def bn_bwd(g, gvec, y, stats, C, gamma, dgamma, dbeta, accumulate, dbias):
+def bn_bwd_coef_raw(partials, y, stats, C, gamma, dgamma, dbeta, accumulate):
+    """bn_bwd_coef from partial rows [n,2,CP] = sum(gz), sum(gz*y) already reduced by the dgrad that produced g
+    (conv3x3_dgrad_bwdstats): no pass over (g, y)."""
+    B, H, W, CP = y.shape
+    coef = torch.empty(3, CP, device=y.device, dtype=torch.float32)
+    rc = _lib.lib().wm_bn_bwd_finalize_raw(_p(partials), c_int(partials.shape[0]), c_int(C), c_int(CP), c_double(B * H * W), _p(gamma),
+                                           _p(stats[2]), _p(stats[3]), _p(dgamma), _p(dbeta), c_int(1 if accumulate else 0), _p(coef),
+                                           _stream())
+    _lib.check(rc, "wm_bn_bwd_finalize_raw")
+    return coef
+
+
+def bn_bwd(g, gvec, y, stats, C, gamma, dgamma, dbeta, accumulate, dbias, coef=None):
     """ReLU+BN backward.  g [B,H,W,ld] or None with gvec [B,CP]; y raw conv output [B,H,W,CP];
-    stats = [4,CP] (scale, shift, mean, invstd).  Returns dy [B,H,W,CP]; writes dgamma/dbeta/dbias."""
+    stats = [4,CP] (scale, shift, mean, invstd).  Returns dy [B,H,W,CP]; writes dgamma/dbeta/dbias.
+    coef: the result of bn_bwd_coef / bn_bwd_coef_raw when the reduce pass already ran (dgamma / dbeta written there)."""
     B, H, W, CP = y.shape
     hw = H * W
     L = _lib.lib()
     dev = y.device
-    coef = bn_bwd_coef(g, gvec, y, stats, C, gamma, dgamma, dbeta, accumulate)
+    if coef is None:
+        coef = bn_bwd_coef(g, gvec, y, stats, C, gamma, dgamma, dbeta, accumulate)
     nparts = L.wm_bn_bwd_nparts(c_size_t(B * hw))
     ldg = c_int(0 if g is None else g.shape[-1])
     dy = torch.empty_like(y)
@@ -343,6 +357,27 @@ def conv3x3_dgrad_gvfused(y, wpt, gvec, stats, coef):
                                              c_int(H), c_int(W), c_int(CinP), c_int(dtype_id(y)), _stream())
     _lib.check(rc, "wm_conv3x3_dgrad_gvfused")
     return dx
+
+
+def conv3x3_dgrad_bwdstats_supported(CoutY, CinP, dtype):
+    return bool(_lib.lib().wm_conv3x3_dgrad_bwdstats_supported(c_int(CoutY), c_int(CinP), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32)))
+
+
+def conv3x3_dgrad_bwdstats(src, wpt, ry, r_scale, r_shift, gvec=None, stats=None, coef=None):
+    """input gradient dx = conv3x3(dy, wpt) whose epilogue also reduces the BatchNorm-backward sums of the layer that feeds
+    this one (raw output ry, constants r_scale / r_shift).  src = dy, or (with gvec, stats, coef) this layer's raw output
+    with the apply pass fused.  Returns (dx, partials [n,2,64])."""
+    B, H, W, lds = src.shape
+    CinP, CoutY = wpt.shape[1], wpt.shape[2]
+    assert ry.shape == (B, H, W, CinP) and ry.is_contiguous() and CoutY <= lds
+    assert (gvec is None) == (stats is None) == (coef is None)
+    dx = torch.empty(B, H, W, CinP, device=src.device, dtype=src.dtype)
+    part = torch.empty(conv3x3_nparts(B, H, W, CoutY, CinP, src.dtype), 2, CinP, device=src.device, dtype=torch.float32)
+    rc = _lib.lib().wm_conv3x3_dgrad_bwdstats(_p(src), c_int(lds), c_int(CoutY), _p(wpt), _p(gvec), _p(stats), _p(coef), _p(ry), _p(r_scale),
+                                              _p(r_shift), _p(dx), _p(part), c_int(B), c_int(H), c_int(W), c_int(CinP),
+                                              c_int(dtype_id(src)), _stream())
+    _lib.check(rc, "wm_conv3x3_dgrad_bwdstats")
+    return dx, part
 
 
 def linear_head_fwd(pooled, w, bias, I):
