@@ -109,8 +109,8 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const T* __restrict__ g, int
         sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e];
         if (APPLY) { ca[e] = coef[c0 + e]; c1[e] = coef[CP + c0 + e]; c2[e] = coef[2 * CP + c0 + e]; }
     }
-    // bf16 apply pass of a globally pooled layer: the folded form of wm_common.h (shared with the kernels that fuse this pass)
-    constexpr bool FOLD = APPLY && GVEC && sizeof(T) == 2;
+    // bf16 apply pass: the folded form of wm_common.h (shared with the kernels that fuse this pass)
+    constexpr bool FOLD = APPLY && sizeof(T) == 2;
     float k2[VE], k3[VE];
     if (FOLD) {
 #pragma unroll
@@ -137,7 +137,8 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const T* __restrict__ g, int
         for (int e = 0; e < VE; ++e) {
             const float yy = yv.get(e);
             if (FOLD) {
-                const float d = wm_bn_fold_dy(yy, sc[e], sh[e], k2[e], k3[e], wm_bn_fold_g(ca[e], gg[e], k3[e]));
+                const float d = GVEC ? wm_bn_fold_dy(yy, sc[e], sh[e], k2[e], k3[e], wm_bn_fold_g(ca[e], gg[e], k3[e]))
+                                     : wm_bn_fold_dyg(yy, gg[e], sc[e], sh[e], ca[e], k2[e], k3[e]);
                 out.set(e, d);
                 a1[e] += d;
                 continue;

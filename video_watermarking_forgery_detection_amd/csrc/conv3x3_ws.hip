@@ -64,7 +64,7 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 // BatchNorm-backward sums from the tile they hold -- per channel sum(gz) and sum(gz*y), gz = g*[scale*y+shift > 0], g rounded
 // to bf16 as stored, y = that layer's raw conv output read at the tile's pixels -- into the partial rows `stat`: the separate
 // reduce pass over (g, y) disappears (its y read moves here, its g read is gone)
-template <int CIN, int COUT, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false, bool BNBWD = false, bool BWDST = false>
+template <int CIN, int COUT, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false, bool BNBWD = false, bool BWDST = false, bool PIN = true>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned long long* __restrict__ stamps = nullptr) {
     static_assert(CIN == 64 || CIN == 32 || CIN == 16, "input channels");
     static_assert(!M16 || CIN % 32 == 0, "the 16x16x32 MFMA consumes 32 input channels per step");
@@ -428,6 +428,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                     s1[2 * j] += t0; s1[2 * j + 1] += t1;
                     s2[2 * j] = __builtin_fmaf(t0, v0, s2[2 * j]);
                     s2[2 * j + 1] = __builtin_fmaf(t1, v1, s2[2 * j + 1]);
+                    // pin: without it instruction selection gathers every one of these sums AFTER the pass's last MFMA (they
+                    // are pure arithmetic, the sched_barriers do not hold them), out of the matrix pipe's shadow
+                    if (PIN) asm volatile("" : "+v"(s1[2 * j]), "+v"(s1[2 * j + 1]), "+v"(s2[2 * j]), "+v"(s2[2 * j + 1]));
                 }
                 const bf16x2 p2 = {(bf16_t)v0, (bf16_t)v1};
                 pk[j] = __builtin_bit_cast(unsigned, p2);
@@ -440,6 +443,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                     s1[2 * j] += gz0; s1[2 * j + 1] += gz1;
                     s2[2 * j] = __builtin_fmaf(gz0, y0, s2[2 * j]);
                     s2[2 * j + 1] = __builtin_fmaf(gz1, y1, s2[2 * j + 1]);
+                    // (no pin here: measured 0.4 % slower on the step than the compiler's placement after the pass)
                 }
             } else if (d[ml].inb && !(STAMPS && (a.dbg & 2))) {
 #pragma unroll
@@ -759,6 +763,10 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void*
     } while (0)
 #define WM_WS_LAUNCH(CIN_, M16_) WM_WS_LAUNCH2(CIN_, 64, M16_)
     // 16x16x32 consumers by default where Cin allows (-4.5 % on the 64->64 conv in the training step, tools/ab_step.py)
+    if (g_ws_variant == 9 && Cin == 64 && CoutP == 64 && xf && st) {   // knob 9: the statistics sums left to the compiler's placement
+        hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, true, true, true, false, false, false, false>), grid, block, 0, s, a, nullptr);
+        return WM_OK;
+    }
     if (CoutP == 32) WM_WS_LAUNCH2(64, 32, true);
     else if (Cin == 64 && g_ws_variant != 1) WM_WS_LAUNCH(64, true);
     else if (Cin == 64) WM_WS_LAUNCH(64, false);

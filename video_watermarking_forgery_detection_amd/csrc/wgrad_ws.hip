@@ -48,8 +48,8 @@ __device__ __forceinline__ int swz16(int col) { return (((col >> 1) & 1) << 5) |
 __device__ __forceinline__ int slot16(int col) { return col ^ (((col >> 3) & 1) << 2); }
 
 // DYF: dy is not read but formed on the fly from (g, y) -- the apply pass of the BatchNorm backward, fused for layers whose dy
-// has no other consumer (no input gradient wanted): dy = ca * (g*[scale*y+shift > 0] - c1 - (y-mean)*invstd * c2), same
-// arithmetic and bf16 rounding as bn_bwd_kernel<APPLY>
+// has no other consumer (no input gradient wanted): dy = ca * (g*[scale*y+shift > 0] - c1 - (y-mean)*invstd * c2) in the folded
+// form of wm_common.h, bit-identical to bn_bwd_kernel<bf16, APPLY>
 // DYF == 2: the same with g[b, pixel, c] = gvec[b][c] (a globally pooled layer): the producers read y only
 template <int CI, bool XFORM, int DYF = 0>
 __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
@@ -115,13 +115,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
             dst = *reinterpret_cast<const bf16x8*>(a.x + ((size_t)(g.b * a.H + gyc) * a.W + gxc) * a.ldx + cxl);
             okbits |= ((cxok && gy == gyc && gx == gxc) ? 1u : 0u) << k;
         };
-        float bsc[8], bsh[8], bmu[8], bis[8], bca[8], bc1[8], bc2[8];
+        float bsc[8], bsh[8], bca[8], bk2[8], bk3[8];   // DYF == 1: scale, shift, ca and the folded k2, k3 (wm_bn_fold) of this thread's 8 channels
         if (DYF == 1) {
             const int CP = a.ldgv;   // row pitch of the constants (= the layer's physical channel count)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                bsc[e] = a.bscale[cdl + e]; bsh[e] = a.bshift[cdl + e]; bmu[e] = a.bmean[cdl + e]; bis[e] = a.binvstd[cdl + e];
-                bca[e] = a.bcoef[cdl + e]; bc1[e] = a.bcoef[CP + cdl + e]; bc2[e] = a.bcoef[2 * CP + cdl + e];
+                bsc[e] = a.bscale[cdl + e]; bsh[e] = a.bshift[cdl + e]; bca[e] = a.bcoef[cdl + e];
+                wm_bn_fold(a.bmean[cdl + e], a.binvstd[cdl + e], bca[e], a.bcoef[CP + cdl + e], a.bcoef[2 * CP + cdl + e], bk2[e], bk3[e]);
             }
         }
         auto load_d = [&](const TileGeo& g, int k, bf16x8& dst, bf16x8& ydst, unsigned& okbits) {
@@ -167,10 +167,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
                         const int e = 2 * pq + hlf;
                         const float gg = __builtin_bit_cast(float, hlf ? (w[pq] & 0xffff0000u) : (w[pq] << 16));
                         const float yy = __builtin_bit_cast(float, hlf ? (yw[pq] & 0xffff0000u) : (yw[pq] << 16));
-                        const float z = bsc[e] * yy + bsh[e];
-                        const float gz = z > 0.f ? gg : 0.f;
-                        const float xh = (yy - bmu[e]) * bis[e];
-                        dd[hlf] = bca[e] * (gz - bc1[e] - xh * bc2[e]);
+                        dd[hlf] = wm_bn_fold_dyg(yy, gg, bsc[e], bsh[e], bca[e], bk2[e], bk3[e]);
                     }
                     const bf16x2 pk = {(bf16_t)dd[0], (bf16_t)dd[1]};
                     w[pq] = __builtin_bit_cast(unsigned, pk);
@@ -181,23 +178,24 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
             for (int q = 0; q < 4; ++q) w[q] &= keep;
             *reinterpret_cast<u32x4*>(base + XB + pix * 128 + ((vd * 16) ^ swz16(pix & 15))) = w;
         };
-        // DYF == 2: the 8 staged y vectors of a tile -> dy, in place, one channel at a time (its constants come from the LDS,
-        // its gradient from the sample's gvec row: 8 registers live instead of 64)
+        // DYF == 2: the 8 staged y vectors of a tile -> dy, in place, one channel pair at a time (its constants come from the
+        // LDS, its gradient from the sample's gvec row: a dozen registers live instead of 64)
         auto gv_apply = [&](bf16x8 (&d)[DVP], int b) {
             if (DYF != 2) return;
             const float* gv = a.gvec + (size_t)b * a.ldgv + cdl;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int pq = e >> 1, hlf = e & 1;
-                const f32x4 ka = *reinterpret_cast<const f32x4*>(sK + (vd * 8 + e) * 8);   // scale, shift, k2, k3 (wm_bn_fold)
-                const float k3g = wm_bn_fold_g(sK[(vd * 8 + e) * 8 + 4], gv[e], ka[3]);
+            for (int pq = 0; pq < 4; ++pq) {   // a channel pair = one dword of each staged vector
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(sK + (vd * 8 + 2 * pq) * 8);       // scale, shift, k2, k3 (wm_bn_fold)
+                const f32x4 kb = *reinterpret_cast<const f32x4*>(sK + (vd * 8 + 2 * pq + 1) * 8);
+                const float k3ga = wm_bn_fold_g(sK[(vd * 8 + 2 * pq) * 8 + 4], gv[2 * pq], ka[3]);
+                const float k3gb = wm_bn_fold_g(sK[(vd * 8 + 2 * pq + 1) * 8 + 4], gv[2 * pq + 1], kb[3]);
 #pragma unroll
                 for (int k = 0; k < DVP; ++k) {
                     u32x4 w = __builtin_bit_cast(u32x4, d[k]);
-                    const float yy = __builtin_bit_cast(float, hlf ? (w[pq] & 0xffff0000u) : (w[pq] << 16));
-                    const float dd = wm_bn_fold_dy(yy, ka[0], ka[1], ka[2], ka[3], k3g);
-                    const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)dd);
-                    w[pq] = hlf ? ((w[pq] & 0xffffu) | (bits << 16)) : ((w[pq] & 0xffff0000u) | bits);
+                    const float da = wm_bn_fold_dy(__builtin_bit_cast(float, w[pq] << 16), ka[0], ka[1], ka[2], ka[3], k3ga);
+                    const float db = wm_bn_fold_dy(__builtin_bit_cast(float, w[pq] & 0xffff0000u), kb[0], kb[1], kb[2], kb[3], k3gb);
+                    const bf16x2 pk = {(bf16_t)da, (bf16_t)db};
+                    w[pq] = __builtin_bit_cast(unsigned, pk);
                     d[k] = __builtin_bit_cast(bf16x8, w);
                 }
             }

@@ -32,7 +32,7 @@ void wm_set_error(const char* fmt, ...);
 
 static inline int wm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// ---- BatchNorm+ReLU backward of a globally pooled layer, folded (bf16 path).  With g one value per (sample, channel):
+// ---- BatchNorm+ReLU backward apply, folded (bf16 path).  With g one value per (sample, channel) -- a globally pooled layer:
 //   dy = ca*(g*[z>0] - c1 - (y-mean)*invstd*c2),  z = scale*y + shift
 //      = (z > 0 ? k3 + ca*g : k3) - k2*y,         k2 = ca*invstd*c2,  k3 = k2*mean - ca*c1
 // two fused multiply-adds, a compare and a select per element.  The stand-alone apply pass (bn.hip) and the two kernels that
@@ -40,6 +40,11 @@ static inline int wm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 __device__ __forceinline__ void wm_bn_fold(float mean, float invstd, float ca, float c1, float c2, float& k2, float& k3) {
     k2 = ca * (invstd * c2);
     k3 = __builtin_fmaf(k2, mean, -(ca * c1));
+}
+// g a tensor element:  dy = ca*(g*[z>0]) + (k3 - k2*y)
+__device__ __forceinline__ float wm_bn_fold_dyg(float y, float g, float scale, float shift, float ca, float k2, float k3) {
+    const float z = __builtin_fmaf(scale, y, shift);
+    return __builtin_fmaf(ca, z > 0.f ? g : 0.f, __builtin_fmaf(-k2, y, k3));
 }
 __device__ __forceinline__ float wm_bn_fold_g(float ca, float g, float k3) { return __builtin_fmaf(ca, g, k3); }
 __device__ __forceinline__ float wm_bn_fold_dy(float y, float scale, float shift, float k2, float k3, float k3g) {
