@@ -8,8 +8,10 @@ kernels: same constructor, `train_on_batch([images, messages])` / `validate_on_b
 The backward is written out (engine.py) instead of traced by autograd, every heavy op is a HIP kernel
 behind the C ABI, parameters/gradients/moments of each optimiser live in flat f32 buffers (one fused
 Adam launch, one RCCL bucket for data parallel), and the seven logged scalars are fetched with a
-single host sync.
+single asynchronous copy that the host waits for only when a value is read (StepLosses).
 """
+import collections.abc
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -19,6 +21,57 @@ from .. import engine, ops
 from ..options import HiDDenConfiguration
 from .discriminator import Discriminator
 from .encoder_decoder import EncoderDecoder
+
+
+LOSS_KEYS = ('loss           ', 'encoder_mse    ', 'dec_mse        ', 'bitwise-error  ', 'adversarial_bce', 'discr_cover_bce',
+             'discr_encod_bce')   # hidden.py:105-113
+
+
+class StepLosses(collections.abc.Mapping):
+    """The reference's losses dict (hidden.py:105-113: name -> float), fetched from the device on first access.
+
+    The seven scalars of a step are copied to pinned host memory asynchronously; reading any value (items(), [], ...)
+    waits for that copy.  A training loop that logs every step behaves exactly like the reference's; one that only looks
+    at the losses now and then (bench.py, print_each) no longer drains the GPU queue once per step."""
+
+    def __init__(self, dev_vals, extra=None):
+        self._host = torch.empty(len(LOSS_KEYS), dtype=torch.float32, pin_memory=True)
+        self._host.copy_(dev_vals, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+        self._vals = None
+        self._extra = extra
+
+    def _resolve(self):
+        if self._vals is None:
+            self._event.synchronize()
+            self._vals = dict(zip(LOSS_KEYS, self._host.tolist()))
+            if self._extra:
+                self._vals['_extra'] = self._extra
+            self._host = None
+        return self._vals
+
+    def __getitem__(self, k):
+        return self._resolve()[k]
+
+    def __iter__(self):
+        return iter(self._resolve())
+
+    def __len__(self):
+        return len(self._resolve())
+
+    def pop(self, k, *default):
+        if k == '_extra' and self._vals is None:   # host-side data: no need to wait for the device
+            extra, self._extra = self._extra, None
+            if extra:
+                return extra
+            if default:
+                return default[0]
+            raise KeyError(k)
+        return self._resolve().pop(k, *default)
+
+    def __repr__(self):
+        return repr(self._resolve())
 
 
 class _FlatAdam:
@@ -123,6 +176,7 @@ class Hidden:
         self.tb_logger = tb_logger
         self.grad_sync = grad_sync
         self.noise_id = None  # optional deterministic choice for Combined/Noiser layers
+        self.lazy_losses = True  # train_on_batch returns StepLosses (host sync on first read) instead of a plain dict
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -222,17 +276,10 @@ class Hidden:
         g_loss_enc = enc_part.sum() / n_img
         g_loss = cfg.adversarial_loss * g_loss_adv + cfg.encoder_loss * g_loss_enc + cfg.decoder_loss * g_loss_dec
         bit_err = msg_out[1]
-        vals = torch.stack([g_loss, g_loss_enc, g_loss_dec, bit_err, g_loss_adv, d_loss_on_cover,
-                            d_loss_on_encoded]).tolist()
-        losses = {
-            'loss           ': vals[0],
-            'encoder_mse    ': vals[1],
-            'dec_mse        ': vals[2],
-            'bitwise-error  ': vals[3],
-            'adversarial_bce': vals[4],
-            'discr_cover_bce': vals[5],
-            'discr_encod_bce': vals[6],
-        }
+        vals = torch.stack([g_loss, g_loss_enc, g_loss_dec, bit_err, g_loss_adv, d_loss_on_cover, d_loss_on_encoded])
+        if self.lazy_losses:
+            return StepLosses(vals, extra_logs), (encoded, noised, decoded)
+        losses = dict(zip(LOSS_KEYS, vals.tolist()))
         if extra_logs:
             losses['_extra'] = extra_logs
         return losses, (encoded, noised, decoded)
