@@ -318,6 +318,11 @@ int wm_bce_logits(const float* logits, float target, int n, float gscale, float*
  * out2[1] = mean |clip(round(d),0,1) - m| (the bitwise error), grad_out[n] (may be NULL) = gscale * (d - m). */
 int wm_message_loss(const float* decoded, const float* messages, int n, float gscale, float* out2, float* grad_out,
                     void* stream);
+/* the seven scalars hidden.py:105-113 logs, in one launch: out7 = [w_adv*adv + w_enc*enc + w_dec*dec, enc, dec, bit error,
+ * adv, d_cover, d_encoded] with enc = sum(enc_partials[nparts]) / n_img (wm_mse_fwd_bwd's rows), msg2 = wm_message_loss's
+ * out2, adv / d_cover / d_enc = device scalars written by wm_bce_logits. */
+int wm_hidden_metrics(const float* enc_partials, int nparts, double n_img, const float* msg2, const float* adv,
+                      const float* d_cover, const float* d_enc, float w_adv, float w_enc, float w_dec, float* out7, void* stream);
 int wm_sumsq(const float* x, size_t n, float* partials, int nparts, void* stream);
 
 #ifdef __cplusplus

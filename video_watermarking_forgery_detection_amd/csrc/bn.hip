@@ -20,6 +20,38 @@ constexpr int RED_THREADS = 256;
 // finalisation kernels short: they then walk at most R = 64 rows.
 constexpr int TREE_ROWS = 64;
 __global__ __launch_bounds__(256) void tree_reduce_rows_kernel(float* __restrict__ rows, int n, int W) {
+    // thread -> (16-byte column, row sub-slice): with W = 128 a workgroup keeps 8 sub-slices x 4 loads in flight per column
+    const int j = blockIdx.x, W4 = W >> 2;
+    __shared__ float4 red[256];
+    for (int cb = 0; cb < W4; cb += 256) {
+        const int ncol = min(256, W4 - cb), nsub = 256 / ncol;
+        const int cl = threadIdx.x % ncol, sub = threadIdx.x / ncol;
+        float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        if (sub < nsub) {
+            const float4* col = reinterpret_cast<const float4*>(rows) + cb + cl;
+            const size_t st = (size_t)nsub * TREE_ROWS;
+            size_t r = (size_t)j + (size_t)sub * TREE_ROWS;
+            auto add = [](float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+            for (; r + 3 * st < (size_t)n; r += 4 * st) {
+                const float4 v0 = col[r * W4], v1 = col[(r + st) * W4], v2 = col[(r + 2 * st) * W4], v3 = col[(r + 3 * st) * W4];
+                add(a0, v0); add(a1, v1); add(a2, v2); add(a3, v3);
+            }
+            for (; r < (size_t)n; r += st) add(a0, col[r * W4]);
+            a0.x = (a0.x + a1.x) + (a2.x + a3.x); a0.y = (a0.y + a1.y) + (a2.y + a3.y);
+            a0.z = (a0.z + a1.z) + (a2.z + a3.z); a0.w = (a0.w + a1.w) + (a2.w + a3.w);
+        }
+        red[threadIdx.x] = a0;
+        __syncthreads();   // every read of row j (sub-slice 0) is done before it is overwritten
+        if (sub == 0) {
+            float4 t = red[cl];
+            for (int k = 1; k < nsub; ++k) { const float4 v = red[k * ncol + cl]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            reinterpret_cast<float4*>(rows)[(size_t)j * W4 + cb + cl] = t;
+        }
+        __syncthreads();
+    }
+}
+// row pitch not a multiple of 4 floats (the 1x1 head's 3 x (Cin+1) rows): one column per thread
+__global__ __launch_bounds__(256) void tree_reduce_rows_scalar_kernel(float* __restrict__ rows, int n, int W) {
     const int j = blockIdx.x;
     for (int c = threadIdx.x; c < W; c += 256) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -37,7 +69,8 @@ __global__ __launch_bounds__(256) void tree_reduce_rows_kernel(float* __restrict
 // returns the number of rows left
 inline int tree_reduce_rows(float* rows, int n, int W, hipStream_t s) {
     if (n <= 4 * TREE_ROWS) return n;  // the finalisation kernels walk up to 256 rows (8 slices x 32) themselves
-    hipLaunchKernelGGL(tree_reduce_rows_kernel, dim3(TREE_ROWS), dim3(256), 0, s, rows, n, W);
+    if ((W & 3) == 0 && ((uintptr_t)rows & 15) == 0) hipLaunchKernelGGL(tree_reduce_rows_kernel, dim3(TREE_ROWS), dim3(256), 0, s, rows, n, W);
+    else hipLaunchKernelGGL(tree_reduce_rows_scalar_kernel, dim3(TREE_ROWS), dim3(256), 0, s, rows, n, W);
     return TREE_ROWS;
 }
 

@@ -132,6 +132,38 @@ extern "C" int wm_message_loss(const float* decoded, const float* messages, int 
     return WM_OK;
 }
 
+// the seven logged scalars of a HiDDeN step (hidden.py:105-113) in one launch:
+// out = [w_adv*adv + w_enc*enc + w_dec*dec, enc, dec, bit error, adv, d_cover, d_encoded], enc = sum(enc_partials) / n_img
+__global__ __launch_bounds__(256) void hidden_metrics_kernel(const float* __restrict__ enc_partials, int nparts, double n_img,
+                                                             const float* __restrict__ msg2, const float* __restrict__ adv,
+                                                             const float* __restrict__ d_cover, const float* __restrict__ d_enc,
+                                                             float w_adv, float w_enc, float w_dec, float* __restrict__ out) {
+    __shared__ double red[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) a += (double)enc_partials[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float enc = (float)(red[0] / n_img), dec = msg2[0], av = adv[0];
+        out[0] = w_adv * av + w_enc * enc + w_dec * dec;
+        out[1] = enc; out[2] = dec; out[3] = msg2[1]; out[4] = av; out[5] = d_cover[0]; out[6] = d_enc[0];
+    }
+}
+
+extern "C" int wm_hidden_metrics(const float* enc_partials, int nparts, double n_img, const float* msg2, const float* adv,
+                                 const float* d_cover, const float* d_enc, float w_adv, float w_enc, float w_dec, float* out7,
+                                 void* stream) {
+    WM_REQUIRE(enc_partials && msg2 && adv && d_cover && d_enc && out7 && nparts > 0 && n_img > 0, WM_E_BADARG, "wm_hidden_metrics: bad arguments");
+    hipLaunchKernelGGL(hidden_metrics_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, enc_partials, nparts, n_img, msg2, adv, d_cover,
+                       d_enc, w_adv, w_enc, w_dec, out7);
+    WM_LAUNCH_CHECK("wm_hidden_metrics");
+    return WM_OK;
+}
+
 extern "C" int wm_sumsq(const float* x, size_t n, float* partials, int nparts, void* stream) {
     WM_REQUIRE(x && partials && n > 0 && nparts > 0 && nparts <= 2048, WM_E_BADARG, "wm_sumsq: bad arguments");
     hipLaunchKernelGGL(sumsq_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, partials, n);

@@ -13,6 +13,8 @@ Data layout in HBM
   * image inputs: 3 channels zero-padded to 16 (one 32-byte bf16 pixel);
   * parameters / gradients / Adam moments: f32, one flat buffer per network.
 """
+import contextlib
+
 import torch
 
 from . import ops
@@ -243,11 +245,34 @@ def set_compute_dtype(module, dtype):
     return module
 
 
+_deferred_bumps = None   # module -> pending count while a defer_bn_counters() block is open
+
+
+@contextlib.contextmanager
+def defer_bn_counters():
+    """inside the block, bump_bn_counters only counts; one multi-tensor add applies everything at exit (a training step
+    runs five network forwards: one launch instead of five)"""
+    global _deferred_bumps
+    if _deferred_bumps is not None:   # nested: the outer block flushes
+        yield
+        return
+    _deferred_bumps = {}
+    try:
+        yield
+    finally:
+        pend, _deferred_bumps = _deferred_bumps, None
+        if pend:
+            torch._foreach_add_([m._nbt for m in pend], [pend[m] for m in pend])
+
+
 def bump_bn_counters(module):
     """num_batches_tracked += 1 for every BatchNorm2d of `module` (one launch when the counters are flat)."""
     nbt = getattr(module, "_nbt", None)
     if nbt is not None and all(m.num_batches_tracked.data_ptr() == nbt[i].data_ptr() for i, m in enumerate(
             mm for mm in module.modules() if isinstance(mm, torch.nn.BatchNorm2d) and mm.num_batches_tracked is not None)):
+        if _deferred_bumps is not None:
+            _deferred_bumps[module] = _deferred_bumps.get(module, 0) + 1
+            return
         nbt += 1
         return
     for m in module.modules():

@@ -218,7 +218,8 @@ class Hidden:
         try:
             for n in nets:
                 n.refresh_packs()
-            return self._train_step(images, messages, B, cfg, ed, enc_net, dec_net, D, gD, gE, gDec, extra_encoded_grad, clip)
+            with engine.defer_bn_counters():
+                return self._train_step(images, messages, B, cfg, ed, enc_net, dec_net, D, gD, gE, gDec, extra_encoded_grad, clip)
         finally:
             for n in nets:
                 n.invalidate_packs()
@@ -273,10 +274,8 @@ class Hidden:
         self.optimizer_enc_dec.step()
 
         # ---------------- metrics: one host sync for all seven scalars (hidden.py:105-117)
-        g_loss_enc = enc_part.sum() / n_img
-        g_loss = cfg.adversarial_loss * g_loss_adv + cfg.encoder_loss * g_loss_enc + cfg.decoder_loss * g_loss_dec
-        bit_err = msg_out[1]
-        vals = torch.stack([g_loss, g_loss_enc, g_loss_dec, bit_err, g_loss_adv, d_loss_on_cover, d_loss_on_encoded])
+        vals = ops.hidden_metrics(enc_part, n_img, msg_out, g_loss_adv, d_loss_on_cover, d_loss_on_encoded, cfg.adversarial_loss,
+                                  cfg.encoder_loss, cfg.decoder_loss)
         if self.lazy_losses:
             return StepLosses(vals, extra_logs), (encoded, noised, decoded)
         losses = dict(zip(LOSS_KEYS, vals.tolist()))

@@ -426,6 +426,15 @@ def message_loss(decoded, messages, gscale, want_grad=True):
     return out, grad
 
 
+def hidden_metrics(enc_partials, n_img, msg2, adv, d_cover, d_enc, w_adv, w_enc, w_dec):
+    """[7] f32: loss, encoder mse, decoder mse, bitwise error, adversarial bce, D(cover) bce, D(encoded) bce (one launch)"""
+    out = torch.empty(7, device=enc_partials.device, dtype=torch.float32)
+    rc = _lib.lib().wm_hidden_metrics(_p(enc_partials), c_int(enc_partials.numel()), c_double(float(n_img)), _p(msg2), _p(adv), _p(d_cover),
+                                      _p(d_enc), c_float(w_adv), c_float(w_enc), c_float(w_dec), _p(out), _stream())
+    _lib.check(rc, "wm_hidden_metrics")
+    return out
+
+
 def colsum(partials, C, ldp, out, accumulate):
     rc = _lib.lib().wm_colsum_finalize(_p(partials), c_int(partials.shape[0]), c_int(C), c_int(ldp), _p(out),
                                        c_int(1 if accumulate else 0), _stream())
