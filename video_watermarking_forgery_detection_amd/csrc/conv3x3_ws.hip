@@ -716,7 +716,7 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
 }
 
 static int g_ws_reverse = 0;
-static int g_ws_variant = getenv("WM_WS_VARIANT") ? atoi(getenv("WM_WS_VARIANT")) : 0;   // A/B knobs -- 1: 32x32x16 MFMA consumers, 2: no XCD-aware run assignment, 3: producers at s_setprio 3, 8: no halo-edge reuse
+static int g_ws_variant = getenv("WM_WS_VARIANT") ? atoi(getenv("WM_WS_VARIANT")) : 0;   // A/B knobs -- 1: 32x32x16 MFMA consumers, 2: no XCD-aware run assignment, 3: producers at s_setprio 3, 8: no halo-edge reuse, 9: statistics sums not pinned
 extern "C" void wm_debug_ws_variant(int v) { g_ws_variant = v; }
 
 extern "C" void wm_debug_ws_direction(int reverse) { g_ws_reverse = reverse; }

@@ -255,7 +255,6 @@ class Hidden:
         enc_part, g_mse = ops.mse_fwd_bwd(encoded, images, 2.0 * cfg.encoder_loss / n_img)
         ops.axpy_(g_enc, g_mse)
         msg_out, g_dec = ops.message_loss(decoded, messages, 2.0 * cfg.decoder_loss / decoded.numel())   # mse, bit error, grad
-        g_loss_dec = msg_out[0]
         g_dec = g_dec.view_as(decoded)
         g_noised = dec_net.bwd(cDec, g_dec, gDec, accumulate=False, need_input_grad=True)
         g_from_noise = _noise_bwd(ed.noiser, cN, g_noised)
