@@ -575,3 +575,63 @@ def test_fused_bn_backward_reduce_keeps_the_training_step():
             worst = max(worst, (a - b).abs().max().item() / den)
     # bf16 dy downstream of a coefficient that moved by 1e-7 can flip a rounding here and there
     assert worst < 2e-2, worst
+
+
+@pytest.mark.parametrize("case", [(2, 40, 36, True), (1, 17, 50, False), (3, 64, 64, True), (17, 16, 16, True), (1, 33, 31, False)])
+def test_dgrad_with_fused_bn_backward_apply_tensor_gradient(case):
+    """wm_conv3x3_dgrad_applyfused (64 -> 64 layer, g a tensor): dy and dx bit-identical to wm_bn_bwd_apply followed by the plain
+    dgrad; with the feeding layer's raw output also the same partial sums as wm_conv3x3_dgrad_bwdstats."""
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, feed = case
+    C = 64
+    g = nhwc(detgen.normal((B, C, H, W), 161), torch.bfloat16)
+    y = nhwc(detgen.normal((B, C, H, W), 162, mean=0.3), torch.bfloat16)
+    w = detgen.normal((C, C, 3, 3), 163, std=0.05).cuda()
+    wpt = ops.pack_w3x3(w, C, C, torch.bfloat16, transpose=True)
+    gamma = detgen.normal((C,), 164, mean=1.0, std=0.3).cuda(); beta = detgen.normal((C,), 165, std=0.3).cuda()
+    yf = y.float()
+    mean = yf.mean((0, 1, 2)); invstd = torch.rsqrt(yf.var((0, 1, 2), unbiased=False) + 1e-5)
+    scale = gamma * invstd
+    stats = torch.stack([scale, beta - mean * scale, mean, invstd]).contiguous()
+    ry = nhwc(detgen.normal((B, C, H, W), 166, mean=-0.2), torch.bfloat16)
+    rsc = detgen.normal((C,), 167, mean=1.0, std=0.3).cuda(); rsh = detgen.normal((C,), 168, std=0.3).cuda()
+    assert ops.conv3x3_dgrad_applyfused_supported(64, 64, torch.bfloat16)
+    z = torch.zeros(C, device="cuda")
+    coef = ops.bn_bwd_coef(g, None, y, stats, C, gamma, z.clone(), z.clone(), False)
+    dy0 = ops.bn_bwd(g, None, y, stats, C, gamma, z.clone(), z.clone(), False, None, coef=coef)
+    if feed:
+        dx0, part0 = ops.conv3x3_dgrad_bwdstats(dy0, wpt, ry, rsc, rsh)
+        dy1, dx1, part1 = ops.conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry, rsc, rsh)
+        assert torch.equal(part0, part1)
+    else:
+        dx0, _ = ops.conv3x3_fwd(dy0, wpt, None, None, None, want_stats=False)
+        dy1, dx1, part1 = ops.conv3x3_dgrad_applyfused(g, y, stats, coef, wpt)
+        assert part1 is None
+    assert dy0.float().abs().max().item() > 0 and dx0.float().abs().max().item() > 0
+    assert torch.equal(dy0, dy1)
+    assert torch.equal(dx0, dx1)
+
+
+def test_fused_apply_keeps_the_training_step():
+    """the HiDDeN step with the apply pass inside the dgrad kernels is bit-identical to the step with the stand-alone pass"""
+    import ctypes
+    from video_watermarking_forgery_detection_amd import _lib
+    from video_watermarking_forgery_detection_amd.hidden_models import Hidden
+    from video_watermarking_forgery_detection_amd import noise_layers as NL
+    from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
+    L = _lib.lib()
+    outs = []
+    try:
+        for on in (1, 0):
+            L.wm_debug_apply_fuse(ctypes.c_int(on))
+            torch.manual_seed(10)
+            h = Hidden(HiDDenConfiguration(H=64, W=64), torch.device("cuda"), NL.Jpeg(50), None, compute_dtype=torch.bfloat16)
+            images = detgen.uniform((4, 3, 64, 64), 171).cuda(); messages = (detgen.uniform((4, 30), 172) > 0.5).float().cuda()
+            for _ in range(2):
+                losses, _ = h.train_on_batch([images, messages])
+            outs.append((dict(losses), [p.detach().clone() for p in list(h.encoder_decoder.parameters()) + list(h.discriminator.parameters())]))
+    finally:
+        L.wm_debug_apply_fuse(ctypes.c_int(1))
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)

@@ -37,6 +37,7 @@ struct WsArgs {
     int xcd_map;
     const float* bw_stats4; int bw_ld; const float* bw_coef; const float* bw_gvec;   // BNBWD: [scale|shift|mean|invstd][bw_ld], coef [3][bw_ld], gvec [B][bw_ld]
     const bf16_t* ry; const float* r_scale; const float* r_shift;   // BWDST: raw output [B,H,W,COUT] and scale / shift of the layer whose output gradient this kernel writes
+    const bf16_t* ay; bf16_t* dy_out;   // BNBWD == 2: x is g [B,H,W,64]; ay the layer's raw output, dy_out where dy is written (both dense)
     int reverse;  // walk the workgroup's run of tiles backwards (Infinity Cache reuse of the previous kernel's tail)
 };
 
@@ -60,11 +61,15 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 // BNBWD (dgrad of a layer whose output was globally pooled): the input tensor is that layer's raw conv output y, and the
 // producers turn it into dy = ca * (gvec[b]*[scale*y+shift > 0] - c1 - (y-mean)*invstd * c2) while staging -- the
 // BatchNorm-backward APPLY pass, fused (the folded form of wm_common.h: bit-identical to bn_bwd_kernel<bf16, APPLY, GVEC>)
+// BNBWD == 2 (dgrad of an ordinary layer, gradient g a tensor): the producers read g AND the layer's raw output y, form dy the
+// same way (wm_bn_fold_dyg), publish it to the LDS tile and write each tile's own 16x16 pixels of it to `dy_out` for the weight
+// gradient that follows: the stand-alone apply pass (402 MB, HBM-bound) is gone for 268 MB inside this kernel.  Two input
+// streams leave no registers for a second tile in flight, so this mode loads one tile ahead instead of two.
 // BWDST (dgrad whose output is the gradient g wrt a ConvBNRelu's ReLU output): the consumers also reduce that layer's
 // BatchNorm-backward sums from the tile they hold -- per channel sum(gz) and sum(gz*y), gz = g*[scale*y+shift > 0], g rounded
 // to bf16 as stored, y = that layer's raw conv output read at the tile's pixels -- into the partial rows `stat`: the separate
 // reduce pass over (g, y) disappears (its y read moves here, its g read is gone)
-template <int CIN, int COUT, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false, bool BNBWD = false, bool BWDST = false, bool PIN = true>
+template <int CIN, int COUT, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false, int BNBWD = 0, bool BWDST = false, bool PIN = true>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned long long* __restrict__ stamps = nullptr) {
     static_assert(CIN == 64 || CIN == 32 || CIN == 16, "input channels");
     static_assert(!M16 || CIN % 32 == 0, "the 16x16x32 MFMA consumes 32 input channels per step");
@@ -161,6 +166,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             }
         }
         static_assert(!(BNBWD && XFORM), "one input transform at a time");
+        static_assert(BNBWD != 2 || CIN == 64, "the tensor-gradient form is built for 64-channel layers");
+        float kca[8];   // BNBWD == 2: ca of the 8 channels
         float kb[4][8], k3g[8];   // BNBWD: scale, shift, k2, k3 of this thread's 8 channels (wm_bn_fold); k3g = k3 + ca*gvec[sample being published]
         int gvb = -1;
 #pragma unroll
@@ -172,10 +179,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 kb[0][e] = a.bw_stats4[c]; kb[1][e] = a.bw_stats4[a.bw_ld + c];
                 wm_bn_fold(a.bw_stats4[2 * a.bw_ld + c], a.bw_stats4[3 * a.bw_ld + c], a.bw_coef[c], a.bw_coef[a.bw_ld + c],
                            a.bw_coef[2 * a.bw_ld + c], kb[2][e], kb[3][e]);
+                kca[e] = a.bw_coef[c];
             }
         }
         auto load_gvec = [&](int b) {   // wave-uniform: a run of tiles rarely crosses a sample
-            if (BNBWD && b != gvb) {
+            if (BNBWD == 1 && b != gvb) {
                 gvb = b;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) k3g[e] = wm_bn_fold_g(a.bw_coef[vec * 8 + e], a.bw_gvec[(size_t)b * a.bw_ld + vec * 8 + e], kb[3][e]);
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         }
         const bool last_live = EDGE ? (((ptid + 256 * (XVP - 1 - KMAIN)) >> 3) < 36) : (((ptid + 256 * (XVP - 1)) / VPP) < NPIX);
         // does tile T start with the two columns its predecessor in the run ended with?
-        auto reuse_of = [&](int T) { return EDGE && !a.reverse && !(a.dbg & 64) && T > t_begin && (T % a.tilesX) != 0; };
+        auto reuse_of = [&](int T) { return EDGE && BNBWD != 2 && !a.reverse && !(a.dbg & 64) && T > t_begin && (T % a.tilesX) != 0; };
         // loads: always a valid address, never under a per-lane branch; the branches on `interior` are wave-uniform
         auto is_interior = [&](const TileGeo& g) {
             return g.ty0 >= 1 && g.ty0 + TH + 1 <= a.H && g.tx0 >= 1 && g.tx0 + TW + 1 <= a.W;
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                     w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
                 }
             }
-            if (BNBWD) {
+            if (BNBWD == 1) {
 #pragma unroll
                 for (int pq = 0; pq < 4; ++pq) {
                     const float d0 = wm_bn_fold_dy(__builtin_bit_cast(float, w[pq] << 16), kb[0][2 * pq], kb[1][2 * pq], kb[2][2 * pq], kb[3][2 * pq], k3g[2 * pq]);
@@ -276,6 +284,73 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             for (int q = 0; q < 4; ++q) w[q] &= keep;
             if (k + 1 < XVP || last_live) *reinterpret_cast<u32x4*>(sX + lds[k]) = w;
         };
+        if constexpr (BNBWD == 2) {
+            // vectors whose halo pixel is one of the tile's own 16x16 pixels: those are written out as dy
+            unsigned wmask = 0;
+#pragma unroll
+            for (int k = 0; k < XVP; ++k)
+                if (hpy[k] >= 1 && hpy[k] <= TH && hpx[k] >= 1 && hpx[k] <= TW && (k + 1 < XVP || last_live)) wmask |= 1u << k;
+            bf16x8 dG[XVP], dY[XVP];
+            unsigned ok = 0;
+            auto load_both = [&](const TileGeo& g) {
+                if (is_interior(g)) {
+                    const bf16_t* gt = tile_ptr(g);
+                    const bf16_t* yt = a.ay + (gt - a.x);
+#pragma unroll
+                    for (int k = 0; k < XVP; ++k) { load_interior(gt, k, dG[k]); load_interior(yt, k, dY[k]); }
+                    ok = 0xffffffffu;
+                } else {
+                    const bf16_t* gb = image_ptr(g);
+                    const bf16_t* yb = a.ay + (gb - a.x);
+                    unsigned unused = 0;
+                    ok = 0;
+#pragma unroll
+                    for (int k = 0; k < XVP; ++k) { load_border(g, gb, k, dG[k], ok); load_border(g, yb, k, dY[k], unused); }
+                }
+            };
+            auto put_both = [&](bf16_t* sX, const TileGeo& g) {
+                const long tofs = ((long)(g.b * a.H + g.ty0 - 1) * a.W + (g.tx0 - 1)) * CIN;   // + rel[k] (ldx == CIN): the pixel's offset
+#pragma unroll
+                for (int k = 0; k < XVP; ++k) {
+                    u32x4 w = __builtin_bit_cast(u32x4, dG[k]);
+                    const u32x4 wy = __builtin_bit_cast(u32x4, dY[k]);
+#pragma unroll
+                    for (int pq = 0; pq < 4; ++pq) {
+                        const float d0 = wm_bn_fold_dyg(__builtin_bit_cast(float, wy[pq] << 16), __builtin_bit_cast(float, w[pq] << 16), kb[0][2 * pq],
+                                                        kb[1][2 * pq], kca[2 * pq], kb[2][2 * pq], kb[3][2 * pq]);
+                        const float d1 = wm_bn_fold_dyg(__builtin_bit_cast(float, wy[pq] & 0xffff0000u), __builtin_bit_cast(float, w[pq] & 0xffff0000u),
+                                                        kb[0][2 * pq + 1], kb[1][2 * pq + 1], kca[2 * pq + 1], kb[2][2 * pq + 1], kb[3][2 * pq + 1]);
+                        const bf16x2 pk = {(bf16_t)d0, (bf16_t)d1};
+                        w[pq] = __builtin_bit_cast(unsigned, pk);
+                    }
+                    const unsigned inimg = (ok >> k) & 1u, keep = 0u - inimg;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[q] &= keep;
+                    if (k + 1 < XVP || last_live) *reinterpret_cast<u32x4*>(sX + lds[k]) = w;
+                    if (((wmask >> k) & 1u) && inimg) *reinterpret_cast<u32x4*>(a.dy_out + tofs + rel[k]) = w;
+                }
+            };
+            if (t_begin < t_end) {
+                const TileGeo g0 = geo(t_begin);
+                load_both(g0);
+                put_both(sX0, g0);
+            }
+            __syncthreads();  // filter + first halo tile visible
+            stamp(-1);
+            for (int tile = t_begin; tile < t_end; ++tile) {
+                if (tile + 1 < t_end) {
+                    const TileGeo g1 = geo(tile + 1);
+                    load_both(g1);
+                    put_both(sX0 + (((tile - t_begin) & 1) ^ 1) * (NPIX * CIN), g1);
+                }
+                stamp(0);
+                stamp(1);
+                __syncthreads();
+                stamp(2);
+            }
+            if (STATS || BWDST) __syncthreads();
+            return;
+        }
         bf16x8 dA[XVP], dB[XVP];
         unsigned okA = 0, okB = 0;
         if (t_begin < t_end) load_tile(geo(t_begin), dA, okA, false);
@@ -295,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             const bf16_t* sXc = sX0 + ((tile - t_begin) & 1) * (NPIX * CIN);   // the tile the consumers are on: left neighbour of tile+1
             const bool have_next = tile + 2 < t_end && !(STAMPS && (a.dbg & 4));
             const bool reuse_cur = reuse_of(tile + 1), reuse_nxt = reuse_of(tile + 2);
-            if (BNBWD && tile + 1 < t_end) load_gvec(geo(tile + 1).b);
+            if (BNBWD == 1 && tile + 1 < t_end) load_gvec(geo(tile + 1).b);
             if (have_next) {
                 const TileGeo g2 = geo(tile + 2);
                 if (is_interior(g2)) {
@@ -708,7 +783,7 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
     a.in_shift = in_shift; a.y = (bf16_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
     const int wgs = a.ntiles < 256 ? a.ntiles : 256;
-    a.tiles_per_wg = wm_cdiv(a.ntiles, wgs); a.reverse = 0; a.bw_stats4 = nullptr; a.bw_ld = 0; a.bw_coef = nullptr; a.bw_gvec = nullptr; a.ry = nullptr; a.r_scale = nullptr; a.r_shift = nullptr;
+    a.tiles_per_wg = wm_cdiv(a.ntiles, wgs); a.reverse = 0; a.bw_stats4 = nullptr; a.bw_ld = 0; a.bw_coef = nullptr; a.bw_gvec = nullptr; a.ry = nullptr; a.r_scale = nullptr; a.r_shift = nullptr; a.ay = nullptr; a.dy_out = nullptr;
     const dim3 grid((unsigned)wm_cdiv(a.ntiles, a.tiles_per_wg)), block(512);
     if (in_scale && stat) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, true, true, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
     else hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
@@ -726,7 +801,7 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void*
                            const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
                            hipStream_t s, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
                            const float* bw_gvec = nullptr, const void* ry = nullptr, const float* r_scale = nullptr,
-                           const float* r_shift = nullptr) {
+                           const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr) {
     WsArgs a;
     a.dbg = g_ws_variant == 3 ? 8 : (g_ws_variant == 8 ? 64 : 0); a.xcd_map = g_ws_variant != 2;
     a.x = (const bf16_t*)x; a.ldx = ldx; a.wp = (const bf16_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
@@ -735,22 +810,29 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void*
     a.reverse = g_ws_reverse;
     a.bw_stats4 = bw_stats4; a.bw_ld = bw_ld; a.bw_coef = bw_coef; a.bw_gvec = bw_gvec;
     a.ry = (const bf16_t*)ry; a.r_scale = r_scale; a.r_shift = r_shift;
+    a.ay = (const bf16_t*)ay; a.dy_out = (bf16_t*)dy_out;
     const dim3 grid((unsigned)wgs), block(512);
+    if (ay) {   // dgrad with the BatchNorm-backward apply (tensor gradient) fused; x = g, dy written out for the weight gradient
+        if (Cin != 64 || CoutP != 64 || ldx != 64 || in_scale || !bw_stats4 || !bw_coef || bw_gvec || !dy_out || (ry != nullptr) != (stat != nullptr)) return WM_E_SHAPE;
+        if (ry) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, 2, true>), grid, block, 0, s, a, nullptr);
+        else hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, 2, false>), grid, block, 0, s, a, nullptr);
+        return WM_OK;
+    }
     if (ry) {   // dgrad that also reduces the BatchNorm-backward sums of the layer it feeds
         if (CoutP != 64 || in_scale || !stat || (Cin != 64 && Cin != 32)) return WM_E_SHAPE;
         if (bw_stats4) {
-            if (Cin == 64) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, true, true>), grid, block, 0, s, a, nullptr);
-            else hipLaunchKernelGGL((conv3x3_ws_kernel<32, 64, false, false, true, false, true, true>), grid, block, 0, s, a, nullptr);
+            if (Cin == 64) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, 1, true>), grid, block, 0, s, a, nullptr);
+            else hipLaunchKernelGGL((conv3x3_ws_kernel<32, 64, false, false, true, false, 1, true>), grid, block, 0, s, a, nullptr);
         } else {
-            if (Cin == 64) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, false, true>), grid, block, 0, s, a, nullptr);
-            else hipLaunchKernelGGL((conv3x3_ws_kernel<32, 64, false, false, true, false, false, true>), grid, block, 0, s, a, nullptr);
+            if (Cin == 64) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, 0, true>), grid, block, 0, s, a, nullptr);
+            else hipLaunchKernelGGL((conv3x3_ws_kernel<32, 64, false, false, true, false, 0, true>), grid, block, 0, s, a, nullptr);
         }
         return WM_OK;
     }
     if (bw_stats4) {   // dgrad with the BatchNorm-backward apply (per-sample gradient rows) fused: 64 or 32 -> 64
         if ((Cin != 64 && Cin != 32) || CoutP != 64 || in_scale || stat) return WM_E_SHAPE;
-        if (Cin == 64) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, true>), grid, block, 0, s, a, nullptr);
-        else hipLaunchKernelGGL((conv3x3_ws_kernel<32, 64, false, false, true, false, true>), grid, block, 0, s, a, nullptr);
+        if (Cin == 64) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, 1>), grid, block, 0, s, a, nullptr);
+        else hipLaunchKernelGGL((conv3x3_ws_kernel<32, 64, false, false, true, false, 1>), grid, block, 0, s, a, nullptr);
         return WM_OK;
     }
     const bool xf = in_scale != nullptr, st = stat != nullptr;
@@ -764,7 +846,7 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void*
 #define WM_WS_LAUNCH(CIN_, M16_) WM_WS_LAUNCH2(CIN_, 64, M16_)
     // 16x16x32 consumers by default where Cin allows (-4.5 % on the 64->64 conv in the training step, tools/ab_step.py)
     if (g_ws_variant == 9 && Cin == 64 && CoutP == 64 && xf && st) {   // knob 9: the statistics sums left to the compiler's placement
-        hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, true, true, true, false, false, false, false>), grid, block, 0, s, a, nullptr);
+        hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, true, true, true, false, 0, false, false>), grid, block, 0, s, a, nullptr);
         return WM_OK;
     }
     if (CoutP == 32) WM_WS_LAUNCH2(64, 32, true);

@@ -380,6 +380,26 @@ def conv3x3_dgrad_bwdstats(src, wpt, ry, r_scale, r_shift, gvec=None, stats=None
     return dx, part
 
 
+def conv3x3_dgrad_applyfused_supported(CoutY, CinP, dtype):
+    return bool(_lib.lib().wm_conv3x3_dgrad_applyfused_supported(c_int(CoutY), c_int(CinP), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32)))
+
+
+def conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry=None, r_scale=None, r_shift=None):
+    """64 -> 64 layer, gradient g a dense tensor: the BatchNorm-backward apply pass inside the input-gradient kernel.
+    Returns (dy, dx, partials or None): dy for the weight gradient, dx = conv3x3(dy, wpt), partials = the feeding layer's
+    BatchNorm-backward sums when its raw output ry (+ r_scale, r_shift) is given."""
+    B, H, W, C = y.shape
+    assert C == 64 and g.shape == y.shape and g.is_contiguous() and y.is_contiguous() and tuple(wpt.shape) == (9, 64, 64)
+    assert stats.is_contiguous() and coef.is_contiguous() and (ry is None or (ry.shape == y.shape and ry.is_contiguous()))
+    dy = torch.empty_like(y)
+    dx = torch.empty_like(y)
+    part = torch.empty(conv3x3_nparts(B, H, W, 64, 64, y.dtype), 2, 64, device=y.device, dtype=torch.float32) if ry is not None else None
+    rc = _lib.lib().wm_conv3x3_dgrad_applyfused(_p(g), _p(y), _p(stats), _p(coef), _p(wpt), _p(dy), _p(dx), _p(ry), _p(r_scale), _p(r_shift),
+                                                _p(part), c_int(B), c_int(H), c_int(W), c_int(dtype_id(y)), _stream())
+    _lib.check(rc, "wm_conv3x3_dgrad_applyfused")
+    return dy, dx, part
+
+
 def linear_head_fwd(pooled, w, bias, I):
     """pooled [B,ldp] f32 (first I columns used), w [O,I], bias [O] -> [B,O]"""
     _need_cuda(pooled, w)
