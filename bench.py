@@ -13,12 +13,15 @@ decoder 7x64, discriminator 3x64; bf16 activations, f32 accumulate/params; synth
 random-init weights; inputs resident in HBM before the timed region.  One step = one batch.
 
 The JSON line carries, besides the driver contract:
-  roofline     -- the dominant kernel family (conv3x3_ws_kernel<64,true,true,M16>: bf16 64->64 conv3x3 implicit
-                  GEMM with fused BN+ReLU input and BatchNorm statistics, 15 launches / step),
-                  77.3 GFLOP algorithmic per launch at B=16 256x256, duration measured live with
-                  events on the launch stream inside the timed region; peak = 2.5 PFLOP/s dense bf16;
-                  `traffic` = HBM bytes / launch from the committed rocprofv3 PMC passes of this round
-                  (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled as the gfx950 guide prescribes)
+  roofline     -- the dominant kernel (most time per step, 12 launches): conv3x3_ws_kernel<64,64,...,BNBWD=2,BWDST> = the
+                  64->64 input-gradient conv with the BatchNorm-backward apply pass and the feeding layer's BatchNorm sums
+                  fused.  Its 77.3 GFLOP ride on 5 tensor passes (reads g, y, y of the layer below; writes dy, dx =
+                  671 MB algorithmic per launch at B=16 256x256: 115 FLOP/B, below the 312 FLOP/B ridge), so the bound
+                  is HBM: achieved = algorithmic bytes / launch duration measured live with events on the launch stream
+                  inside the timed region; peak = 8 TB/s; `traffic` = HBM bytes / launch from the committed rocprofv3
+                  PMC passes of this round (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled as the gfx950 guide says)
+  roofline_mfma -- the runner-up, conv3x3_ws_kernel<64,64,XFORM,STATS,M16> (forward 64->64 conv, fused BN+ReLU input and
+                  BatchNorm statistics, 15 launches / step): 77.3 GFLOP per launch against 2.5 PFLOP/s dense bf16
   cpu_baseline -- the oracle (oracle/hidden_ref.py, torch CPU fp32, all host cores) on a bounded
                   sample of the same step (rank 0, N=1 only)
 """
@@ -66,13 +69,13 @@ def cpu_baseline(size, frames):
             "sample": f"1 step of the same HiDDeN-order step on {frames} frames {size}x{size} (oracle/hidden_ref.py, torch {torch.__version__} CPU fp32, {dt:.1f} s)"}
 
 
-def pmc_traffic(args, S, B):
-    """HBM bytes per launch of the dominant kernel, from this round's committed PMC passes (same workload only)."""
+def pmc_traffic(args, S, B, key="hbm_bytes_per_launch"):
+    """HBM bytes per launch of the dominant kernel (key: of the runner-up), from this round's committed PMC passes (same workload only)."""
     if args.dtype != "bf16" or S != 256 or B != 16:
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
+            return json.load(f)[key]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -125,8 +128,10 @@ def main():
 
     for _ in range(args.warmup):
         h.train_on_batch([images, messages])
-    # dominant kernel: bf16/f32 conv3x3 64->64 with fused BN+ReLU input transform (15 launches / step)
-    timer = ops.KernelTimer(lambda name, i: name == "conv3x3_fwd" and i["Cin"] == 64 and i["CoutP"] == 64 and i["xform"])
+    # the two heaviest kernels: the fused 64->64 input-gradient conv (12 launches / step, bf16 only) and the forward 64->64
+    # conv with fused BN+ReLU input transform (15 launches / step)
+    timer = ops.KernelTimer(lambda name, i: (name == "conv3x3_dgrad_applyfused" and i["feed"]) or
+                            (name == "conv3x3_fwd" and i["Cin"] == 64 and i["CoutP"] == 64 and i["xform"]))
     ops.set_kernel_timer(timer)
     barrier()
     t0 = time.perf_counter()
@@ -139,13 +144,32 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    kms = timer.elapsed_ms()
+    kms = timer.elapsed_ms("conv3x3_fwd")
+    dms = timer.elapsed_ms("conv3x3_dgrad_applyfused")
     if rank == 0:
         fps = world * B * args.steps / dt
+        esz = 2 if dtype == torch.bfloat16 else 4
+        tensor_bytes = float(B * S * S * 64 * esz)
         flops_per_launch = 2.0 * B * S * S * 64 * 9 * 64
         avg_ms = sum(kms) / max(1, len(kms))
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         peak = 2500.0 if dtype == torch.bfloat16 else 157.3
+        mfma = {"bound": "mfma",
+                "kernel": ("conv3x3_ws_kernel<64,64,XFORM,STATS,M16>" if dtype == torch.bfloat16 else "conv3x3_kernel<float,64,true>") + " (forward 64->64 implicit GEMM, fused BN+ReLU input, BN statistics)",
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": pmc_traffic(args, S, B, "fwd_hbm_bytes_per_launch"), "launches_timed": len(kms), "avg_launch_ms": avg_ms,
+                "flops_per_launch": flops_per_launch, "hbm_algorithmic_bytes_per_launch": 2.0 * tensor_bytes}
+        if dms:   # bf16: the fused input-gradient kernel is the dominant one, and it is HBM-bound
+            davg = sum(dms) / len(dms)
+            dbytes = 5.0 * tensor_bytes   # reads g, y, y of the layer below; writes dy, dx
+            roof = {"bound": "hbm",
+                    "kernel": "conv3x3_ws_kernel<64,64,M16,BNBWD=2,BWDST> (64->64 input-gradient implicit GEMM + BatchNorm-backward apply + the feeding layer's BatchNorm sums)",
+                    "achieved": dbytes / (davg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": dbytes / (davg * 1e-3) / 1e9 / 8000.0,
+                    "traffic": pmc_traffic(args, S, B), "launches_timed": len(dms), "avg_launch_ms": davg,
+                    "algorithmic_bytes_per_launch": dbytes, "flops_per_launch": flops_per_launch,
+                    "flops_frac_of_mfma_peak": flops_per_launch / (davg * 1e-3) / 1e12 / peak}
+        else:
+            roof = mfma
         out = {
             "metric": "frames/sec training step (embed->JPEG->decode), 256x256",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -153,12 +177,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"C2: HiDDeN GAN step enc(4x64)->{args.noise}->dec(7x64)+disc(3x64), L=30, {S}x{S}, batch {B}/GPU",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma",
-                         "kernel": ("conv3x3_ws_kernel<64,true,true,M16>" if dtype == torch.bfloat16 else "conv3x3_kernel<float,64,true>") + " (64->64 implicit GEMM, fused BN+ReLU input, BN statistics)",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic(args, S, B), "launches_timed": len(kms), "avg_launch_ms": avg_ms,
-                         "flops_per_launch": flops_per_launch,
-                         "hbm_algorithmic_bytes_per_launch": 2.0 * B * S * S * 64 * (2 if dtype == torch.bfloat16 else 4)},
+            "roofline": roof,
+            "roofline_mfma": mfma,
             "step_flops_frac_of_peak": (249.0e9 * (S / 256.0) ** 2 * world * B * args.steps / dt) / (peak * 1e12 * world),
             "last_losses": {k.strip(): v for k, v in losses.items()},
         }

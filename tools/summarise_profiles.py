@@ -28,10 +28,14 @@ for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
             g.write(f"\"{k[:120]}\",{len(v)},{sum(v)/len(v):.2f}\n")
     out[name] = {k: sum(v) / len(v) for k, v in agg.items()}
-dom = [k for k in out["FETCH_SIZE"] if "conv3x3_ws_kernel<64, 64, true, true" in k]
-k = dom[0]
-res = {"kernel": k, "FETCH_SIZE_KB": out["FETCH_SIZE"][k], "WRITE_SIZE_KB": out["WRITE_SIZE"][k],
-       "hbm_bytes_per_launch": (2.0 * out["FETCH_SIZE"][k] + out["WRITE_SIZE"][k]) * 1024.0,
+def traffic(pattern):
+    k = [k for k in out["FETCH_SIZE"] if pattern in k][0]
+    return k, out["FETCH_SIZE"][k], out["WRITE_SIZE"][k], (2.0 * out["FETCH_SIZE"][k] + out["WRITE_SIZE"][k]) * 1024.0
+# dominant kernel: the fused 64->64 input-gradient conv (BNBWD = 2, BWDST); runner-up: the forward 64->64 conv (XFORM, STATS)
+k, f, w, b = traffic("conv3x3_ws_kernel<64, 64, false, false, true, false, 2, true")
+k2, f2, w2, b2 = traffic("conv3x3_ws_kernel<64, 64, true, true")
+res = {"kernel": k, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": b,
+       "fwd_kernel": k2, "fwd_FETCH_SIZE_KB": f2, "fwd_WRITE_SIZE_KB": w2, "fwd_hbm_bytes_per_launch": b2,
        "note": "FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads); KB = 1024 B"}
 json.dump(res, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -394,8 +394,10 @@ def conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry=None, r_scale=None, r_sh
     dy = torch.empty_like(y)
     dx = torch.empty_like(y)
     part = torch.empty(conv3x3_nparts(B, H, W, 64, 64, y.dtype), 2, 64, device=y.device, dtype=torch.float32) if ry is not None else None
-    rc = _lib.lib().wm_conv3x3_dgrad_applyfused(_p(g), _p(y), _p(stats), _p(coef), _p(wpt), _p(dy), _p(dx), _p(ry), _p(r_scale), _p(r_shift),
-                                                _p(part), c_int(B), c_int(H), c_int(W), c_int(dtype_id(y)), _stream())
+    info = {"B": B, "H": H, "W": W, "feed": ry is not None, "dtype": y.dtype}
+    rc = _timed("conv3x3_dgrad_applyfused", info, lambda: _lib.lib().wm_conv3x3_dgrad_applyfused(
+        _p(g), _p(y), _p(stats), _p(coef), _p(wpt), _p(dy), _p(dx), _p(ry), _p(r_scale), _p(r_shift), _p(part), c_int(B), c_int(H), c_int(W),
+        c_int(dtype_id(y)), _stream()))
     _lib.check(rc, "wm_conv3x3_dgrad_applyfused")
     return dy, dx, part
 
@@ -564,11 +566,11 @@ _TIMER = None
 class KernelTimer:
     def __init__(self, match):
         self.match = match  # callable(name, info) -> bool
-        self.pairs = []
+        self.pairs = []     # (name, start event, end event)
 
-    def elapsed_ms(self):
+    def elapsed_ms(self, name=None):
         torch.cuda.synchronize()
-        return [a.elapsed_time(b) for a, b in self.pairs]
+        return [a.elapsed_time(b) for n, a, b in self.pairs if name is None or n == name]
 
 
 def set_kernel_timer(timer):
@@ -585,7 +587,7 @@ def _timed(name, info, launch):
     a.record()
     r = launch()
     b.record()
-    t.pairs.append((a, b))
+    t.pairs.append((name, a, b))
     return r
 
 
