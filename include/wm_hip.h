@@ -243,6 +243,18 @@ int wm_avgpool_slices(size_t hw);
 int wm_bnrelu_avgpool(const void* y, int ldy, const float* scale, const float* shift, float* out,
                       float* ws /* f32[B * wm_avgpool_slices(hw) * CP] */, int B, size_t hw, int CP, int dtype,
                       void* stream);
+/* Training form: out3 f32[3][B][CP] = the pooled mean, and per (sample, channel) the number of active pixels N+ = #[z > 0]
+ * and S+ = the sum of y over them (ws: 3x the size above).  The pooled layer's gradient is one value per (sample, channel),
+ * so its BatchNorm-backward sums follow from N+ / S+ without a pass over y: wm_pooled_bn_bwd_rows writes the B partial rows
+ * rows f32[B][2][CP] = (gvec*N+, gvec*S+) for wm_bn_bwd_finalize_raw (replaces wm_bn_bwd_reduce with gvec). */
+int wm_bnrelu_avgpool_stats(const void* y, int ldy, const float* scale, const float* shift, float* out3, float* ws, int B,
+                            size_t hw, int CP, int dtype, void* stream);
+int wm_pooled_bn_bwd_rows(const float* gvec, const float* npos, const float* ysum, int B, int CP, float* rows, void* stream);
+/* the two steps in one launch: dgamma, dbeta, coef of the pooled layer straight from (gvec, N+, S+) */
+int wm_bn_bwd_finalize_pooled(const float* gvec, const float* npos, const float* ysum, int B, int C, int CP, double count,
+                              const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                              int accumulate, float* coef, void* stream);
+int wm_pool_stats_enabled(void);
 /* 1x1 conv Cin->Cout (Cout <= 4) on relu(scale*y+shift): replaces nn.Conv2d(64,3,1) at
  * hidden_models/encoder.py:28,42 and the sigmoid head of network/UNet.py:41-43,65.
  * w f32[Cout,Cin], bias f32[Cout]; out f32 NCHW [B,Cout,H,W]; act 0 = none, 1 = sigmoid. */

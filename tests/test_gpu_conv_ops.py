@@ -635,3 +635,36 @@ def test_fused_apply_keeps_the_training_step():
     assert outs[0][0] == outs[1][0]
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", [(3, 40, 36, 64, torch.bfloat16), (2, 17, 50, 30, torch.bfloat16), (2, 32, 32, 64, torch.float32)])
+def test_pooled_layer_bn_backward_sums_from_forward_pool_statistics(case):
+    """wm_bnrelu_avgpool_stats (pooled mean + active-pixel count N+ and sum S+ per sample and channel) + wm_pooled_bn_bwd_rows +
+    wm_bn_bwd_finalize_raw give the same pooled output, dgamma / dbeta / coef as wm_bnrelu_avgpool + wm_bn_bwd_reduce(gvec)."""
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, C, dt = case
+    CP = 32 * ((C + 31) // 32)
+    y = nhwc(detgen.normal((B, C, H, W), 181, mean=0.25), dt, CP)
+    gamma = detgen.normal((C,), 182, mean=1.0, std=0.3).cuda(); beta = detgen.normal((C,), 183, std=0.3).cuda()
+    yf = y.float()[..., :C]
+    mean = yf.mean((0, 1, 2)); invstd = torch.rsqrt(yf.var((0, 1, 2), unbiased=False) + 1e-5)
+    stats = torch.zeros(4, CP, device="cuda")
+    stats[0, :C] = gamma * invstd; stats[1, :C] = beta - mean * gamma * invstd; stats[2, :C] = mean; stats[3, :C] = invstd
+    gvec = torch.zeros(B, CP, device="cuda"); gvec[:, :C] = detgen.normal((B, C), 184).cuda() / (H * W)
+    p0 = ops.bnrelu_avgpool(y, stats[0], stats[1])
+    p1, ps = ops.bnrelu_avgpool_stats(y, stats[0], stats[1])
+    torch.testing.assert_close(p1, p0, rtol=1e-6, atol=1e-7)
+    z = stats[0] * y.float() + stats[1]
+    assert torch.equal(ps[0], (z > 0).float().sum((1, 2)))
+    dg0 = torch.zeros(C, device="cuda"); db0 = torch.zeros(C, device="cuda")
+    c0 = ops.bn_bwd_coef(None, gvec, y, stats, C, gamma, dg0, db0, False)
+    dg1 = torch.full((C,), 0.5, device="cuda"); db1 = torch.full((C,), -0.5, device="cuda")
+    c1 = ops.bn_bwd_coef_raw(ops.pooled_bwd_rows(gvec, ps), y, stats, C, gamma, dg1, db1, False)
+    sc = dg0.abs().max().item() + db0.abs().max().item()
+    torch.testing.assert_close(db1, db0, rtol=1e-4, atol=1e-5 * sc)
+    torch.testing.assert_close(dg1, dg0, rtol=1e-4, atol=1e-5 * sc)
+    torch.testing.assert_close(c1, c0, rtol=1e-4, atol=1e-5 * c0.abs().max().item())
+    dg2 = torch.full((C,), 0.5, device="cuda"); db2 = torch.full((C,), -0.5, device="cuda")
+    c2 = ops.bn_bwd_coef_pooled(gvec, ps, y, stats, C, gamma, dg2, db2, False)     # the two steps in one launch
+    torch.testing.assert_close(c2, c1, rtol=1e-6, atol=1e-7 * c0.abs().max().item())
+    torch.testing.assert_close(dg2, dg1, rtol=1e-6, atol=1e-7 * sc); torch.testing.assert_close(db2, db1, rtol=1e-6, atol=1e-7 * sc)

@@ -235,7 +235,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ invstd, float* dgamma,
                                                               float* dbeta, int accumulate, float* coef,
-                                                              const float* __restrict__ raw_mean) {
+                                                              const float* __restrict__ raw_mean,
+                                                              const float* __restrict__ pgv = nullptr,
+                                                              const float* __restrict__ pn = nullptr,
+                                                              const float* __restrict__ ps = nullptr) {
+    // pgv != nullptr (a globally pooled layer): row p is sample p's (gv*N+, gv*S+) formed here from the pooled statistics
     // 8 channels x 32 row slices per workgroup: every thread's <= 8 row loads are independent and in flight together
     __shared__ double s1[32][8], s2[32][8];
     const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
@@ -244,8 +248,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     if (c < CP) {
 #pragma unroll 8
         for (int p = sl; p < nparts; p += 32) {
-            a1 += (double)partials[((size_t)p * 2 + 0) * CP + c];
-            a2 += (double)partials[((size_t)p * 2 + 1) * CP + c];
+            if (pgv) {
+                const float gv = pgv[(size_t)p * CP + c];
+                a1 += (double)(gv * pn[(size_t)p * CP + c]);
+                a2 += (double)(gv * ps[(size_t)p * CP + c]);
+            } else {
+                a1 += (double)partials[((size_t)p * 2 + 0) * CP + c];
+                a2 += (double)partials[((size_t)p * 2 + 1) * CP + c];
+            }
         }
     }
     s1[sl][cl] = a1; s2[sl][cl] = a2;
@@ -286,8 +296,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
 }
 
 // ------------------------------------------------------------------ avg pool of relu(scale*y+shift)
-// grid (S slices, B).  ws [B][S][CP]
-template <typename T>
+// grid (S slices, B).  ws [B][S][NPL][CP]; NPL = 1: the pooled sums; NPL = 3 (training): also, per (sample, channel), the
+// number of active pixels N+ = #[z > 0] and S+ = sum of y over them.  With the pooled layer's gradient one value gv[b,c] per
+// (sample, channel), its BatchNorm-backward sums are sum(gz) = sum_b gv N+ and sum(gz*y) = sum_b gv S+: the backward needs no
+// pass over y (pooled_bwd_rows_kernel below).
+template <typename T, int NPL>
 __global__ __launch_bounds__(RED_THREADS) void avgpool_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float* __restrict__ ws,
                                                               size_t hw, int CP) {
@@ -296,25 +309,65 @@ __global__ __launch_bounds__(RED_THREADS) void avgpool_kernel(const T* __restric
     const int vv = threadIdx.x % VPP, ps = threadIdx.x / VPP;
     const int c0 = vv * VE;
     const int b = blockIdx.y, S = gridDim.x;
-    float sc[VE], sh[VE], a1[VE];
+    float sc[VE], sh[VE], a1[VE], a2[VE], a3[VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; a1[e] = 0.f; }
+    for (int e = 0; e < VE; ++e) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; a1[e] = 0.f; a2[e] = 0.f; a3[e] = 0.f; }
     if (ps < PPB) {
-        for (size_t p = (size_t)blockIdx.x * PPB + ps; p < hw; p += (size_t)S * PPB) {
-            const vec16<T> yv = *reinterpret_cast<const vec16<T>*>(y + ((size_t)b * hw + p) * ldy + c0);
+        auto body = [&](const vec16<T>& yv) {
 #pragma unroll
-            for (int e = 0; e < VE; ++e) a1[e] += fmaxf(sc[e] * yv.get(e) + sh[e], 0.f);
+            for (int e = 0; e < VE; ++e) {
+                const float yy = yv.get(e);
+                const float z = sc[e] * yy + sh[e];
+                a1[e] += fmaxf(z, 0.f);
+                if (NPL == 3) { a2[e] += z > 0.f ? 1.f : 0.f; a3[e] += z > 0.f ? yy : 0.f; }
+            }
+        };
+        // four pixels per trip, the loads issued before the arithmetic
+        const size_t st = (size_t)S * PPB;
+        const T* yb = y + (size_t)b * hw * ldy + c0;
+        size_t p = (size_t)blockIdx.x * PPB + ps;
+        for (; p + 3 * st < hw; p += 4 * st) {
+            const vec16<T> v0 = *reinterpret_cast<const vec16<T>*>(yb + p * ldy);
+            const vec16<T> v1 = *reinterpret_cast<const vec16<T>*>(yb + (p + st) * ldy);
+            const vec16<T> v2 = *reinterpret_cast<const vec16<T>*>(yb + (p + 2 * st) * ldy);
+            const vec16<T> v3 = *reinterpret_cast<const vec16<T>*>(yb + (p + 3 * st) * ldy);
+            body(v0); body(v1); body(v2); body(v3);
         }
+        for (; p < hw; p += st) body(*reinterpret_cast<const vec16<T>*>(yb + p * ldy));
     }
-    __shared__ float red[RED_THREADS][vec16<T>::N + 1];
+    __shared__ float red[NPL][RED_THREADS][vec16<T>::N + 1];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) red[threadIdx.x][e] = a1[e];
+    for (int e = 0; e < VE; ++e) {
+        red[0][threadIdx.x][e] = a1[e];
+        if (NPL == 3) { red[NPL - 2][threadIdx.x][e] = a2[e]; red[NPL - 1][threadIdx.x][e] = a3[e]; }
+    }
     __syncthreads();
-    for (int c = threadIdx.x; c < CP; c += RED_THREADS) {
+    for (int i = threadIdx.x; i < NPL * CP; i += RED_THREADS) {
+        const int pl = i / CP, c = i - pl * CP;
         const int v2 = c / VE, e = c - v2 * VE;
         float s = 0.f;
-        for (int q = 0; q < PPB; ++q) s += red[q * VPP + v2][e];
-        ws[((size_t)b * S + blockIdx.x) * CP + c] = s;
+        for (int q = 0; q < PPB; ++q) s += red[pl][q * VPP + v2][e];
+        ws[(((size_t)b * S + blockIdx.x) * NPL + pl) * CP + c] = s;
+    }
+}
+// ws [B][S][3][CP] -> out3 [3][B][CP]: plane 0 = pooled mean (x inv_hw), planes 1, 2 = N+, S+
+__global__ __launch_bounds__(256) void avgpool_stats_finalize_kernel(const float* __restrict__ ws, int S, int B, int CP, float inv_hw,
+                                                                     float* __restrict__ out3) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < 3 * CP; i += 256) {
+        const int pl = i / CP, c = i - pl * CP;
+        double a = 0.0;
+        for (int s = 0; s < S; ++s) a += (double)ws[(((size_t)b * S + s) * 3 + pl) * CP + c];
+        out3[((size_t)pl * B + b) * CP + c] = (float)(pl == 0 ? a * (double)inv_hw : a);
+    }
+}
+// partial rows for wm_bn_bwd_finalize_raw from the pooled statistics: rows[b] = (gv[b,:] * N+[b,:], gv[b,:] * S+[b,:])
+__global__ __launch_bounds__(256) void pooled_bwd_rows_kernel(const float* __restrict__ gvec, const float* __restrict__ npos,
+                                                              const float* __restrict__ ysum, int B, int CP, float* __restrict__ rows) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B * CP; i += gridDim.x * 256) {
+        const int b = i / CP, c = i - b * CP;
+        rows[((size_t)b * 2 + 0) * CP + c] = gvec[i] * npos[i];
+        rows[((size_t)b * 2 + 1) * CP + c] = gvec[i] * ysum[i];
     }
 }
 
@@ -460,12 +513,48 @@ extern "C" int wm_bnrelu_avgpool(const void* y, int ldy, const float* scale, con
     const int S = wm_avgpool_slices(hw);
     hipStream_t s = (hipStream_t)stream;
     WM_DISPATCH_DTYPE(dtype, "wm_bnrelu_avgpool",
-        hipLaunchKernelGGL((avgpool_kernel<T>), dim3(S, B), dim3(RED_THREADS), 0, s, (const T*)y, ldy, scale, shift, ws, hw, CP));
+        hipLaunchKernelGGL((avgpool_kernel<T, 1>), dim3(S, B), dim3(RED_THREADS), 0, s, (const T*)y, ldy, scale, shift, ws, hw, CP));
     WM_LAUNCH_CHECK("wm_bnrelu_avgpool");
     // ws viewed as [B][S*CP]: per sample reduce S rows of CP -> out[b][CP], scaled by 1/hw
     hipLaunchKernelGGL(colsum_kernel, dim3(wm_cdiv(CP, 32), B), dim3(256), 0, s, ws, S, CP, CP, out, 0,
                        (float)(1.0 / (double)hw), (size_t)S * CP, (size_t)CP);
     WM_LAUNCH_CHECK("wm_bnrelu_avgpool(finalize)");
+    return WM_OK;
+}
+
+static int g_pool_stats = getenv("WM_NO_POOL_STATS") ? 0 : 1;
+extern "C" void wm_debug_pool_stats(int on) { g_pool_stats = on; }   // A/B knob (tools/ab_step.py)
+extern "C" int wm_pool_stats_enabled(void) { return g_pool_stats; }
+
+extern "C" int wm_bnrelu_avgpool_stats(const void* y, int ldy, const float* scale, const float* shift, float* out3, float* ws, int B,
+                                       size_t hw, int CP, int dtype, void* stream) {
+    WM_REQUIRE(y && scale && shift && out3 && ws, WM_E_BADARG, "wm_bnrelu_avgpool_stats: null pointer");
+    WM_REQUIRE(cp_ok(CP, dtype), WM_E_SHAPE, "wm_bnrelu_avgpool_stats: unsupported channel count CP=%d", CP);
+    const int S = wm_avgpool_slices(hw);
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_bnrelu_avgpool_stats",
+        hipLaunchKernelGGL((avgpool_kernel<T, 3>), dim3(S, B), dim3(RED_THREADS), 0, s, (const T*)y, ldy, scale, shift, ws, hw, CP));
+    WM_LAUNCH_CHECK("wm_bnrelu_avgpool_stats");
+    hipLaunchKernelGGL(avgpool_stats_finalize_kernel, dim3(B), dim3(256), 0, s, ws, S, B, CP, (float)(1.0 / (double)hw), out3);
+    WM_LAUNCH_CHECK("wm_bnrelu_avgpool_stats(finalize)");
+    return WM_OK;
+}
+
+// the pooled layer's whole reduce + finalisation in one launch: rows formed from (gvec, N+, S+) on the fly
+extern "C" int wm_bn_bwd_finalize_pooled(const float* gvec, const float* npos, const float* ysum, int B, int C, int CP, double count,
+                                         const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                         int accumulate, float* coef, void* stream) {
+    WM_REQUIRE(gvec && npos && ysum && gamma && mean && invstd && coef && B > 0, WM_E_BADARG, "wm_bn_bwd_finalize_pooled: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(wm_cdiv(CP, 8)), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, B, C, CP,
+                       count, gamma, invstd, dgamma, dbeta, accumulate, coef, mean, gvec, npos, ysum);
+    WM_LAUNCH_CHECK("wm_bn_bwd_finalize_pooled");
+    return WM_OK;
+}
+
+extern "C" int wm_pooled_bn_bwd_rows(const float* gvec, const float* npos, const float* ysum, int B, int CP, float* rows, void* stream) {
+    WM_REQUIRE(gvec && npos && ysum && rows && B > 0 && CP > 0, WM_E_BADARG, "wm_pooled_bn_bwd_rows: bad arguments");
+    hipLaunchKernelGGL(pooled_bwd_rows_kernel, dim3(wm_cdiv(B * CP, 256)), dim3(256), 0, (hipStream_t)stream, gvec, npos, ysum, B, CP, rows);
+    WM_LAUNCH_CHECK("wm_pooled_bn_bwd_rows");
     return WM_OK;
 }
 

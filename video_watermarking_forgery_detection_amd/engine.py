@@ -84,7 +84,7 @@ def cbr_forward(conv, bn, x, dtype, perm=None, training=True, momentum=0.1):
 
 
 def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, accumulate=False,
-                 dgrad_channels=None, perm_dev=None):
+                 dgrad_channels=None, perm_dev=None, pool_stats=None):
     """Backward of ConvBNRelu.  g: NHWC gradient wrt the ReLU output ([B,H,W,>=CoutP]) or gvec [B,CoutP]
     (global-average-pool gradient, already / (H*W)).  grads: dict param -> f32 grad view.
     Returns the NHWC gradient wrt the (activated) input, `dgrad_channels` wide (default: the input's
@@ -103,6 +103,8 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
     gam, dgam, dbet = bn.weight.data, grads[bn.weight], grads[bn.bias]
 
     def coef_of():
+        if gvec is not None and pool_stats is not None:   # (N+, S+) from the forward pool: no pass over y
+            return ops.bn_bwd_coef_pooled(gvec, pool_stats, y, ctx.stats, Cout, gam, dgam, dbet, accumulate)
         if pre is not None and g is not None and pre[0] is g:
             return ops.bn_bwd_coef_raw(pre[1], y, ctx.stats, Cout, gam, dgam, dbet, accumulate)
         return ops.bn_bwd_coef(g, gvec, y, ctx.stats, Cout, gam, dgam, dbet, accumulate)

@@ -10,7 +10,7 @@ from .conv_bn_relu import ConvBNRelu
 
 
 class StackCtx:
-    __slots__ = ("layers", "pooled", "HW", "x_is_leaf_image")
+    __slots__ = ("layers", "pooled", "pool_stats", "HW", "x_is_leaf_image")
 
 
 def stack_fwd(blocks, image, dt, training):
@@ -21,7 +21,10 @@ def stack_fwd(blocks, image, dt, training):
     for blk in blocks:
         a, cx = engine.cbr_forward(blk.layers[0], blk.layers[1], a, dt, training=training)
         ctx.layers.append(cx)
-    ctx.pooled = ops.bnrelu_avgpool(a.t, a.scale, a.shift)
+    if training and ops.pool_stats_enabled():
+        ctx.pooled, ctx.pool_stats = ops.bnrelu_avgpool_stats(a.t, a.scale, a.shift)
+    else:
+        ctx.pooled, ctx.pool_stats = ops.bnrelu_avgpool(a.t, a.scale, a.shift), None
     ctx.HW = image.shape[2] * image.shape[3]
     return ctx.pooled, ctx
 
@@ -41,7 +44,8 @@ def stack_bwd(blocks, ctx, gvec, grads, accumulate, need_input_grad):
     for i in range(n - 1, -1, -1):
         blk = blocks[i]
         g = engine.cbr_backward(blk.layers[0], blk.layers[1], ctx.layers[i], grads, g=g, gvec=gvec if i == n - 1 else None,
-                                accumulate=accumulate, need_input_grad=(i > 0 or need_input_grad))
+                                accumulate=accumulate, need_input_grad=(i > 0 or need_input_grad),
+                                pool_stats=ctx.pool_stats if i == n - 1 else None)
     if not need_input_grad:
         return None
     return ops.nhwc_to_nchw(g, 3, 0)

@@ -480,6 +480,48 @@ def conv3x3_wgrad(x, CinX, in_scale, in_shift, dy, dw, accumulate, perm_dev=None
 
 
 # ----------------------------------------------------------------------------- heads
+def pool_stats_enabled():
+    return bool(_lib.lib().wm_pool_stats_enabled())
+
+
+def bnrelu_avgpool_stats(y, scale, shift):
+    """global average pool of relu(scale*y+shift) plus, per (sample, channel), the active-pixel count N+ and the sum S+ of y over
+    the active pixels.  Returns (pooled [B,CP], (N+ [B,CP], S+ [B,CP]))."""
+    B, H, W, CP = y.shape
+    L = _lib.lib()
+    S = L.wm_avgpool_slices(c_size_t(H * W))
+    ws = torch.empty(B * S * 3 * CP, device=y.device, dtype=torch.float32)
+    out3 = torch.empty(3, B, CP, device=y.device, dtype=torch.float32)
+    rc = L.wm_bnrelu_avgpool_stats(_p(y), c_int(CP), _p(scale), _p(shift), _p(out3), _p(ws), c_int(B), c_size_t(H * W), c_int(CP),
+                                   c_int(dtype_id(y)), _stream())
+    _lib.check(rc, "wm_bnrelu_avgpool_stats")
+    return out3[0], (out3[1], out3[2])
+
+
+def pooled_bwd_rows(gvec, pool_stats):
+    """partial rows [B,2,CP] = (gvec*N+, gvec*S+) for bn_bwd_coef_raw: the pooled layer's BatchNorm-backward sums without a pass over y"""
+    B, CP = gvec.shape
+    npos, ysum = pool_stats
+    assert gvec.is_contiguous() and npos.is_contiguous() and ysum.is_contiguous() and npos.shape == gvec.shape
+    rows = torch.empty(B, 2, CP, device=gvec.device, dtype=torch.float32)
+    rc = _lib.lib().wm_pooled_bn_bwd_rows(_p(gvec), _p(npos), _p(ysum), c_int(B), c_int(CP), _p(rows), _stream())
+    _lib.check(rc, "wm_pooled_bn_bwd_rows")
+    return rows
+
+
+def bn_bwd_coef_pooled(gvec, pool_stats, y, stats, C, gamma, dgamma, dbeta, accumulate):
+    """bn_bwd_coef of a globally pooled layer from the forward pool's (N+, S+): one small launch, no pass over y"""
+    B, H, W, CP = y.shape
+    npos, ysum = pool_stats
+    assert gvec.is_contiguous() and npos.is_contiguous() and ysum.is_contiguous() and tuple(gvec.shape) == (B, CP) == tuple(npos.shape)
+    coef = torch.empty(3, CP, device=y.device, dtype=torch.float32)
+    rc = _lib.lib().wm_bn_bwd_finalize_pooled(_p(gvec), _p(npos), _p(ysum), c_int(B), c_int(C), c_int(CP), c_double(B * H * W), _p(gamma),
+                                              _p(stats[2]), _p(stats[3]), _p(dgamma), _p(dbeta), c_int(1 if accumulate else 0), _p(coef),
+                                              _stream())
+    _lib.check(rc, "wm_bn_bwd_finalize_pooled")
+    return coef
+
+
 def bnrelu_avgpool(y, scale, shift):
     B, H, W, CP = y.shape
     L = _lib.lib()
