@@ -188,13 +188,14 @@ int wm_conv3x3_dgrad_gvfused(const void* y, int ldy, int CoutY, const void* wpt,
  * output with the apply pass fused as in wm_conv3x3_dgrad_gvfused. */
 /* The ordinary 64 -> 64 layer (gradient g a dense bf16 tensor [B,H,W,64]): input gradient with the BatchNorm-backward APPLY
  * pass fused.  The kernel reads g and the layer's raw output y (dense), forms dy from stats4 / coef while staging, writes
- * dy_out [B,H,W,64] (bit-identical to wm_bn_bwd_apply's; input of the wm_conv3x3_wgrad that follows) and dx = conv(dy, wpt).
+ * dy_out [B,H,W,64] (bit-identical to wm_bn_bwd_apply's; input of the wm_conv3x3_wgrad that follows) and dx = conv(dy, wpt)
+ * [B,H,W,CinP], CinP = 64, or 32 for an image-fed layer (wpt [9][CinP][64]).
  * ry / r_scale / r_shift / partials: optional, all or none -- the sums of the feeding layer as in
  * wm_conv3x3_dgrad_bwdstats. */
 int wm_conv3x3_dgrad_applyfused_supported(int CoutY, int CinP, int dtype);
 int wm_conv3x3_dgrad_applyfused(const void* g, const void* y, const float* stats4, const float* coef, const void* wpt,
                                 void* dy_out, void* dx, const void* ry, const float* r_scale, const float* r_shift,
-                                float* partials, int B, int H, int W, int dtype, void* stream);
+                                float* partials, int B, int H, int W, int CinP, int dtype, void* stream);
 int wm_conv3x3_dgrad_bwdstats_supported(int CoutY, int CinP, int dtype);
 int wm_conv3x3_dgrad_bwdstats(const void* src, int lds, int CoutY, const void* wpt, const float* gvec, const float* stats4,
                               const float* coef, const void* ry, const float* r_scale, const float* r_shift, void* dx,

@@ -610,6 +610,12 @@ def test_dgrad_with_fused_bn_backward_apply_tensor_gradient(case):
     assert dy0.float().abs().max().item() > 0 and dx0.float().abs().max().item() > 0
     assert torch.equal(dy0, dy1)
     assert torch.equal(dx0, dx1)
+    # image-fed layer: the input gradient has 3 (-> 32) channels
+    w3 = detgen.normal((C, 3, 3, 3), 169, std=0.05).cuda()
+    wpt3 = ops.pack_w3x3(w3, C, 32, torch.bfloat16, transpose=True)
+    dx2, _ = ops.conv3x3_fwd(dy0, wpt3, None, None, None, want_stats=False)
+    dy3, dx3, _ = ops.conv3x3_dgrad_applyfused(g, y, stats, coef, wpt3)
+    assert dx2.float().abs().max().item() > 0 and torch.equal(dy0, dy3) and torch.equal(dx2, dx3)
 
 
 def test_fused_apply_keeps_the_training_step():

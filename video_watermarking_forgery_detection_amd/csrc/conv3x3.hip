@@ -434,20 +434,21 @@ extern "C" int wm_conv3x3_dgrad_bwdstats(const void* src, int lds, int CoutY, co
 static int g_applyfuse = getenv("WM_NO_APPLY_FUSE") ? 0 : 1;
 extern "C" void wm_debug_apply_fuse(int on) { g_applyfuse = on; }   // A/B knob (tools/ab_step.py)
 extern "C" int wm_conv3x3_dgrad_applyfused_supported(int CoutY, int CinP, int dtype) {
-    return (g_applyfuse && dtype == WM_BF16 && CoutY == 64 && CinP == 64 && use_ws(CoutY, CinP, dtype)) ? 1 : 0;
+    return (g_applyfuse && dtype == WM_BF16 && CoutY == 64 && (CinP == 64 || CinP == 32) && use_ws(CoutY, CinP, dtype)) ? 1 : 0;
 }
 extern "C" int wm_conv3x3_dgrad_applyfused(const void* g, const void* y, const float* stats4, const float* coef, const void* wpt,
                                            void* dy_out, void* dx, const void* ry, const float* r_scale, const float* r_shift,
-                                           float* partials, int B, int H, int W, int dtype, void* stream) {
+                                           float* partials, int B, int H, int W, int CinP, int dtype, void* stream) {
     WM_REQUIRE(g && y && stats4 && coef && wpt && dy_out && dx, WM_E_BADARG, "wm_conv3x3_dgrad_applyfused: null pointer");
     WM_REQUIRE((ry == nullptr) == (partials == nullptr) && (ry == nullptr) == (r_scale == nullptr) && (ry == nullptr) == (r_shift == nullptr),
                WM_E_BADARG, "wm_conv3x3_dgrad_applyfused: ry, r_scale, r_shift and partials come together");
     WM_REQUIRE(B > 0 && H > 0 && W > 0, WM_E_BADARG, "wm_conv3x3_dgrad_applyfused: bad shape");
-    WM_REQUIRE(wm_conv3x3_dgrad_applyfused_supported(64, 64, dtype), WM_E_SHAPE, "wm_conv3x3_dgrad_applyfused: unsupported dtype %d", dtype);
+    WM_REQUIRE(wm_conv3x3_dgrad_applyfused_supported(64, CinP, dtype) && (CinP == 64 || !ry), WM_E_SHAPE,
+               "wm_conv3x3_dgrad_applyfused: unsupported CinP=%d dtype=%d (the feeding layer's sums need CinP = 64)", CinP, dtype);
     WM_REQUIRE((((uintptr_t)g | (uintptr_t)y | (uintptr_t)wpt | (uintptr_t)dy_out | (uintptr_t)dx | (uintptr_t)ry) & 15) == 0, WM_E_SHAPE,
                "wm_conv3x3_dgrad_applyfused: pointers must be 16-byte aligned");
     const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
-    const int rc = wm_launch_conv3x3_ws(g, 64, 64, 64, wpt, nullptr, 0, nullptr, nullptr, dx, partials, B, H, W, ws_wgs(ntiles),
+    const int rc = wm_launch_conv3x3_ws(g, 64, 64, CinP, wpt, nullptr, 0, nullptr, nullptr, dx, partials, B, H, W, ws_wgs(ntiles),
                                         ws_tiles_per_wg(ntiles), (hipStream_t)stream, stats4, 64, coef, nullptr, ry, r_scale, r_shift, y, dy_out);
     WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_dgrad_applyfused: no kernel for this shape");
     WM_LAUNCH_CHECK("wm_conv3x3_dgrad_applyfused");

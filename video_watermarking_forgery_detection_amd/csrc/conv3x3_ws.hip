@@ -813,8 +813,11 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void*
     a.ay = (const bf16_t*)ay; a.dy_out = (bf16_t*)dy_out;
     const dim3 grid((unsigned)wgs), block(512);
     if (ay) {   // dgrad with the BatchNorm-backward apply (tensor gradient) fused; x = g, dy written out for the weight gradient
-        if (Cin != 64 || CoutP != 64 || ldx != 64 || in_scale || !bw_stats4 || !bw_coef || bw_gvec || !dy_out || (ry != nullptr) != (stat != nullptr)) return WM_E_SHAPE;
-        if (ry) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, 2, true>), grid, block, 0, s, a, nullptr);
+        if (Cin != 64 || (CoutP != 64 && CoutP != 32) || ldx != 64 || in_scale || !bw_stats4 || !bw_coef || bw_gvec || !dy_out ||
+            (ry != nullptr) != (stat != nullptr) || (ry && CoutP != 64))
+            return WM_E_SHAPE;
+        if (CoutP == 32) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 32, false, false, true, false, 2, false>), grid, block, 0, s, a, nullptr);   // image-fed layer: dx has 3 (-> 32) channels
+        else if (ry) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, 2, true>), grid, block, 0, s, a, nullptr);
         else hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, 2, false>), grid, block, 0, s, a, nullptr);
         return WM_OK;
     }

@@ -133,9 +133,9 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
         return ops.conv3x3_dgrad_gvfused(y, wpt, gvec, ctx.stats, coef)
     # An ordinary 64 -> 64 layer: the input-gradient kernel reads g and y, forms dy while staging and leaves it in memory
     # for the weight gradient -- the stand-alone apply pass is gone.
-    if (g is not None and need_input_grad and x.scale is not None and perm_dev is None and ctx.perm is None and rows == 64
-            and x.t.shape[-1] == 64 and y.shape[-1] == 64 and g.shape == y.shape and g.is_contiguous() and ctx.stats.is_contiguous()
-            and ops.conv3x3_dgrad_applyfused_supported(64, 64, dtype)):
+    if (g is not None and need_input_grad and perm_dev is None and ctx.perm is None and rows in (64, 32)
+            and y.shape[-1] == 64 and g.shape == y.shape and g.is_contiguous() and ctx.stats.is_contiguous()
+            and ops.conv3x3_dgrad_applyfused_supported(64, rows, dtype)):
         coef = coef_of()
         wpt = _packed(conv, 64, rows, dtype, None, True)
         if feed_stats:
@@ -143,7 +143,7 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
             x.bwd = (gx, part)
         else:
             dy, gx, _ = ops.conv3x3_dgrad_applyfused(g, y, ctx.stats, coef, wpt)
-        ops.conv3x3_wgrad(x.t, 64, x.scale, x.shift, dy, grads[conv.weight], accumulate)
+        ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate)
         return gx
     dy = ops.bn_bwd(g, gvec, y, ctx.stats, Cout, gam, dgam, dbet, accumulate, dbias, coef=coef_of())
     ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, perm_dev=perm_dev)

@@ -389,15 +389,16 @@ def conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry=None, r_scale=None, r_sh
     Returns (dy, dx, partials or None): dy for the weight gradient, dx = conv3x3(dy, wpt), partials = the feeding layer's
     BatchNorm-backward sums when its raw output ry (+ r_scale, r_shift) is given."""
     B, H, W, C = y.shape
-    assert C == 64 and g.shape == y.shape and g.is_contiguous() and y.is_contiguous() and tuple(wpt.shape) == (9, 64, 64)
-    assert stats.is_contiguous() and coef.is_contiguous() and (ry is None or (ry.shape == y.shape and ry.is_contiguous()))
+    CinP = wpt.shape[1]
+    assert C == 64 and g.shape == y.shape and g.is_contiguous() and y.is_contiguous() and tuple(wpt.shape) == (9, CinP, 64) and CinP in (64, 32)
+    assert stats.is_contiguous() and coef.is_contiguous() and (ry is None or (CinP == 64 and ry.shape == y.shape and ry.is_contiguous()))
     dy = torch.empty_like(y)
-    dx = torch.empty_like(y)
+    dx = torch.empty(B, H, W, CinP, device=y.device, dtype=y.dtype)
     part = torch.empty(conv3x3_nparts(B, H, W, 64, 64, y.dtype), 2, 64, device=y.device, dtype=torch.float32) if ry is not None else None
     info = {"B": B, "H": H, "W": W, "feed": ry is not None, "dtype": y.dtype}
     rc = _timed("conv3x3_dgrad_applyfused", info, lambda: _lib.lib().wm_conv3x3_dgrad_applyfused(
         _p(g), _p(y), _p(stats), _p(coef), _p(wpt), _p(dy), _p(dx), _p(ry), _p(r_scale), _p(r_shift), _p(part), c_int(B), c_int(H), c_int(W),
-        c_int(dtype_id(y)), _stream()))
+        c_int(CinP), c_int(dtype_id(y)), _stream()))
     _lib.check(rc, "wm_conv3x3_dgrad_applyfused")
     return dy, dx, part
 
