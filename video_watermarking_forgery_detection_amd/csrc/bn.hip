@@ -350,14 +350,21 @@ __global__ __launch_bounds__(RED_THREADS) void avgpool_kernel(const T* __restric
         ws[(((size_t)b * S + blockIdx.x) * NPL + pl) * CP + c] = s;
     }
 }
-// ws [B][S][3][CP] -> out3 [3][B][CP]: plane 0 = pooled mean (x inv_hw), planes 1, 2 = N+, S+
+// ws [B][S][3][CP] -> out3 [3][B][CP]: plane 0 = pooled mean (x inv_hw), planes 1, 2 = N+, S+.  grid (3*CP/32, B): 32 columns x 8
+// slice groups per workgroup
 __global__ __launch_bounds__(256) void avgpool_stats_finalize_kernel(const float* __restrict__ ws, int S, int B, int CP, float inv_hw,
                                                                      float* __restrict__ out3) {
-    const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < 3 * CP; i += 256) {
+    __shared__ double s1[8][32];
+    const int b = blockIdx.y, cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;   // column of the [3*CP] row
+    double a = 0.0;
+    if (i < 3 * CP)
+        for (int s = sl; s < S; s += 8) a += (double)ws[((size_t)b * S + s) * 3 * CP + i];
+    s1[sl][cl] = a;
+    __syncthreads();
+    if (sl == 0 && i < 3 * CP) {
+        for (int k = 1; k < 8; ++k) a += s1[k][cl];
         const int pl = i / CP, c = i - pl * CP;
-        double a = 0.0;
-        for (int s = 0; s < S; ++s) a += (double)ws[(((size_t)b * S + s) * 3 + pl) * CP + c];
         out3[((size_t)pl * B + b) * CP + c] = (float)(pl == 0 ? a * (double)inv_hw : a);
     }
 }
@@ -535,7 +542,7 @@ extern "C" int wm_bnrelu_avgpool_stats(const void* y, int ldy, const float* scal
     WM_DISPATCH_DTYPE(dtype, "wm_bnrelu_avgpool_stats",
         hipLaunchKernelGGL((avgpool_kernel<T, 3>), dim3(S, B), dim3(RED_THREADS), 0, s, (const T*)y, ldy, scale, shift, ws, hw, CP));
     WM_LAUNCH_CHECK("wm_bnrelu_avgpool_stats");
-    hipLaunchKernelGGL(avgpool_stats_finalize_kernel, dim3(B), dim3(256), 0, s, ws, S, B, CP, (float)(1.0 / (double)hw), out3);
+    hipLaunchKernelGGL(avgpool_stats_finalize_kernel, dim3(wm_cdiv(3 * CP, 32), B), dim3(256), 0, s, ws, S, B, CP, (float)(1.0 / (double)hw), out3);
     WM_LAUNCH_CHECK("wm_bnrelu_avgpool_stats(finalize)");
     return WM_OK;
 }
