@@ -111,14 +111,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
     // (i&3) + 8(i>>2) + 4h.  Output channel c of a 32-channel fragment is therefore stored at filter row
     // rho(c) = (i&3) + 8(i>>2) + 4hh with hh = c>>4, i = c&15: register i of lane half h is channel 16h + i, and a
     // lane owns 16 ADJACENT channels of its pixel -- two 16-byte stores, no transpose.
-    {
-        constexpr int NV = 9 * COUT * VPP, WV = (NV + 511) / 512;
-        bf16x8 wv[WV];
+    // The loads are issued here; the LDS stores (commit_filter) come after the producers have issued their first tile loads,
+    // so the filter's trip from L2 and the first halo tiles' trip from HBM overlap at the start of every launch.
+    constexpr int NV = 9 * COUT * VPP, WV = (NV + 511) / 512;
+    bf16x8 wv[WV];
 #pragma unroll
-        for (int k = 0; k < WV; ++k) {
-            const int i = min(tid + 512 * k, NV - 1);
-            wv[k] = *reinterpret_cast<const bf16x8*>(a.wp + (size_t)(i / VPP) * CIN + (i % VPP) * 8);
-        }
+    for (int k = 0; k < WV; ++k) {
+        const int i = min(tid + 512 * k, NV - 1);
+        wv[k] = *reinterpret_cast<const bf16x8*>(a.wp + (size_t)(i / VPP) * CIN + (i % VPP) * 8);
+    }
+    auto commit_filter = [&]() {
 #pragma unroll
         for (int k = 0; k < WV; ++k) {
             const int i = tid + 512 * k;
@@ -131,7 +133,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             const int lrow = M16 ? tap * COUT + ((n >> 2) % NFR) * 16 + 4 * (n / CPL) + (n & 3) : tap * COUT + (n >> 5) * 32 + rho;
             if (i < NV) *reinterpret_cast<bf16x8*>(sW + lrow * CIN + swz<CIN>(lrow, i % VPP) * 8) = wv[k];
         }
-    }
+    };
+    const bool early_filter = (a.dbg & 128) != 0;   // A/B knob (variant 10): the filter committed before anything else is issued
+    if (early_filter) commit_filter();
 
     // XCD-aware run assignment: workgroups b and b+8 share an XCD (round-robin dispatch), so give XCD x the
     // consecutive runs [x*G/8, (x+1)*G/8): vertically adjacent tile rows then meet in ONE L2 at about the same time
@@ -330,11 +334,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                     if (((wmask >> k) & 1u) && inimg) *reinterpret_cast<u32x4*>(a.dy_out + tofs + rel[k]) = w;
                 }
             };
-            if (t_begin < t_end) {
-                const TileGeo g0 = geo(t_begin);
-                load_both(g0);
-                put_both(sX0, g0);
-            }
+            if (t_begin < t_end) load_both(geo(t_begin));
+            if (!early_filter) commit_filter();
+            if (t_begin < t_end) put_both(sX0, geo(t_begin));
             __syncthreads();  // filter + first halo tile visible
             stamp(-1);
             for (int tile = t_begin; tile < t_end; ++tile) {
@@ -355,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         unsigned okA = 0, okB = 0;
         if (t_begin < t_end) load_tile(geo(t_begin), dA, okA, false);
         if (t_begin + 1 < t_end) load_tile(geo(t_begin + 1), dB, okB, reuse_of(t_begin + 1));
+        if (!early_filter) commit_filter();
         if (t_begin < t_end) {
             load_gvec(geo(t_begin).b);
 #pragma unroll
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
     // fragment mf = 0 then mf = 1 (2 MFMAs per step; the filter fragments are read twice -- the LDS has the room), and
     // while one half accumulates, the finished other half is drained (BatchNorm sums, bf16 pack, stores) in the
     // shadow of the MFMAs, a few instructions per step, so the matrix pipe never waits for an epilogue.
+    if (!early_filter) commit_filter();
     if constexpr (M16) {
         // lane (p, q): pixel column p of the tile row wave*4 + mf; accumulator [mf][nf] register i = channel 16q + 4nf + i
         constexpr int KS2 = CIN / 32, NSTEP2 = 9 * KS2;
@@ -791,7 +795,7 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
 }
 
 static int g_ws_reverse = 0;
-static int g_ws_variant = getenv("WM_WS_VARIANT") ? atoi(getenv("WM_WS_VARIANT")) : 0;   // A/B knobs -- 1: 32x32x16 MFMA consumers, 2: no XCD-aware run assignment, 3: producers at s_setprio 3, 8: no halo-edge reuse, 9: statistics sums not pinned
+static int g_ws_variant = getenv("WM_WS_VARIANT") ? atoi(getenv("WM_WS_VARIANT")) : 0;   // A/B knobs -- 1: 32x32x16 MFMA consumers, 2: no XCD-aware run assignment, 3: producers at s_setprio 3, 8: no halo-edge reuse, 9: statistics sums not pinned, 10: filter committed to LDS before the first tile loads are issued
 extern "C" void wm_debug_ws_variant(int v) { g_ws_variant = v; }
 
 extern "C" void wm_debug_ws_direction(int reverse) { g_ws_reverse = reverse; }
@@ -803,7 +807,7 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void*
                            const float* bw_gvec = nullptr, const void* ry = nullptr, const float* r_scale = nullptr,
                            const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr) {
     WsArgs a;
-    a.dbg = g_ws_variant == 3 ? 8 : (g_ws_variant == 8 ? 64 : 0); a.xcd_map = g_ws_variant != 2;
+    a.dbg = g_ws_variant == 3 ? 8 : (g_ws_variant == 8 ? 64 : (g_ws_variant == 10 ? 128 : 0)); a.xcd_map = g_ws_variant != 2;
     a.x = (const bf16_t*)x; a.ldx = ldx; a.wp = (const bf16_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
     a.in_shift = in_shift; a.y = (bf16_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY; a.tiles_per_wg = tiles_per_wg;
