@@ -174,6 +174,10 @@ int wm_conv3x3_wgrad_bnfused(const void* x, int ldx, int CinX, const void* g, in
  * read the layer's raw conv output y instead of dy and apply the BatchNorm backward while staging (bf16, CinX = 64,
  * CoutY in {64, 32}); results are bit-identical to wm_bn_bwd_apply followed by wm_conv3x3_wgrad / wm_conv3x3_fwd.
  * wpt: the transposed packed filter (wm_pack_w3x3 with transpose = 1), dx: [B,H,W,CinP] dense. */
+/* Optional hint for the NEXT wm_conv3x3_fwd / wm_conv3x3_dgrad_* call from this thread: sweep the pixel tiles backwards.
+ * A kernel that starts where the producer of its input stopped finds the freshest part of that tensor in the Infinity
+ * Cache; the host alternates the direction along a chain of layers.  Consumed by that one call. */
+void wm_conv3x3_sweep_hint(int reverse);
 int wm_conv3x3_gvfused_supported(int CinX, int CoutY, int dtype);
 int wm_conv3x3_wgrad_gvfused(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const float* gvec,
                              const void* y, int ldy, int CoutY, const float* stats4, const float* coef, float* ws, float* dw,

@@ -674,3 +674,39 @@ def test_pooled_layer_bn_backward_sums_from_forward_pool_statistics(case):
     c2 = ops.bn_bwd_coef_pooled(gvec, ps, y, stats, C, gamma, dg2, db2, False)     # the two steps in one launch
     torch.testing.assert_close(c2, c1, rtol=1e-6, atol=1e-7 * c0.abs().max().item())
     torch.testing.assert_close(dg2, dg1, rtol=1e-6, atol=1e-7 * sc); torch.testing.assert_close(db2, db1, rtol=1e-6, atol=1e-7 * sc)
+
+
+@pytest.mark.parametrize("case", [(2, 40, 36), (1, 64, 64), (3, 17, 50)])
+def test_backward_sweep_hint_changes_only_the_summation_order(case):
+    """wm_conv3x3_sweep_hint: the next persistent conv / wgrad launch walks its tiles backwards (Infinity-Cache reuse along a
+    chain of layers).  Outputs are bit-identical (the halo-edge reuse mirrors: right columns from the tile before);
+    per-workgroup statistics rows and weight-gradient slabs only change their summation order."""
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W = case
+    C = 64
+    x = nhwc(detgen.normal((B, C, H, W), 191), torch.bfloat16)
+    xs = detgen.normal((C,), 192, mean=1.0, std=0.3).cuda(); xt = detgen.normal((C,), 193, std=0.3).cuda()
+    w = detgen.normal((C, C, 3, 3), 194, std=0.05).cuda()
+    wp = ops.pack_w3x3(w, C, C, torch.bfloat16)
+    y0, st0 = ops.conv3x3_fwd(x, wp, None, xs, xt, want_stats=True)
+    y1, st1 = ops.conv3x3_fwd(x, wp, None, xs, xt, want_stats=True, reverse=True)
+    y2, _ = ops.conv3x3_fwd(x, wp, None, xs, xt, want_stats=True)          # the hint is consumed by one launch
+    assert y0.float().abs().max().item() > 0 and torch.equal(y0, y1) and torch.equal(y0, y2)
+    torch.testing.assert_close(st1.sum(0), st0.sum(0), rtol=1e-5, atol=1e-3)
+    dy = nhwc(detgen.normal((B, C, H, W), 195), torch.bfloat16)
+    dw0 = torch.zeros(C, C, 3, 3, device="cuda"); dw1 = torch.zeros(C, C, 3, 3, device="cuda")
+    ops.conv3x3_wgrad(x, C, xs, xt, dy, dw0, False)
+    ops.conv3x3_wgrad(x, C, xs, xt, dy, dw1, False, reverse=True)
+    torch.testing.assert_close(dw1, dw0, rtol=1e-5, atol=1e-5 * dw0.abs().max().item())
+    g = nhwc(detgen.normal((B, C, H, W), 196), torch.bfloat16)
+    gamma = detgen.normal((C,), 197, mean=1.0, std=0.3).cuda()
+    yf = y0.float()
+    mean = yf.mean((0, 1, 2)); invstd = torch.rsqrt(yf.var((0, 1, 2), unbiased=False) + 1e-5)
+    stats = torch.stack([gamma * invstd, -mean * gamma * invstd, mean, invstd]).contiguous()
+    z = torch.zeros(C, device="cuda")
+    coef = ops.bn_bwd_coef(g, None, y0, stats, C, gamma, z.clone(), z.clone(), False)
+    wpt = ops.pack_w3x3(w, C, C, torch.bfloat16, transpose=True)
+    a0 = ops.conv3x3_dgrad_applyfused(g, y0, stats, coef, wpt, x, xs, xt)
+    a1 = ops.conv3x3_dgrad_applyfused(g, y0, stats, coef, wpt, x, xs, xt, reverse=True)
+    assert torch.equal(a0[0], a1[0]) and torch.equal(a0[1], a1[1])
+    torch.testing.assert_close(a1[2].sum(0), a0[2].sum(0), rtol=1e-5, atol=1e-3)

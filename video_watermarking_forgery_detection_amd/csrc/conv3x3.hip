@@ -34,6 +34,8 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void*
                          const float* bw_gvec = nullptr, const void* ry = nullptr, const float* r_scale = nullptr,
                          const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr);
 
+int wm_take_sweep_hint();   // conv3x3_ws.hip: the hint is consumed by the launch it was set for, whichever kernel takes it
+
 namespace {
 
 constexpr int TH = 16, TW = 16;
@@ -381,6 +383,7 @@ extern "C" int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const floa
     hipStream_t s = (hipStream_t)stream;
     if (dtype == WM_BF16) launch_conv<bf16_t>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s);
     else launch_conv<float>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s);
+    wm_take_sweep_hint();   // (a no-op when the persistent kernel took it)
     WM_LAUNCH_CHECK("wm_conv3x3_fwd");
     return WM_OK;
 }

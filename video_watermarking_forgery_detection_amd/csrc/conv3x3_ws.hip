@@ -204,9 +204,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
 #pragma unroll
         for (int k = 0; k < XVP; ++k) {
             int py, px;
-            if (EDGE) {
-                if (k < KMAIN) { const int m = (ptid + 256 * k) >> 3; py = m >> 4; px = 2 + (m & 15); }
-                else { const int e = min((ptid + 256 * (k - KMAIN)) >> 3, 35); py = e >> 1; px = e & 1; }
+            if (EDGE) {   // a backward sweep (tiles right to left) shares its RIGHT two columns with the tile before it
+                if (k < KMAIN) { const int m = (ptid + 256 * k) >> 3; py = m >> 4; px = (a.reverse ? 0 : 2) + (m & 15); }
+                else { const int e = min((ptid + 256 * (k - KMAIN)) >> 3, 35); py = e >> 1; px = (a.reverse ? 16 : 0) + (e & 1); }
             } else {
                 const int pix = min((ptid + 256 * k) / VPP, NPIX - 1);
                 py = pix / HW; px = pix - py * HW;
@@ -217,7 +217,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         }
         const bool last_live = EDGE ? (((ptid + 256 * (XVP - 1 - KMAIN)) >> 3) < 36) : (((ptid + 256 * (XVP - 1)) / VPP) < NPIX);
         // does tile T start with the two columns its predecessor in the run ended with?
-        auto reuse_of = [&](int T) { return EDGE && BNBWD != 2 && !a.reverse && !(a.dbg & 64) && T > t_begin && (T % a.tilesX) != 0; };
+        auto reuse_of = [&](int T) {
+            if (!(EDGE && BNBWD != 2 && !(a.dbg & 64) && T > t_begin)) return false;
+            return a.reverse ? ((t_begin + (t_end - 1 - T)) % a.tilesX) != a.tilesX - 1 : (T % a.tilesX) != 0;
+        };
         // loads: always a valid address, never under a per-lane branch; the branches on `interior` are wave-uniform
         auto is_interior = [&](const TileGeo& g) {
             return g.ty0 >= 1 && g.ty0 + TH + 1 <= a.H && g.tx0 >= 1 && g.tx0 + TW + 1 <= a.W;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         };
         // edge vector k of the tile being published <- columns 16..17 of the tile in the other buffer
         auto copy_edge = [&](bf16_t* sX, const bf16_t* sPrev, int k) {
-            const int px = hpx[k] + 16;
+            const int px = hpx[k] + (a.reverse ? -16 : 16);
             const u32x4 w = *reinterpret_cast<const u32x4*>(sPrev + (hpy[k] * HW + px) * CIN + swz_px<CIN>(px, vec) * 8);
             if (k + 1 < XVP || last_live) *reinterpret_cast<u32x4*>(sX + lds[k]) = w;
         };
@@ -794,11 +797,18 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
     return (int)grid.x;
 }
 
-static int g_ws_reverse = 0;
+static int g_ws_reverse = -1;   // -1: follow the caller's sweep hint (default), 0 / 1: force forward / backward sweeps (A/B knob)
+static thread_local int g_sweep_hint = 0;
+// Optional hint for the NEXT persistent-conv launch issued from this thread: sweep the tiles backwards.  A kernel that starts
+// where its input's producer stopped finds the freshest part of that tensor in the Infinity Cache (256 MB; a layer's
+// tensor is 134 MB): the host alternates the direction along a chain of layers (engine.py).  Results do not depend on it
+// except for the summation order inside the per-workgroup statistics rows.
+extern "C" void wm_conv3x3_sweep_hint(int reverse) { g_sweep_hint = reverse ? 1 : 0; }
+int wm_take_sweep_hint() { const int h = g_sweep_hint; g_sweep_hint = 0; return g_ws_reverse >= 0 ? g_ws_reverse : h; }
 static int g_ws_variant = getenv("WM_WS_VARIANT") ? atoi(getenv("WM_WS_VARIANT")) : 0;   // A/B knobs -- 1: 32x32x16 MFMA consumers, 2: no XCD-aware run assignment, 3: producers at s_setprio 3, 8: no halo-edge reuse, 9: statistics sums not pinned, 10: filter committed to LDS before the first tile loads are issued
 extern "C" void wm_debug_ws_variant(int v) { g_ws_variant = v; }
 
-extern "C" void wm_debug_ws_direction(int reverse) { g_ws_reverse = reverse; }
+extern "C" void wm_debug_ws_direction(int reverse) { g_ws_reverse = (reverse == 0 || reverse == 1) ? reverse : -1; }
 
 // launcher used by conv3x3.hip
 int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void* wp, const float* bias, int nbias, const float* in_scale,
@@ -811,7 +821,7 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void*
     a.x = (const bf16_t*)x; a.ldx = ldx; a.wp = (const bf16_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
     a.in_shift = in_shift; a.y = (bf16_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY; a.tiles_per_wg = tiles_per_wg;
-    a.reverse = g_ws_reverse;
+    a.reverse = wm_take_sweep_hint();
     a.bw_stats4 = bw_stats4; a.bw_ld = bw_ld; a.bw_coef = bw_coef; a.bw_gvec = bw_gvec;
     a.ry = (const bf16_t*)ry; a.r_scale = r_scale; a.r_shift = r_shift;
     a.ay = (const bf16_t*)ay; a.dy_out = (bf16_t*)dy_out;

@@ -30,6 +30,8 @@ void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale,
                         int ldyb = 0, const float* bstats4 = nullptr, int bstats_ld = 0, const float* bcoef = nullptr,
                         const float* gvec = nullptr);
 
+int wm_take_sweep_hint();   // conv3x3_ws.hip
+
 namespace {
 
 constexpr int TW = 16;
@@ -406,6 +408,7 @@ extern "C" int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* i
     if (dtype == WM_BF16 && !v1) wm_launch_wgrad_ws(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, nslabs_for(B, H, W), s);
     else if (dtype == WM_BF16) launch_wgrad<bf16_t>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
     else launch_wgrad<float>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
+    wm_take_sweep_hint();   // (a no-op when the persistent kernel took it)
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad");
     const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
     const size_t slab_elems = (size_t)9 * CinP * CoutP;

@@ -9,6 +9,8 @@
 // producer variant of it 1.4 % slower still -- tools/ab_step.py.)
 #include "wm_common.h"
 
+int wm_take_sweep_hint();   // conv3x3_ws.hip
+
 namespace {
 
 constexpr int TH = 16, TW = 16, HH = 18, HW = 18, CB = 64;
@@ -25,6 +27,7 @@ struct WsWgArgs {
     const float* gvec; int ldgv;   // DYF == 2: g is one row per sample (the layer's output was globally pooled); dy/lddy unused
     float* ws;           // [gridDim.x][9][CinP][CoutP]
     int B, H, W, tilesX, tilesY, ntiles, ciBlocks, coBlocks;
+    int reverse;
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
     struct TileGeo { int b, ty0, tx0; };
     auto geo = [&](int tile) {
         TileGeo g;
-        int t = tile;
+        int t = a.reverse ? t_begin + (t_end - 1 - tile) : tile;   // (wm_conv3x3_sweep_hint: start where the producer of dy stopped)
         const int txi = t % a.tilesX; t /= a.tilesX;
         const int tyi = t % a.tilesY; t /= a.tilesY;
         g.b = t; g.ty0 = tyi * TH; g.tx0 = txi * TW;
@@ -343,6 +346,7 @@ void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale,
     a.bscale = bstats4; a.bshift = bstats4 ? bstats4 + bstats_ld : nullptr; a.bmean = bstats4 ? bstats4 + 2 * bstats_ld : nullptr;
     a.binvstd = bstats4 ? bstats4 + 3 * bstats_ld : nullptr; a.bcoef = bcoef; a.gvec = gvec; a.ldgv = bstats_ld;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
+    a.reverse = wm_take_sweep_hint();
     a.ciBlocks = wm_cdiv(CinX, CB); a.coBlocks = wm_cdiv(CoutY, CB);
     const dim3 block(512);
     if (CinX <= 16) {   // one 16-channel input block; the slab keeps its 64-row pitch (rows >= 16 are never read back)

@@ -22,11 +22,18 @@ from . import ops
 
 class Act:
     """NHWC activation: logical value = t (if scale is None) or relu(scale*t+shift)."""
-    __slots__ = ("t", "C", "scale", "shift", "bwd")
+    __slots__ = ("t", "C", "scale", "shift", "bwd", "rev")
 
-    def __init__(self, t, C, scale=None, shift=None):
+    def __init__(self, t, C, scale=None, shift=None, rev=None):
         self.t, self.C, self.scale, self.shift = t, C, scale, shift
         self.bwd = None   # backward: (g, partials) left by the consumer's dgrad when it reduced this layer's BatchNorm sums
+        self.rev = rev    # sweep direction of the conv that just wrote t (False forward, True backward, None: not fresh)
+
+
+def _opposite(rev):
+    """sweep direction for a kernel whose main input was written in direction `rev`: start where the producer stopped (its
+    last tiles are the part of the tensor still in the Infinity Cache).  None (not fresh) -> forward."""
+    return rev is False
 
 
 def round_up(n, m):
@@ -65,7 +72,8 @@ def cbr_forward(conv, bn, x, dtype, perm=None, training=True, momentum=0.1):
     wp = _packed(conv, CoutP, CinX, dtype, perm, False)
     bias = conv.bias.data if conv.bias is not None else None
     B, H, W, _ = x.t.shape
-    y, st = ops.conv3x3_fwd(x.t, wp, bias, x.scale, x.shift, want_stats=training)
+    d = _opposite(x.rev)
+    y, st = ops.conv3x3_fwd(x.t, wp, bias, x.scale, x.shift, want_stats=training, reverse=d)
     if training:
         stats = ops.bn_finalize(st, Cout, CoutP, B * H * W, bn.weight.data, bn.bias.data, bn.running_mean,
                                 bn.running_var, momentum if bn.momentum is None else bn.momentum, bn.eps)
@@ -79,7 +87,7 @@ def cbr_forward(conv, bn, x, dtype, perm=None, training=True, momentum=0.1):
         stats[3, :Cout] = invstd
     ctx = CBRCtx()
     ctx.x, ctx.y, ctx.stats, ctx.perm, ctx.training = x, y, stats, perm, training
-    ctx.out = Act(y, Cout, stats[0], stats[1])
+    ctx.out = Act(y, Cout, stats[0], stats[1], rev=d)
     return ctx.out, ctx
 
 
@@ -100,6 +108,11 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
     dbias = None
     # The dgrad that produced g (the next layer's, below) may have reduced this layer's sums in its epilogue already
     pre, ctx.out.bwd = ctx.out.bwd, None
+    d = _opposite(getattr(g, "_wm_rev", None)) if g is not None else False   # this layer's input-gradient sweep
+
+    def tag(gx, direction=d):
+        gx._wm_rev = direction
+        return gx
     gam, dgam, dbet = bn.weight.data, grads[bn.weight], grads[bn.bias]
 
     def coef_of():
@@ -129,8 +142,8 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
         if feed_stats:
             gx, part = ops.conv3x3_dgrad_bwdstats(y, wpt, x.t, x.scale, x.shift, gvec, ctx.stats, coef)
             x.bwd = (gx, part)
-            return gx
-        return ops.conv3x3_dgrad_gvfused(y, wpt, gvec, ctx.stats, coef)
+            return tag(gx)
+        return tag(ops.conv3x3_dgrad_gvfused(y, wpt, gvec, ctx.stats, coef))
     # An ordinary 64 -> 64 layer: the input-gradient kernel reads g and y, forms dy while staging and leaves it in memory
     # for the weight gradient -- the stand-alone apply pass is gone.
     if (g is not None and need_input_grad and perm_dev is None and ctx.perm is None and rows in (64, 32)
@@ -139,23 +152,23 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
         coef = coef_of()
         wpt = _packed(conv, 64, rows, dtype, None, True)
         if feed_stats:
-            dy, gx, part = ops.conv3x3_dgrad_applyfused(g, y, ctx.stats, coef, wpt, x.t, x.scale, x.shift)
+            dy, gx, part = ops.conv3x3_dgrad_applyfused(g, y, ctx.stats, coef, wpt, x.t, x.scale, x.shift, reverse=d)
             x.bwd = (gx, part)
         else:
-            dy, gx, _ = ops.conv3x3_dgrad_applyfused(g, y, ctx.stats, coef, wpt)
-        ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate)
-        return gx
+            dy, gx, _ = ops.conv3x3_dgrad_applyfused(g, y, ctx.stats, coef, wpt, reverse=d)
+        ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, reverse=not d)
+        return tag(gx)
     dy = ops.bn_bwd(g, gvec, y, ctx.stats, Cout, gam, dgam, dbet, accumulate, dbias, coef=coef_of())
-    ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, perm_dev=perm_dev)
+    ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, perm_dev=perm_dev, reverse=True)   # the apply pass swept forwards
     if not need_input_grad:
         return None
     wpt = _packed(conv, y.shape[-1], rows, dtype, ctx.perm, True)
     if feed_stats:
         gx, part = ops.conv3x3_dgrad_bwdstats(dy, wpt, x.t, x.scale, x.shift)
         x.bwd = (gx, part)
-        return gx
+        return tag(gx, False)
     gx, _ = ops.conv3x3_fwd(dy, wpt, None, None, None, want_stats=False)
-    return gx
+    return tag(gx, False)
 
 
 def grad_dict(module, flat_grad=None):

@@ -224,9 +224,16 @@ def conv3x3_nparts(B, H, W, Cin, CoutP, dtype):
     return _lib.lib().wm_conv3x3_nparts(c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(CoutP), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32))
 
 
-def conv3x3_fwd(x, wp, bias, in_scale, in_shift, want_stats, Cin=None):
+def _sweep(reverse):
+    """hint for the next conv / wgrad launch: sweep the tiles backwards (start where the producer of the input stopped)"""
+    if reverse:
+        _lib.lib().wm_conv3x3_sweep_hint(c_int(1))
+
+
+def conv3x3_fwd(x, wp, bias, in_scale, in_shift, want_stats, Cin=None, reverse=False):
     """x [B,H,W,ld]; wp [9,CoutP,Cin]; returns y [B,H,W,CoutP] and stat partials (or None)."""
     _need_cuda(x, wp)
+    _sweep(reverse)
     B, H, W, ldx = x.shape
     CoutP, CinW = wp.shape[1], wp.shape[2]
     Cin = CinW if Cin is None else Cin
@@ -363,7 +370,7 @@ def conv3x3_dgrad_bwdstats_supported(CoutY, CinP, dtype):
     return bool(_lib.lib().wm_conv3x3_dgrad_bwdstats_supported(c_int(CoutY), c_int(CinP), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32)))
 
 
-def conv3x3_dgrad_bwdstats(src, wpt, ry, r_scale, r_shift, gvec=None, stats=None, coef=None):
+def conv3x3_dgrad_bwdstats(src, wpt, ry, r_scale, r_shift, gvec=None, stats=None, coef=None, reverse=False):
     """input gradient dx = conv3x3(dy, wpt) whose epilogue also reduces the BatchNorm-backward sums of the layer that feeds
     this one (raw output ry, constants r_scale / r_shift).  src = dy, or (with gvec, stats, coef) this layer's raw output
     with the apply pass fused.  Returns (dx, partials [n,2,64])."""
@@ -373,6 +380,7 @@ def conv3x3_dgrad_bwdstats(src, wpt, ry, r_scale, r_shift, gvec=None, stats=None
     assert (gvec is None) == (stats is None) == (coef is None)
     dx = torch.empty(B, H, W, CinP, device=src.device, dtype=src.dtype)
     part = torch.empty(conv3x3_nparts(B, H, W, CoutY, CinP, src.dtype), 2, CinP, device=src.device, dtype=torch.float32)
+    _sweep(reverse)
     rc = _lib.lib().wm_conv3x3_dgrad_bwdstats(_p(src), c_int(lds), c_int(CoutY), _p(wpt), _p(gvec), _p(stats), _p(coef), _p(ry), _p(r_scale),
                                               _p(r_shift), _p(dx), _p(part), c_int(B), c_int(H), c_int(W), c_int(CinP),
                                               c_int(dtype_id(src)), _stream())
@@ -384,7 +392,7 @@ def conv3x3_dgrad_applyfused_supported(CoutY, CinP, dtype):
     return bool(_lib.lib().wm_conv3x3_dgrad_applyfused_supported(c_int(CoutY), c_int(CinP), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32)))
 
 
-def conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry=None, r_scale=None, r_shift=None):
+def conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry=None, r_scale=None, r_shift=None, reverse=False):
     """64 -> 64 layer, gradient g a dense tensor: the BatchNorm-backward apply pass inside the input-gradient kernel.
     Returns (dy, dx, partials or None): dy for the weight gradient, dx = conv3x3(dy, wpt), partials = the feeding layer's
     BatchNorm-backward sums when its raw output ry (+ r_scale, r_shift) is given."""
@@ -396,6 +404,7 @@ def conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry=None, r_scale=None, r_sh
     dx = torch.empty(B, H, W, CinP, device=y.device, dtype=y.dtype)
     part = torch.empty(conv3x3_nparts(B, H, W, 64, 64, y.dtype), 2, 64, device=y.device, dtype=torch.float32) if ry is not None else None
     info = {"B": B, "H": H, "W": W, "feed": ry is not None, "dtype": y.dtype}
+    _sweep(reverse)
     rc = _timed("conv3x3_dgrad_applyfused", info, lambda: _lib.lib().wm_conv3x3_dgrad_applyfused(
         _p(g), _p(y), _p(stats), _p(coef), _p(wpt), _p(dy), _p(dx), _p(ry), _p(r_scale), _p(r_shift), _p(part), c_int(B), c_int(H), c_int(W),
         c_int(CinP), c_int(dtype_id(y)), _stream()))
@@ -464,8 +473,9 @@ def colsum(partials, C, ldp, out, accumulate):
     _lib.check(rc, "wm_colsum_finalize")
 
 
-def conv3x3_wgrad(x, CinX, in_scale, in_shift, dy, dw, accumulate, perm_dev=None):
+def conv3x3_wgrad(x, CinX, in_scale, in_shift, dy, dw, accumulate, perm_dev=None, reverse=False):
     """dw [Cout,Cin,3,3] f32 view (written in place)."""
+    _sweep(reverse)
     B, H, W, ldx = x.shape
     CoutY = dy.shape[-1]
     L = _lib.lib()
