@@ -40,12 +40,37 @@ def round_up(n, m):
     return (n + m - 1) // m * m
 
 
+_image_acts = None   # id(image) -> (image, version, dtype, NHWC16 tensor) while a share_image_acts() block is open
+
+
+@contextlib.contextmanager
+def share_image_acts():
+    """inside the block, image_to_act converts an image tensor once: a training step feeds `images` to the discriminator and the
+    encoder and `encoded` to two discriminator passes (the images are not modified in between -- checked through their
+    version counters)"""
+    global _image_acts
+    if _image_acts is not None:
+        yield
+        return
+    _image_acts = {}
+    try:
+        yield
+    finally:
+        _image_acts = None
+
+
 def image_to_act(img, dtype):
     """[B,3,H,W] f32 (NCHW) -> Act over a [B,H,W,16] zero-padded NHWC tensor."""
     B, C, H, W = img.shape
     assert C == 3
+    if _image_acts is not None:
+        hit = _image_acts.get(id(img))
+        if hit is not None and hit[0] is img and hit[1] == img._version and hit[2] == dtype:
+            return Act(hit[3], 3)
     t = torch.empty(B, H, W, 16, device=img.device, dtype=dtype)
     ops.nchw_to_nhwc(img, t, 0, 13)
+    if _image_acts is not None:
+        _image_acts[id(img)] = (img, img._version, dtype, t)
     return Act(t, 3)
 
 

@@ -218,7 +218,7 @@ class Hidden:
         try:
             for n in nets:
                 n.refresh_packs()
-            with engine.defer_bn_counters():
+            with engine.defer_bn_counters(), engine.share_image_acts():
                 return self._train_step(images, messages, B, cfg, ed, enc_net, dec_net, D, gD, gE, gDec, extra_encoded_grad, clip)
         finally:
             for n in nets:
