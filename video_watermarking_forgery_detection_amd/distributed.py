@@ -36,17 +36,29 @@ def shard_indices(n, rank, world_size):
 
 
 class GradSync:
-    """callable(flat_grad): all-reduce SUM then / world, in place, on the current stream."""
+    """callable(flat_grad): all-reduce SUM then / world, in place.  start() / finish() split the call so that a network's
+    bucket travels over xGMI while the backward of the next network still runs (hidden.py: the decoder's bucket overlaps the
+    attack + encoder backward): the collective is queued on RCCL's stream behind the work already on the current stream, and
+    finish() makes the current stream wait for it."""
 
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
-    def __call__(self, flat):
+    def start(self, flat):
         if self.world == 1:
-            return flat
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            return None
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat
+
+    def finish(self, handle):
+        if handle is None:
+            return
+        work, flat = handle
+        work.wait()
         flat.mul_(1.0 / self.world)
+
+    def __call__(self, flat):
+        self.finish(self.start(flat))
         return flat
 
 

@@ -257,6 +257,9 @@ class Hidden:
         msg_out, g_dec = ops.message_loss(decoded, messages, 2.0 * cfg.decoder_loss / decoded.numel())   # mse, bit error, grad
         g_dec = g_dec.view_as(decoded)
         g_noised = dec_net.bwd(cDec, g_dec, gDec, accumulate=False, need_input_grad=True)
+        # data parallel: the decoder's gradient bucket goes out now and travels while the attack and the encoder run their backward
+        overlap = self.grad_sync is not None and hasattr(self.grad_sync, "start")
+        pending_dec = self.grad_sync.start(dec_net.flat_grads) if overlap else None
         g_from_noise = _noise_bwd(ed.noiser, cN, g_noised)
         ops.axpy_(g_enc, g_from_noise.contiguous())
         extra_logs = []
@@ -266,7 +269,10 @@ class Hidden:
         enc_net.bwd(cE, g_enc, gE, accumulate=False)
         if self.grad_sync is not None:
             self.grad_sync(enc_net.flat_grads)
-            self.grad_sync(dec_net.flat_grads)
+            if overlap:
+                self.grad_sync.finish(pending_dec)
+            else:
+                self.grad_sync(dec_net.flat_grads)
         if clip is not None:
             clip(enc_net.flat_grads)
             clip(dec_net.flat_grads)
