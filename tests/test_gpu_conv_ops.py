@@ -710,3 +710,41 @@ def test_backward_sweep_hint_changes_only_the_summation_order(case):
     a1 = ops.conv3x3_dgrad_applyfused(g, y0, stats, coef, wpt, x, xs, xt, reverse=True)
     assert torch.equal(a0[0], a1[0]) and torch.equal(a0[1], a1[1])
     torch.testing.assert_close(a1[2].sum(0), a0[2].sum(0), rtol=1e-5, atol=1e-3)
+
+
+def test_body_layer_backward_at_the_baseline_size():
+    """BASELINE size (B=16, 256x256, 64 -> 64, bf16): the fused backward of a body layer (apply pass + feeding layer's sums inside the
+    input-gradient kernel, both sweep directions) is bit-identical to the stand-alone sequence, and the forward / input-gradient
+    kernels satisfy the adjoint identity <conv(a), g> == <a, conv^T(g)> (a size-independent property, f32 accumulation)."""
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, C = 16, 256, 256, 64
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    g = torch.randn(B, H, W, C, device="cuda", generator=gen).to(torch.bfloat16)
+    y = (torch.randn(B, H, W, C, device="cuda", generator=gen) + 0.3).to(torch.bfloat16)
+    ry = (torch.randn(B, H, W, C, device="cuda", generator=gen) - 0.2).to(torch.bfloat16)
+    w = detgen.normal((C, C, 3, 3), 221, std=0.05).cuda()
+    wp = ops.pack_w3x3(w, C, C, torch.bfloat16)
+    wpt = ops.pack_w3x3(w, C, C, torch.bfloat16, transpose=True)
+    gamma = detgen.normal((C,), 222, mean=1.0, std=0.3).cuda(); beta = detgen.normal((C,), 223, std=0.3).cuda()
+    yf = y.float()
+    mean = yf.mean((0, 1, 2)); invstd = torch.rsqrt(yf.var((0, 1, 2), unbiased=False) + 1e-5)
+    stats = torch.stack([gamma * invstd, beta - mean * gamma * invstd, mean, invstd]).contiguous()
+    rsc = detgen.normal((C,), 224, mean=1.0, std=0.3).cuda(); rsh = detgen.normal((C,), 225, std=0.3).cuda()
+    z = torch.zeros(C, device="cuda")
+    coef = ops.bn_bwd_coef(g, None, y, stats, C, gamma, z.clone(), z.clone(), False)
+    dy0 = ops.bn_bwd(g, None, y, stats, C, gamma, z.clone(), z.clone(), False, None, coef=coef)
+    dx0, part0 = ops.conv3x3_dgrad_bwdstats(dy0, wpt, ry, rsc, rsh)
+    for rev in (False, True):
+        dy1, dx1, part1 = ops.conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry, rsc, rsh, reverse=rev)
+        assert torch.equal(dy0, dy1) and torch.equal(dx0, dx1)
+        torch.testing.assert_close(part1.sum(0), part0.sum(0), rtol=1e-5, atol=1e-2)
+    # adjoint identity on the plain kernels: conv(a) with w, conv^T(gg) with the flipped / transposed w
+    a = torch.randn(B, H, W, C, device="cuda", generator=gen).to(torch.bfloat16)
+    gg = torch.randn(B, H, W, C, device="cuda", generator=gen).to(torch.bfloat16)
+    ca, _ = ops.conv3x3_fwd(a, wp, None, None, None, want_stats=False)
+    ctg, _ = ops.conv3x3_fwd(gg, wpt, None, None, None, want_stats=False, reverse=True)
+    pl = ca.double() * gg.double(); pr = a.double() * ctg.double()
+    lhs, rhs = pl.sum().item(), pr.sum().item()
+    # each side rounds its 67M outputs to bf16 (relative error uniform in +-2^-9): the sums differ by a random walk of that size
+    sigma = (2.0 ** -9 / 3 ** 0.5) * ((pl * pl).sum().item() ** 0.5 + (pr * pr).sum().item() ** 0.5)
+    assert abs(lhs - rhs) <= 6 * sigma, (lhs, rhs, sigma)
