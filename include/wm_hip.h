@@ -44,6 +44,14 @@ extern "C" {
 const char* wm_last_error_string(void);
 int wm_abi_version(void);
 
+/* A BatchNorm-backward finalisation that rides on another launch (wm_conv3x3_wgrad_fin: a few extra workgroups of the
+ * weight-gradient slab reduction) instead of costing one of its own.  Same arguments and result as wm_bn_bwd_finalize_raw
+ * (mean != NULL: rows hold sum(gz), sum(gz*y)) / wm_bn_bwd_finalize (mean == NULL); nparts <= 256. */
+typedef struct WmBnBwdFin {
+    const float* partials; int nparts; int C; int CP; double count; const float* gamma; const float* mean; const float* invstd;
+    float* dgamma; float* dbeta; int accumulate; float* coef;
+} WmBnBwdFin;
+
 /* ------------------------------------------------------------------ block-JPEG attack
  * replaces: noise_layers/jpeg.py:226-240 (Jpeg.forward), :259-273 (JpegSS), :295-306 (JpegMask)
  * with helpers :52-211.  x,y: [B,3,H,W] f32 NCHW.  mode 0 = round, 1 = round_ss, 2 = mask.
@@ -161,6 +169,13 @@ size_t wm_conv3x3_wgrad_ws_bytes(int B, int H, int W, int CinX, int CoutY);
 int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift,
                      const void* dy, int lddy, int CoutY, float* ws, float* dw, int accumulate, int B,
                      int H, int W, int Cin, int Cout, const int* perm_dev, int dtype, void* stream);
+/* wm_conv3x3_wgrad / wm_conv3x3_wgrad_gvfused whose slab-reduction launch also carries a BatchNorm-backward finalisation of
+ * ANOTHER layer (fin may be NULL): in a backward sweep the input-gradient kernel of layer l emits the sums of layer l-1
+ * (wm_conv3x3_dgrad_bwdstats / _applyfused), and layer l's weight gradient is the next launch anyway. */
+int wm_fin_rider_enabled(void);
+int wm_conv3x3_wgrad_fin(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy, int lddy,
+                         int CoutY, float* ws, float* dw, int accumulate, int B, int H, int W, int Cin, int Cout,
+                         const int* perm_dev, int dtype, const WmBnBwdFin* fin, void* stream);
 /* The same with the BatchNorm-backward APPLY pass fused, for bf16 image-fed first layers (CinX <= 16) whose input needs
  * no gradient: dy is formed from g (gradient wrt the ReLU output, stride ldg), y (the raw conv output, stride ldy),
  * stats4 = f32[4][CoutY] = scale | shift | mean | invstd and coef = wm_bn_bwd_finalize's f32[3][CoutY] while the tile is
@@ -182,6 +197,9 @@ int wm_conv3x3_gvfused_supported(int CinX, int CoutY, int dtype);
 int wm_conv3x3_wgrad_gvfused(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const float* gvec,
                              const void* y, int ldy, int CoutY, const float* stats4, const float* coef, float* ws, float* dw,
                              int accumulate, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
+int wm_conv3x3_wgrad_gvfused_fin(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const float* gvec,
+                                 const void* y, int ldy, int CoutY, const float* stats4, const float* coef, float* ws, float* dw,
+                                 int accumulate, int B, int H, int W, int Cin, int Cout, int dtype, const WmBnBwdFin* fin, void* stream);
 int wm_conv3x3_dgrad_gvfused(const void* y, int ldy, int CoutY, const void* wpt, const float* gvec, const float* stats4,
                              const float* coef, void* dx, int B, int H, int W, int CinP, int dtype, void* stream);
 /* Input gradient (bf16, CoutY in {64,32} -> CinP = 64) whose epilogue also reduces the BatchNorm-backward sums of the

@@ -748,3 +748,68 @@ def test_body_layer_backward_at_the_baseline_size():
     # each side rounds its 67M outputs to bf16 (relative error uniform in +-2^-9): the sums differ by a random walk of that size
     sigma = (2.0 ** -9 / 3 ** 0.5) * ((pl * pl).sum().item() ** 0.5 + (pr * pr).sum().item() ** 0.5)
     assert abs(lhs - rhs) <= 6 * sigma, (lhs, rhs, sigma)
+
+
+@pytest.mark.parametrize("case", [(2, 40, 36, False), (16, 64, 64, True), (3, 33, 47, False)])
+def test_bn_backward_finalisation_riding_on_the_weight_gradient_reduction(case):
+    """wm_conv3x3_wgrad_fin / wm_conv3x3_wgrad_gvfused_fin: a few extra workgroups of the slab-reduction launch finish ANOTHER layer's
+    BatchNorm-backward sums (dgamma, dbeta, coef) -- bit-identical to wm_bn_bwd_finalize_raw, and dw unchanged."""
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, pooled = case
+    C = 64
+    x = nhwc(detgen.normal((B, C, H, W), 231), torch.bfloat16)
+    xs = detgen.normal((C,), 232, mean=1.0, std=0.3).cuda(); xt = detgen.normal((C,), 233, std=0.3).cuda()
+    dy = nhwc(detgen.normal((B, C, H, W), 234), torch.bfloat16)
+    # the other layer: partial rows as a dgrad epilogue would leave them
+    n = ops.conv3x3_nparts(B, H, W, C, C, torch.bfloat16)
+    part = detgen.normal((n, 2, C), 235).cuda().contiguous()
+    yprev = nhwc(detgen.normal((B, C, H, W), 236, mean=0.3), torch.bfloat16)
+    gamma = detgen.normal((C,), 237, mean=1.0, std=0.3).cuda()
+    mean = detgen.normal((C,), 238, std=0.3).cuda(); invstd = detgen.uniform((C,), 239).cuda() + 0.5
+    pstats = torch.stack([gamma * invstd, -mean * gamma * invstd, mean, invstd]).contiguous()
+    for accumulate in (False, True):
+        dg0 = torch.full((C,), 0.25, device="cuda"); db0 = torch.full((C,), -0.5, device="cuda")
+        c0 = ops.bn_bwd_coef_raw(part.clone(), yprev, pstats, C, gamma, dg0, db0, accumulate)
+        dg1 = torch.full((C,), 0.25, device="cuda"); db1 = torch.full((C,), -0.5, device="cuda")
+        fin = dict(partials=part, y_shape=tuple(yprev.shape), stats=pstats, C=C, gamma=gamma, dgamma=dg1, dbeta=db1, accumulate=accumulate)
+        dw0 = torch.zeros(C, C, 3, 3, device="cuda"); dw1 = torch.zeros(C, C, 3, 3, device="cuda")
+        if pooled:
+            gvec = detgen.normal((B, C), 240).cuda() / (H * W)
+            yf = dy.float()
+            m2 = yf.mean((0, 1, 2)); i2 = torch.rsqrt(yf.var((0, 1, 2), unbiased=False) + 1e-5)
+            st = torch.stack([i2, -m2 * i2, m2, i2]).contiguous()
+            z = torch.zeros(C, device="cuda")
+            coef = ops.bn_bwd_coef(None, gvec, dy, st, C, torch.ones(C, device="cuda"), z.clone(), z.clone(), False)
+            ops.conv3x3_wgrad_gvfused(x, xs, xt, gvec, dy, st, coef, dw0, False)
+            c1 = ops.conv3x3_wgrad_gvfused(x, xs, xt, gvec, dy, st, coef, dw1, False, fin=fin)
+        else:
+            assert ops.conv3x3_wgrad(x, C, xs, xt, dy, dw0, False) is None
+            c1 = ops.conv3x3_wgrad(x, C, xs, xt, dy, dw1, False, fin=fin)
+        assert dw0.abs().max().item() > 0 and torch.equal(dw0, dw1)
+        assert torch.equal(c0, c1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+
+
+def test_finalisation_riders_keep_the_training_step():
+    """the HiDDeN step with the feeding layers' BatchNorm-backward finalisations riding on the weight-gradient reductions is
+    bit-identical to the step with stand-alone finalisation launches"""
+    import ctypes
+    from video_watermarking_forgery_detection_amd import _lib
+    from video_watermarking_forgery_detection_amd.hidden_models import Hidden
+    from video_watermarking_forgery_detection_amd import noise_layers as NL
+    from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
+    L = _lib.lib()
+    outs = []
+    try:
+        for on in (1, 0):
+            L.wm_debug_fin_rider(ctypes.c_int(on))
+            torch.manual_seed(10)
+            h = Hidden(HiDDenConfiguration(H=64, W=64), torch.device("cuda"), NL.Jpeg(50), None, compute_dtype=torch.bfloat16)
+            images = detgen.uniform((4, 3, 64, 64), 241).cuda(); messages = (detgen.uniform((4, 30), 242) > 0.5).float().cuda()
+            for _ in range(3):
+                losses, _ = h.train_on_batch([images, messages])
+            outs.append((dict(losses), [p.detach().clone() for p in list(h.encoder_decoder.parameters()) + list(h.discriminator.parameters())]))
+    finally:
+        L.wm_debug_fin_rider(ctypes.c_int(1))
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)

@@ -229,8 +229,9 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const T* __restrict__ g, int
     }
 }
 
-// partials [nparts][2][CP] -> dgamma, dbeta, coef[3][CP].  raw_mean != nullptr: the second row holds sum(gz*y) (reduced by a
-// dgrad epilogue, conv3x3_ws.hip BWDST) instead of sum(gz*xhat): xhat = (y-mean)*invstd is applied here, in double
+// partials [nparts][2][CP] -> dgamma, dbeta, coef[3][CP] (the body lives in wm_common.h: the weight-gradient slab reduction can carry
+// it as extra workgroups).  raw_mean != nullptr: the second row holds sum(gz*y) (reduced by a dgrad epilogue, conv3x3_ws.hip BWDST)
+// instead of sum(gz*xhat): xhat = (y-mean)*invstd is applied there, in double
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, int CP,
                                                               double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ invstd, float* dgamma,
@@ -239,40 +240,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ pgv = nullptr,
                                                               const float* __restrict__ pn = nullptr,
                                                               const float* __restrict__ ps = nullptr) {
-    // pgv != nullptr (a globally pooled layer): row p is sample p's (gv*N+, gv*S+) formed here from the pooled statistics
-    // 8 channels x 32 row slices per workgroup: every thread's <= 8 row loads are independent and in flight together
-    __shared__ double s1[32][8], s2[32][8];
-    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + cl;
-    double a1 = 0.0, a2 = 0.0;
-    if (c < CP) {
-#pragma unroll 8
-        for (int p = sl; p < nparts; p += 32) {
-            if (pgv) {
-                const float gv = pgv[(size_t)p * CP + c];
-                a1 += (double)(gv * pn[(size_t)p * CP + c]);
-                a2 += (double)(gv * ps[(size_t)p * CP + c]);
-            } else {
-                a1 += (double)partials[((size_t)p * 2 + 0) * CP + c];
-                a2 += (double)partials[((size_t)p * 2 + 1) * CP + c];
-            }
-        }
-    }
-    s1[sl][cl] = a1; s2[sl][cl] = a2;
-    __syncthreads();
-    if (sl == 0 && c < CP) {
-        for (int k = 1; k < 32; ++k) { a1 += s1[k][cl]; a2 += s2[k][cl]; }
-        if (raw_mean && c < C) a2 = (a2 - (double)raw_mean[c] * a1) * (double)invstd[c];
-        if (c < C) {
-            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)a1;
-            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)a2;
-            coef[c] = gamma[c] * invstd[c];
-            coef[CP + c] = (float)(a1 / count);
-            coef[2 * CP + c] = (float)(a2 / count);
-        } else {
-            coef[c] = 0.f; coef[CP + c] = 0.f; coef[2 * CP + c] = 0.f;
-        }
-    }
+    __shared__ double sh[2 * 32 * 8];
+    WmBnBwdFin j;
+    j.partials = partials; j.nparts = nparts; j.C = C; j.CP = CP; j.count = count; j.gamma = gamma; j.mean = raw_mean; j.invstd = invstd;
+    j.dgamma = dgamma; j.dbeta = dbeta; j.accumulate = accumulate; j.coef = coef;
+    wm_bn_bwd_finalize_block(j, (int)blockIdx.x, sh, pgv, pn, ps);
 }
 
 // out[c] (+)= sum_p partials[p*ldp + c]

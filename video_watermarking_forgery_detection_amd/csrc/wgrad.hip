@@ -252,14 +252,21 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgArgs<T> a) {
 // A workgroup owns 32 quads of 4 consecutive co and splits the slabs 8 ways: every thread streams nslabs/8 slabs with
 // 16-byte loads, 8 of them in flight; the 8 partial sums meet in LDS (fixed order: deterministic).
 constexpr int RSPLIT = 8, RQUADS = 256 / RSPLIT;
+// Workgroups >= nred carry a rider: the BatchNorm-backward finalisation of another layer (WmBnBwdFin, 8 channels each) -- in a
+// backward sweep the sums of layer l-1 are ready when layer l's weight gradient runs, and a launch of its own would cost 5 us.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nslabs, int CinP, int CoutP,
                                                            float* __restrict__ dw, int Cin, int Cout,
-                                                           const int* __restrict__ perm, int accumulate) {
+                                                           const int* __restrict__ perm, int accumulate, int nred, WmBnBwdFin fin) {
     __shared__ float4 red[RSPLIT][RQUADS];
+    static_assert(sizeof(float4) * RSPLIT * RQUADS >= sizeof(double) * 2 * 32 * 8, "the rider's LDS fits in the reduction's");
+    if ((int)blockIdx.x >= nred) {
+        wm_bn_bwd_finalize_block(fin, (int)blockIdx.x - nred, reinterpret_cast<double*>(&red[0][0]));
+        return;
+    }
     const size_t slab_elems = (size_t)9 * CinP * CoutP;
     const size_t nquads = slab_elems / 4;
     const int ql = threadIdx.x % RQUADS, sp = threadIdx.x / RQUADS;
-    for (size_t q0 = (size_t)blockIdx.x * RQUADS; q0 < nquads; q0 += (size_t)gridDim.x * RQUADS) {
+    for (size_t q0 = (size_t)blockIdx.x * RQUADS; q0 < nquads; q0 += (size_t)nred * RQUADS) {
         const size_t qd = q0 + ql;
         float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
         if (qd < nquads) {
@@ -310,6 +317,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+inline int nslabs_for(int B, int H, int W);
+// the slab reduction (+ an optional rider)
+static int launch_wgrad_reduce(float* ws, int nslabs, int CinP, int CoutP, float* dw, int Cin, int Cout, const int* perm, int accumulate,
+                               const WmBnBwdFin* fin, hipStream_t s) {
+    const size_t slab_elems = (size_t)9 * CinP * CoutP;
+    const size_t rb = (slab_elems / 4 + RQUADS - 1) / RQUADS;
+    const int blocks = (int)(rb > 2048 ? 2048 : rb);
+    WmBnBwdFin f = {};
+    int extra = 0;
+    if (fin) {
+        if (!fin->partials || !fin->gamma || !fin->invstd || !fin->coef || fin->nparts <= 0 || fin->nparts > 256 || fin->C <= 0 || fin->CP < fin->C)
+            return WM_E_BADARG;
+        f = *fin;
+        extra = wm_cdiv(fin->CP, 8);
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks + extra), dim3(256), 0, s, ws, nslabs, CinP, CoutP, dw, Cin, Cout, perm, accumulate,
+                       blocks, f);
+    return WM_OK;
+}
+
 inline int nslabs_for(int B, int H, int W) {
     const long n = (long)B * wm_cdiv(H, 16) * wm_cdiv(W, 16);
     return (int)(n < 256 ? n : 256);
@@ -355,14 +382,14 @@ extern "C" int wm_conv3x3_wgrad_bnfused(const void* x, int ldx, int CinX, const 
     wm_launch_wgrad_ws(x, ldx, CinX, nullptr, nullptr, g, ldg, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, y, ldy, stats4, CoutY, coef);
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad_bnfused");
     const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
-    const size_t slab_elems = (size_t)9 * CinP * CoutP;
-    const size_t rb = (slab_elems / 4 + RQUADS - 1) / RQUADS;
-    const int blocks = (int)(rb > 2048 ? 2048 : rb);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout,
-                       (const int*)nullptr, accumulate);
+    launch_wgrad_reduce(ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout, nullptr, accumulate, nullptr, s);
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad_bnfused(reduce)");
     return WM_OK;
 }
+
+static int g_fin_rider = getenv("WM_NO_FIN_RIDER") ? 0 : 1;
+extern "C" void wm_debug_fin_rider(int on) { g_fin_rider = on; }   // A/B knob (tools/ab_step.py)
+extern "C" int wm_fin_rider_enabled(void) { return g_fin_rider; }
 
 static int g_gv_fuse = getenv("WM_NO_GV_FUSE") ? 0 : 1;
 extern "C" void wm_debug_gv_fuse(int on) { g_gv_fuse = on; }   // A/B knob (tools/ab_step.py)
@@ -371,9 +398,10 @@ extern "C" int wm_conv3x3_gvfused_supported(int CinX, int CoutY, int dtype) {
     return (g_gv_fuse && dtype == WM_BF16 && CinX == 64 && (CoutY == 64 || CoutY == 32)) ? 1 : 0;
 }
 
-extern "C" int wm_conv3x3_wgrad_gvfused(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const float* gvec,
-                                        const void* y, int ldy, int CoutY, const float* stats4, const float* coef, float* ws, float* dw,
-                                        int accumulate, int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+extern "C" int wm_conv3x3_wgrad_gvfused_fin(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const float* gvec,
+                                            const void* y, int ldy, int CoutY, const float* stats4, const float* coef, float* ws, float* dw,
+                                            int accumulate, int B, int H, int W, int Cin, int Cout, int dtype, const WmBnBwdFin* fin,
+                                            void* stream) {
     WM_REQUIRE(x && in_scale && in_shift && gvec && y && stats4 && coef && ws && dw, WM_E_BADARG, "wm_conv3x3_wgrad_gvfused: null pointer");
     WM_REQUIRE(wm_conv3x3_gvfused_supported(CinX, CoutY, dtype), WM_E_SHAPE, "wm_conv3x3_wgrad_gvfused: unsupported shape CinX=%d CoutY=%d dtype=%d", CinX, CoutY, dtype);
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && CinX >= Cin && CoutY >= Cout && ldx >= CinX && ldy >= CoutY &&
@@ -382,18 +410,21 @@ extern "C" int wm_conv3x3_wgrad_gvfused(const void* x, int ldx, int CinX, const 
     wm_launch_wgrad_ws(x, ldx, CinX, in_scale, in_shift, nullptr, 0, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, y, ldy, stats4, CoutY, coef, gvec);
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad_gvfused");
     const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
-    const size_t slab_elems = (size_t)9 * CinP * CoutP;
-    const size_t rb = (slab_elems / 4 + RQUADS - 1) / RQUADS;
-    const int blocks = (int)(rb > 2048 ? 2048 : rb);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout,
-                       (const int*)nullptr, accumulate);
+    WM_REQUIRE(launch_wgrad_reduce(ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout, nullptr, accumulate, fin, s) == WM_OK, WM_E_BADARG,
+               "wm_conv3x3_wgrad_gvfused: bad finalisation rider");
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad_gvfused(reduce)");
     return WM_OK;
 }
+extern "C" int wm_conv3x3_wgrad_gvfused(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const float* gvec,
+                                        const void* y, int ldy, int CoutY, const float* stats4, const float* coef, float* ws, float* dw,
+                                        int accumulate, int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    return wm_conv3x3_wgrad_gvfused_fin(x, ldx, CinX, in_scale, in_shift, gvec, y, ldy, CoutY, stats4, coef, ws, dw, accumulate, B, H, W, Cin, Cout,
+                                        dtype, nullptr, stream);
+}
 
-extern "C" int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift,
-                                const void* dy, int lddy, int CoutY, float* ws, float* dw, int accumulate, int B, int H,
-                                int W, int Cin, int Cout, const int* perm_dev, int dtype, void* stream) {
+extern "C" int wm_conv3x3_wgrad_fin(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift,
+                                    const void* dy, int lddy, int CoutY, float* ws, float* dw, int accumulate, int B, int H,
+                                    int W, int Cin, int Cout, const int* perm_dev, int dtype, const WmBnBwdFin* fin, void* stream) {
     WM_REQUIRE(x && dy && ws && dw, WM_E_BADARG, "wm_conv3x3_wgrad: null pointer");
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && CinX > 0 && CoutY >= Cout, WM_E_BADARG, "wm_conv3x3_wgrad: bad shape");
     WM_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), WM_E_BADARG, "wm_conv3x3_wgrad: in_scale/in_shift must come together");
@@ -411,11 +442,14 @@ extern "C" int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* i
     wm_take_sweep_hint();   // (a no-op when the persistent kernel took it)
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad");
     const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
-    const size_t slab_elems = (size_t)9 * CinP * CoutP;
-    const size_t rb = (slab_elems / 4 + RQUADS - 1) / RQUADS;
-    const int blocks = (int)(rb > 2048 ? 2048 : rb);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout,
-                       perm_dev, accumulate);
+    WM_REQUIRE(launch_wgrad_reduce(ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout, perm_dev, accumulate, fin, s) == WM_OK, WM_E_BADARG,
+               "wm_conv3x3_wgrad: bad finalisation rider");
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad(reduce)");
     return WM_OK;
+}
+extern "C" int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift,
+                                const void* dy, int lddy, int CoutY, float* ws, float* dw, int accumulate, int B, int H,
+                                int W, int Cin, int Cout, const int* perm_dev, int dtype, void* stream) {
+    return wm_conv3x3_wgrad_fin(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, dw, accumulate, B, H, W, Cin, Cout, perm_dev, dtype, nullptr,
+                                stream);
 }

@@ -52,6 +52,47 @@ __device__ __forceinline__ float wm_bn_fold_dy(float y, float scale, float shift
     return __builtin_fmaf(-k2, y, z > 0.f ? k3g : k3);
 }
 
+// ---- BatchNorm-backward finalisation of 8 channels (one 256-thread workgroup: 8 channels x 32 row slices, double accumulate, fixed
+// order).  partials [nparts][2][CP] -> dgamma, dbeta, coef[3][CP].  mean != nullptr: the second row holds sum(gz*y) instead of
+// sum(gz*xhat) and xhat = (y-mean)*invstd is applied here.  Runs as bn_bwd_finalize_kernel (bn.hip) or as extra workgroups of the
+// weight-gradient slab reduction (wgrad.hip).  sh: 2 x 32 x 8 doubles of LDS.
+__device__ __forceinline__ void wm_bn_bwd_finalize_block(const WmBnBwdFin& j, int blk, double* sh, const float* pgv = nullptr,
+                                                         const float* pn = nullptr, const float* ps = nullptr) {
+    double (*s1)[8] = reinterpret_cast<double (*)[8]>(sh);
+    double (*s2)[8] = reinterpret_cast<double (*)[8]>(sh + 32 * 8);
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int c = blk * 8 + cl, CP = j.CP;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < CP) {
+#pragma unroll 8
+        for (int p = sl; p < j.nparts; p += 32) {
+            if (pgv) {   // a globally pooled layer: row p is sample p's (gv*N+, gv*S+), formed here from the pooled statistics
+                const float gv = pgv[(size_t)p * CP + c];
+                a1 += (double)(gv * pn[(size_t)p * CP + c]);
+                a2 += (double)(gv * ps[(size_t)p * CP + c]);
+            } else {
+                a1 += (double)j.partials[((size_t)p * 2 + 0) * CP + c];
+                a2 += (double)j.partials[((size_t)p * 2 + 1) * CP + c];
+            }
+        }
+    }
+    s1[sl][cl] = a1; s2[sl][cl] = a2;
+    __syncthreads();
+    if (sl == 0 && c < CP) {
+        for (int k = 1; k < 32; ++k) { a1 += s1[k][cl]; a2 += s2[k][cl]; }
+        if (j.mean && c < j.C) a2 = (a2 - (double)j.mean[c] * a1) * (double)j.invstd[c];
+        if (c < j.C) {
+            if (j.dbeta) j.dbeta[c] = (j.accumulate ? j.dbeta[c] : 0.f) + (float)a1;
+            if (j.dgamma) j.dgamma[c] = (j.accumulate ? j.dgamma[c] : 0.f) + (float)a2;
+            j.coef[c] = j.gamma[c] * j.invstd[c];
+            j.coef[CP + c] = (float)(a1 / j.count);
+            j.coef[2 * CP + c] = (float)(a2 / j.count);
+        } else {
+            j.coef[c] = 0.f; j.coef[CP + c] = 0.f; j.coef[2 * CP + c] = 0.f;
+        }
+    }
+}
+
 // ---- dtype helpers
 template <typename T> struct wm_dtype;
 template <> struct wm_dtype<float> { static constexpr int id = WM_F32; };

@@ -22,11 +22,12 @@ from . import ops
 
 class Act:
     """NHWC activation: logical value = t (if scale is None) or relu(scale*t+shift)."""
-    __slots__ = ("t", "C", "scale", "shift", "bwd", "rev")
+    __slots__ = ("t", "C", "scale", "shift", "bwd", "rev", "src")
 
-    def __init__(self, t, C, scale=None, shift=None, rev=None):
+    def __init__(self, t, C, scale=None, shift=None, rev=None, src=None):
         self.t, self.C, self.scale, self.shift = t, C, scale, shift
-        self.bwd = None   # backward: (g, partials) left by the consumer's dgrad when it reduced this layer's BatchNorm sums
+        self.bwd = None   # backward: (g, partials, coef or None) left by the consumer's dgrad when it reduced this layer's BatchNorm sums
+        self.src = src    # (bn module, ctx) of the ConvBNRelu that produced t (lets the consumer's backward finish this layer's statistics)
         self.rev = rev    # sweep direction of the conv that just wrote t (False forward, True backward, None: not fresh)
 
 
@@ -112,7 +113,7 @@ def cbr_forward(conv, bn, x, dtype, perm=None, training=True, momentum=0.1):
         stats[3, :Cout] = invstd
     ctx = CBRCtx()
     ctx.x, ctx.y, ctx.stats, ctx.perm, ctx.training = x, y, stats, perm, training
-    ctx.out = Act(y, Cout, stats[0], stats[1], rev=d)
+    ctx.out = Act(y, Cout, stats[0], stats[1], rev=d, src=(bn, ctx))
     return ctx.out, ctx
 
 
@@ -144,6 +145,8 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
         if gvec is not None and pool_stats is not None:   # (N+, S+) from the forward pool: no pass over y
             return ops.bn_bwd_coef_pooled(gvec, pool_stats, y, ctx.stats, Cout, gam, dgam, dbet, accumulate)
         if pre is not None and g is not None and pre[0] is g:
+            if pre[2] is not None:   # finished already, as a rider on the next layer's weight-gradient reduction (dgamma / dbeta written there)
+                return pre[2]
             return ops.bn_bwd_coef_raw(pre[1], y, ctx.stats, Cout, gam, dgam, dbet, accumulate)
         return ops.bn_bwd_coef(g, gvec, y, ctx.stats, Cout, gam, dgam, dbet, accumulate)
 
@@ -157,17 +160,26 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
     # the input is itself a ConvBNRelu output: this layer's dgrad can reduce THAT layer's BatchNorm-backward sums on the way
     feed_stats = (need_input_grad and x.scale is not None and perm_dev is None and ctx.perm is None and rows == 64
                   and x.t.shape[-1] == 64 and x.t.is_contiguous() and ops.conv3x3_dgrad_bwdstats_supported(y.shape[-1], rows, dtype))
+    def rider(part):
+        """the feeding layer's BatchNorm-backward finalisation, to ride on this layer's weight-gradient slab reduction"""
+        if x.src is None or not ops.fin_rider_enabled():
+            return None
+        pbn, pctx = x.src
+        return dict(partials=part, y_shape=tuple(x.t.shape), stats=pctx.stats, C=x.C, gamma=pbn.weight.data, dgamma=grads[pbn.weight],
+                    dbeta=grads[pbn.bias], accumulate=accumulate)
+
     # A globally pooled layer (the gradient wrt its ReLU output is one row per sample): both consumers of dy -- the weight
     # gradient and the input gradient -- form it from (gvec, y) while staging their tiles; no apply pass, no dy tensor.
     if (gvec is not None and need_input_grad and x.scale is not None and perm_dev is None and ctx.perm is None and rows == 64
             and x.t.shape[-1] == 64 and ctx.stats.is_contiguous() and ops.conv3x3_gvfused_supported(64, y.shape[-1], dtype)):
         coef = coef_of()
-        ops.conv3x3_wgrad_gvfused(x.t, x.scale, x.shift, gvec, y, ctx.stats, coef, grads[conv.weight], accumulate)
         wpt = _packed(conv, y.shape[-1], rows, dtype, None, True)
-        if feed_stats:
+        if feed_stats:   # input gradient first: the sums it emits are finished by a rider on the weight gradient's reduction
             gx, part = ops.conv3x3_dgrad_bwdstats(y, wpt, x.t, x.scale, x.shift, gvec, ctx.stats, coef)
-            x.bwd = (gx, part)
+            pcoef = ops.conv3x3_wgrad_gvfused(x.t, x.scale, x.shift, gvec, y, ctx.stats, coef, grads[conv.weight], accumulate, fin=rider(part))
+            x.bwd = (gx, part, pcoef)
             return tag(gx)
+        ops.conv3x3_wgrad_gvfused(x.t, x.scale, x.shift, gvec, y, ctx.stats, coef, grads[conv.weight], accumulate)
         return tag(ops.conv3x3_dgrad_gvfused(y, wpt, gvec, ctx.stats, coef))
     # An ordinary 64 -> 64 layer: the input-gradient kernel reads g and y, forms dy while staging and leaves it in memory
     # for the weight gradient -- the stand-alone apply pass is gone.
@@ -178,10 +190,11 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
         wpt = _packed(conv, 64, rows, dtype, None, True)
         if feed_stats:
             dy, gx, part = ops.conv3x3_dgrad_applyfused(g, y, ctx.stats, coef, wpt, x.t, x.scale, x.shift, reverse=d)
-            x.bwd = (gx, part)
+            pcoef = ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, reverse=not d, fin=rider(part))
+            x.bwd = (gx, part, pcoef)
         else:
             dy, gx, _ = ops.conv3x3_dgrad_applyfused(g, y, ctx.stats, coef, wpt, reverse=d)
-        ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, reverse=not d)
+            ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, reverse=not d)
         return tag(gx)
     dy = ops.bn_bwd(g, gvec, y, ctx.stats, Cout, gam, dgam, dbet, accumulate, dbias, coef=coef_of())
     ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, perm_dev=perm_dev, reverse=True)   # the apply pass swept forwards
@@ -190,7 +203,7 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
     wpt = _packed(conv, y.shape[-1], rows, dtype, ctx.perm, True)
     if feed_stats:
         gx, part = ops.conv3x3_dgrad_bwdstats(dy, wpt, x.t, x.scale, x.shift)
-        x.bwd = (gx, part)
+        x.bwd = (gx, part, None)
         return tag(gx, False)
     gx, _ = ops.conv3x3_fwd(dy, wpt, None, None, None, want_stats=False)
     return tag(gx, False)

@@ -224,6 +224,31 @@ def conv3x3_nparts(B, H, W, Cin, CoutP, dtype):
     return _lib.lib().wm_conv3x3_nparts(c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(CoutP), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32))
 
 
+class _WmBnBwdFin(ctypes.Structure):   # include/wm_hip.h: WmBnBwdFin
+    _fields_ = [("partials", ctypes.c_void_p), ("nparts", ctypes.c_int), ("C", ctypes.c_int), ("CP", ctypes.c_int), ("count", ctypes.c_double),
+                ("gamma", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("dgamma", ctypes.c_void_p),
+                ("dbeta", ctypes.c_void_p), ("accumulate", ctypes.c_int), ("coef", ctypes.c_void_p)]
+
+
+def fin_rider_enabled():
+    return bool(_lib.lib().wm_fin_rider_enabled())
+
+
+def _fin_rider(fin):
+    """fin: None or dict(partials [n,2,CP], y_shape, stats [4,CP], C, gamma, dgamma, dbeta, accumulate) -- the BatchNorm-backward
+    finalisation (bn_bwd_coef_raw) of ANOTHER layer, carried by this launch's slab reduction.  -> (ctypes struct or None, coef or None)"""
+    if fin is None:
+        return None, None
+    part, stats = fin["partials"], fin["stats"]
+    B, H, W, CP = fin["y_shape"]
+    assert part.shape[0] <= 256 and part.shape[2] == CP and part.is_contiguous()
+    coef = torch.empty(3, CP, device=part.device, dtype=torch.float32)
+    st = _WmBnBwdFin(partials=part.data_ptr(), nparts=part.shape[0], C=fin["C"], CP=CP, count=float(B * H * W), gamma=fin["gamma"].data_ptr(),
+                     mean=stats[2].data_ptr(), invstd=stats[3].data_ptr(), dgamma=fin["dgamma"].data_ptr(), dbeta=fin["dbeta"].data_ptr(),
+                     accumulate=1 if fin["accumulate"] else 0, coef=coef.data_ptr())
+    return st, coef
+
+
 def _sweep(reverse):
     """hint for the next conv / wgrad launch: sweep the tiles backwards (start where the producer of the input stopped)"""
     if reverse:
@@ -337,7 +362,7 @@ def conv3x3_gvfused_supported(CinX, CoutY, dtype):
     return bool(_lib.lib().wm_conv3x3_gvfused_supported(c_int(CinX), c_int(CoutY), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32)))
 
 
-def conv3x3_wgrad_gvfused(x, in_scale, in_shift, gvec, y, stats, coef, dw, accumulate):
+def conv3x3_wgrad_gvfused(x, in_scale, in_shift, gvec, y, stats, coef, dw, accumulate, fin=None):
     """weight gradient of a globally pooled ConvBNRelu with the BatchNorm-backward apply pass fused: dy is formed from
     (gvec [B,CP], y, stats [4,CP] contiguous, coef [3,CP]) while the tile is staged."""
     B, H, W, ldx = x.shape
@@ -348,10 +373,12 @@ def conv3x3_wgrad_gvfused(x, in_scale, in_shift, gvec, y, stats, coef, dw, accum
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     Cout, Cin = dw.shape[0], dw.shape[1]
     assert dw.is_contiguous() and stats.is_contiguous() and coef.is_contiguous() and gvec.is_contiguous() and gvec.shape[-1] == CoutY
-    rc = L.wm_conv3x3_wgrad_gvfused(_p(x), c_int(ldx), c_int(ldx), _p(in_scale), _p(in_shift), _p(gvec), _p(y), c_int(CoutY), c_int(CoutY),
-                                    _p(stats), _p(coef), _p(ws), _p(dw), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W),
-                                    c_int(Cin), c_int(Cout), c_int(dtype_id(x)), _stream())
+    fst, fcoef = _fin_rider(fin)
+    rc = L.wm_conv3x3_wgrad_gvfused_fin(_p(x), c_int(ldx), c_int(ldx), _p(in_scale), _p(in_shift), _p(gvec), _p(y), c_int(CoutY), c_int(CoutY),
+                                        _p(stats), _p(coef), _p(ws), _p(dw), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W),
+                                        c_int(Cin), c_int(Cout), c_int(dtype_id(x)), ctypes.byref(fst) if fst is not None else None, _stream())
     _lib.check(rc, "wm_conv3x3_wgrad_gvfused")
+    return fcoef
 
 
 def conv3x3_dgrad_gvfused(y, wpt, gvec, stats, coef):
@@ -473,8 +500,9 @@ def colsum(partials, C, ldp, out, accumulate):
     _lib.check(rc, "wm_colsum_finalize")
 
 
-def conv3x3_wgrad(x, CinX, in_scale, in_shift, dy, dw, accumulate, perm_dev=None, reverse=False):
-    """dw [Cout,Cin,3,3] f32 view (written in place)."""
+def conv3x3_wgrad(x, CinX, in_scale, in_shift, dy, dw, accumulate, perm_dev=None, reverse=False, fin=None):
+    """dw [Cout,Cin,3,3] f32 view (written in place).  fin: see _fin_rider; then the rider's coef [3,CP] is returned."""
+    fst, fcoef = _fin_rider(fin)
     _sweep(reverse)
     B, H, W, ldx = x.shape
     CoutY = dy.shape[-1]
@@ -484,10 +512,11 @@ def conv3x3_wgrad(x, CinX, in_scale, in_shift, dy, dw, accumulate, perm_dev=None
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     Cout, Cin = dw.shape[0], dw.shape[1]
     assert dw.is_contiguous()
-    rc = L.wm_conv3x3_wgrad(_p(x), c_int(ldx), c_int(CinX), _p(in_scale), _p(in_shift), _p(dy), c_int(CoutY), c_int(CoutY),
-                            _p(ws), _p(dw), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W), c_int(Cin),
-                            c_int(Cout), _p(perm_dev), c_int(dtype_id(x)), _stream())
+    rc = L.wm_conv3x3_wgrad_fin(_p(x), c_int(ldx), c_int(CinX), _p(in_scale), _p(in_shift), _p(dy), c_int(CoutY), c_int(CoutY),
+                                _p(ws), _p(dw), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W), c_int(Cin),
+                                c_int(Cout), _p(perm_dev), c_int(dtype_id(x)), ctypes.byref(fst) if fst is not None else None, _stream())
     _lib.check(rc, "wm_conv3x3_wgrad")
+    return fcoef
 
 
 # ----------------------------------------------------------------------------- heads
