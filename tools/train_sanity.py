@@ -1,4 +1,5 @@
-"""a few hundred bf16 steps on random frames + random messages: the losses must stay finite and the bit error must fall"""
+"""a few hundred steps on random frames + random messages: the losses must stay finite and the bit error must fall.
+usage: train_sanity.py [size] [steps] [Identity|Jpeg] [bf16|f32]   (f32 = the exact parity path: the two dtypes should track each other)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +11,8 @@ dev = torch.device("cuda", 0)
 torch.manual_seed(10)
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 noise = NL.Identity() if (len(sys.argv) > 3 and sys.argv[3] == "Identity") else NL.Jpeg(50)
-h = Hidden(HiDDenConfiguration(H=S, W=S), dev, noise, None, compute_dtype=torch.bfloat16)
+dt = torch.float32 if (len(sys.argv) > 4 and sys.argv[4] == "f32") else torch.bfloat16
+h = Hidden(HiDDenConfiguration(H=S, W=S), dev, noise, None, compute_dtype=dt)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 for it in range(N):
     images = torch.rand(16, 3, S, S, device=dev)
