@@ -813,3 +813,43 @@ def test_finalisation_riders_keep_the_training_step():
     assert outs[0][0] == outs[1][0]
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
+
+
+def test_fused_backward_entry_points_fail_loudly():
+    """the fused backward entry points reject what they do not support with a negative code and a message (no silent fallback):
+    wrong dtype, wrong channel counts, missing partner arguments, an oversized rider"""
+    import ctypes
+    from video_watermarking_forgery_detection_amd import _lib, ops
+    L = _lib.lib()
+    P = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+    B, H, W, C = 1, 16, 16, 64
+    g = torch.zeros(B, H, W, C, device="cuda", dtype=torch.bfloat16)
+    f = torch.zeros(4, C, device="cuda"); coef = torch.zeros(3, C, device="cuda")
+    wpt = torch.zeros(9, C, C, device="cuda", dtype=torch.bfloat16)
+    part = torch.zeros(1, 2, C, device="cuda")
+    def err():
+        return L.wm_last_error_string().decode()
+    # f32 has no fused kernel
+    assert not ops.conv3x3_dgrad_applyfused_supported(64, 64, torch.float32) and not ops.conv3x3_gvfused_supported(64, 64, torch.float32)
+    rc = L.wm_conv3x3_dgrad_applyfused(P(g), P(g), P(f), P(coef), P(wpt), P(g), P(g), P(None), P(None), P(None), P(None), 1, 16, 16, 64, 0, None)
+    assert rc < 0 and "unsupported" in err()
+    # the feeding layer's sums need all four of ry, r_scale, r_shift, partials
+    rc = L.wm_conv3x3_dgrad_applyfused(P(g), P(g), P(f), P(coef), P(wpt), P(g), P(g), P(g), P(None), P(None), P(part), 1, 16, 16, 64, 1, None)
+    assert rc < 0 and "come together" in err()
+    # ... and a 64-channel input gradient
+    rc = L.wm_conv3x3_dgrad_applyfused(P(g), P(g), P(f), P(coef), P(wpt), P(g), P(g), P(g), P(f), P(f), P(part), 1, 16, 16, 32, 1, None)
+    assert rc < 0 and "CinP" in err()
+    rc = L.wm_conv3x3_dgrad_bwdstats(P(g), 64, 48, P(wpt), P(None), P(None), P(None), P(g), P(f), P(f), P(g), P(part), 1, 16, 16, 64, 1, None)
+    assert rc < 0 and "unsupported" in err()
+    # a rider with more than 256 partial rows is refused by the weight-gradient entry (python wrapper: assertion; C ABI: code)
+    big = torch.zeros(300, 2, C, device="cuda")
+    fin = dict(partials=big, y_shape=(B, H, W, C), stats=f, C=C, gamma=f[0], dgamma=f[1].clone(), dbeta=f[2].clone(), accumulate=False)
+    with pytest.raises(AssertionError):
+        ops.conv3x3_wgrad(g, C, f[0], f[1], g, torch.zeros(C, C, 3, 3, device="cuda"), False, fin=fin)
+    st = ops._WmBnBwdFin(partials=big.data_ptr(), nparts=300, C=C, CP=C, count=256.0, gamma=f[0].data_ptr(), mean=f[2].data_ptr(),
+                         invstd=f[3].data_ptr(), dgamma=0, dbeta=0, accumulate=0, coef=coef.data_ptr())
+    ws = torch.zeros(ops._lib.lib().wm_conv3x3_wgrad_nslabs(1, 16, 16) * 9 * 64 * 64, device="cuda")
+    dw = torch.zeros(C, C, 3, 3, device="cuda")
+    rc = L.wm_conv3x3_wgrad_fin(P(g), 64, 64, P(f[0]), P(f[1]), P(g), 64, 64, P(ws), P(dw), 0, 1, 16, 16, 64, 64, P(None), 1, ctypes.byref(st), None)
+    assert rc < 0 and "rider" in err()
+    torch.cuda.synchronize()

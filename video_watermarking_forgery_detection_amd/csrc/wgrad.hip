@@ -318,6 +318,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 inline int nslabs_for(int B, int H, int W);
+static bool fin_rider_ok(const WmBnBwdFin* fin) {
+    return !fin || (fin->partials && fin->gamma && fin->invstd && fin->coef && fin->nparts > 0 && fin->nparts <= 256 && fin->C > 0 && fin->CP >= fin->C);
+}
 // the slab reduction (+ an optional rider)
 static int launch_wgrad_reduce(float* ws, int nslabs, int CinP, int CoutP, float* dw, int Cin, int Cout, const int* perm, int accumulate,
                                const WmBnBwdFin* fin, hipStream_t s) {
@@ -327,8 +330,7 @@ static int launch_wgrad_reduce(float* ws, int nslabs, int CinP, int CoutP, float
     WmBnBwdFin f = {};
     int extra = 0;
     if (fin) {
-        if (!fin->partials || !fin->gamma || !fin->invstd || !fin->coef || fin->nparts <= 0 || fin->nparts > 256 || fin->C <= 0 || fin->CP < fin->C)
-            return WM_E_BADARG;
+        if (!fin_rider_ok(fin)) return WM_E_BADARG;
         f = *fin;
         extra = wm_cdiv(fin->CP, 8);
     }
@@ -403,6 +405,7 @@ extern "C" int wm_conv3x3_wgrad_gvfused_fin(const void* x, int ldx, int CinX, co
                                             int accumulate, int B, int H, int W, int Cin, int Cout, int dtype, const WmBnBwdFin* fin,
                                             void* stream) {
     WM_REQUIRE(x && in_scale && in_shift && gvec && y && stats4 && coef && ws && dw, WM_E_BADARG, "wm_conv3x3_wgrad_gvfused: null pointer");
+    WM_REQUIRE(fin_rider_ok(fin), WM_E_BADARG, "wm_conv3x3_wgrad_gvfused: bad finalisation rider (null pointer, or more than 256 partial rows)");
     WM_REQUIRE(wm_conv3x3_gvfused_supported(CinX, CoutY, dtype), WM_E_SHAPE, "wm_conv3x3_wgrad_gvfused: unsupported shape CinX=%d CoutY=%d dtype=%d", CinX, CoutY, dtype);
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && CinX >= Cin && CoutY >= Cout && ldx >= CinX && ldy >= CoutY &&
                ldx % 8 == 0 && ldy % 8 == 0, WM_E_SHAPE, "wm_conv3x3_wgrad_gvfused: bad shape / strides");
@@ -426,6 +429,7 @@ extern "C" int wm_conv3x3_wgrad_fin(const void* x, int ldx, int CinX, const floa
                                     const void* dy, int lddy, int CoutY, float* ws, float* dw, int accumulate, int B, int H,
                                     int W, int Cin, int Cout, const int* perm_dev, int dtype, const WmBnBwdFin* fin, void* stream) {
     WM_REQUIRE(x && dy && ws && dw, WM_E_BADARG, "wm_conv3x3_wgrad: null pointer");
+    WM_REQUIRE(fin_rider_ok(fin), WM_E_BADARG, "wm_conv3x3_wgrad: bad finalisation rider (null pointer, or more than 256 partial rows)");
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && CinX > 0 && CoutY >= Cout, WM_E_BADARG, "wm_conv3x3_wgrad: bad shape");
     WM_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), WM_E_BADARG, "wm_conv3x3_wgrad: in_scale/in_shift must come together");
     WM_REQUIRE(dtype == WM_F32 || dtype == WM_BF16, WM_E_BADARG, "wm_conv3x3_wgrad: unsupported dtype %d", dtype);
