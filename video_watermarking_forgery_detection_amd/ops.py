@@ -54,7 +54,8 @@ def jpeg_fwd(x, mode, tables, subsample=0):
     y = torch.empty_like(x)
     B, _, H, W = x.shape
     tb = _host_floats(tables) if tables is not None else None
-    rc = _lib.lib().wm_jpeg_fwd(_p(x), _p(y), c_int(B), c_int(H), c_int(W), c_int(mode), tb, c_int(subsample), _stream())
+    rc = _timed("jpeg_fwd", None, lambda: _lib.lib().wm_jpeg_fwd(_p(x), _p(y), c_int(B), c_int(H), c_int(W), c_int(mode), tb, c_int(subsample),
+                                                                 _stream()))
     _lib.check(rc, "wm_jpeg_fwd")
     return y
 
@@ -66,7 +67,8 @@ def jpeg_bwd(x, gy, mode, tables, subsample=0):
     B, _, H, W = gy.shape
     tb = _host_floats(tables) if tables is not None else None
     xx = x.contiguous() if x is not None else None
-    rc = _lib.lib().wm_jpeg_bwd(_p(xx), _p(gy), _p(gx), c_int(B), c_int(H), c_int(W), c_int(mode), tb, c_int(subsample), _stream())
+    rc = _timed("jpeg_bwd", None, lambda: _lib.lib().wm_jpeg_bwd(_p(xx), _p(gy), _p(gx), c_int(B), c_int(H), c_int(W), c_int(mode), tb,
+                                                                 c_int(subsample), _stream()))
     _lib.check(rc, "wm_jpeg_bwd")
     return gx
 
