@@ -12,8 +12,10 @@
  *   - plain C: raw device pointers + explicit sizes, no torch / C++ types;
  *   - the caller owns every buffer (inputs, outputs, workspaces); the library never
  *     allocates, frees or keeps a pointer after the call returns;
- *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant,
- *     and holds no mutable global state; safe under hipGraph capture;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant, and the library
+ *     holds no mutable state between calls (no knobs, no environment variables, no set-then-call hints; the
+ *     only per-thread datum is the text of the last error); safe under hipGraph capture.  The A/B switches
+ *     (wm_debug_*, WM_NO_* variables) of tools/ exist only in the -DWM_DEBUG build lib/libwm_hip_dbg.so;
  *   - return value: 0 = ok, <0 = error (WM_E_*); wm_last_error_string() gives the text of
  *     the last error on the calling thread.  No C++ exception crosses the boundary;
  *   - activations are NHWC ("pixel-major"): element (b,h,w,c) lives at
@@ -157,8 +159,12 @@ int wm_pack_w3x3_batch(const void* jobs_dev, int njobs, size_t max_elems, int dt
 int wm_conv3x3_nparts(int B, int H, int W, int Cin, int CoutP, int dtype);
 int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const float* bias, int nbias,
                    const float* in_scale, const float* in_shift, void* y, int ldy, float* stat_partials, int B, int H,
-                   int W, int Cin, int CoutP, int dtype, void* stream);
-/* weight gradient: dW[co,ci,kh,kw] = sum_{b,h,w} a[b,h+kh-1,w+kw-1,ci] * dy[b,h,w,co], with
+                   int W, int Cin, int CoutP, int dtype, int sweep_reverse, void* stream);
+/* sweep_reverse (wm_conv3x3_fwd, wm_conv3x3_dgrad_applyfused / _bwdstats, wm_conv3x3_wgrad_fin): != 0 sweeps the pixel tiles
+ * backwards.  A kernel that starts where the producer of its input stopped finds the freshest part of that tensor in the
+ * Infinity Cache (256 MB against 134 MB per tensor at B=16, 256x256); the host alternates the direction along a chain of
+ * layers.  Results do not depend on it except for the summation order inside the per-workgroup statistics rows.
+ * weight gradient: dW[co,ci,kh,kw] = sum_{b,h,w} a[b,h+kh-1,w+kw-1,ci] * dy[b,h,w,co], with
  * a = x or relu(in_scale*x+in_shift).  Writes f32 partial slabs ws[nslabs][9][CinP][CoutP]
  * (nslabs = wm_conv3x3_wgrad_nslabs) and reduces them into dw[Cout,Cin,3,3] (PyTorch layout,
  * overwritten or accumulated).  perm as in wm_pack_w3x3 (device int[Cin] or NULL). */
@@ -175,7 +181,7 @@ int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* in_scale, co
 int wm_fin_rider_enabled(void);
 int wm_conv3x3_wgrad_fin(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy, int lddy,
                          int CoutY, float* ws, float* dw, int accumulate, int B, int H, int W, int Cin, int Cout,
-                         const int* perm_dev, int dtype, const WmBnBwdFin* fin, void* stream);
+                         const int* perm_dev, int dtype, const WmBnBwdFin* fin, int sweep_reverse, void* stream);
 /* The same with the BatchNorm-backward APPLY pass fused, for bf16 image-fed first layers (CinX <= 16) whose input needs
  * no gradient: dy is formed from g (gradient wrt the ReLU output, stride ldg), y (the raw conv output, stride ldy),
  * stats4 = f32[4][CoutY] = scale | shift | mean | invstd and coef = wm_bn_bwd_finalize's f32[3][CoutY] while the tile is
@@ -189,10 +195,6 @@ int wm_conv3x3_wgrad_bnfused(const void* x, int ldx, int CinX, const void* g, in
  * read the layer's raw conv output y instead of dy and apply the BatchNorm backward while staging (bf16, CinX = 64,
  * CoutY in {64, 32}); results are bit-identical to wm_bn_bwd_apply followed by wm_conv3x3_wgrad / wm_conv3x3_fwd.
  * wpt: the transposed packed filter (wm_pack_w3x3 with transpose = 1), dx: [B,H,W,CinP] dense. */
-/* Optional hint for the NEXT wm_conv3x3_fwd / wm_conv3x3_dgrad_* call from this thread: sweep the pixel tiles backwards.
- * A kernel that starts where the producer of its input stopped finds the freshest part of that tensor in the Infinity
- * Cache; the host alternates the direction along a chain of layers.  Consumed by that one call. */
-void wm_conv3x3_sweep_hint(int reverse);
 int wm_conv3x3_gvfused_supported(int CinX, int CoutY, int dtype);
 int wm_conv3x3_wgrad_gvfused(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const float* gvec,
                              const void* y, int ldy, int CoutY, const float* stats4, const float* coef, float* ws, float* dw,
@@ -217,11 +219,11 @@ int wm_conv3x3_dgrad_gvfused(const void* y, int ldy, int CoutY, const void* wpt,
 int wm_conv3x3_dgrad_applyfused_supported(int CoutY, int CinP, int dtype);
 int wm_conv3x3_dgrad_applyfused(const void* g, const void* y, const float* stats4, const float* coef, const void* wpt,
                                 void* dy_out, void* dx, const void* ry, const float* r_scale, const float* r_shift,
-                                float* partials, int B, int H, int W, int CinP, int dtype, void* stream);
+                                float* partials, int B, int H, int W, int CinP, int dtype, int sweep_reverse, void* stream);
 int wm_conv3x3_dgrad_bwdstats_supported(int CoutY, int CinP, int dtype);
 int wm_conv3x3_dgrad_bwdstats(const void* src, int lds, int CoutY, const void* wpt, const float* gvec, const float* stats4,
                               const float* coef, const void* ry, const float* r_scale, const float* r_shift, void* dx,
-                              float* partials, int B, int H, int W, int CinP, int dtype, void* stream);
+                              float* partials, int B, int H, int W, int CinP, int dtype, int sweep_reverse, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm2d (training)
  * replaces nn.BatchNorm2d + nn.ReLU of conv_bn_relu.py:12-14 / UNet.py:67-97.
@@ -368,6 +370,38 @@ int wm_message_loss(const float* decoded, const float* messages, int n, float gs
 int wm_hidden_metrics(const float* enc_partials, int nparts, double n_img, const float* msg2, const float* adv,
                       const float* d_cover, const float* d_enc, float w_adv, float w_enc, float w_dec, float* out7, void* stream);
 int wm_sumsq(const float* x, size_t n, float* partials, int nparts, void* stream);
+
+/* ------------------------------------------------------------------ tamper-localisation branch (elementwise, f32 NCHW planes)
+ * replaces: models/IRNcrop_model.py:320-322 (clamp_with_grad), :344-345 / :372-373 (Quantization after the clamp),
+ * :348 (splice), :379-388 (PSNR of the int-truncated images, metrics.py:30-46, and the 1.0 / 0.8 forward weight at 33 dB),
+ * :378,391-393 (BCEWithLogitsLoss on the predicted mask), :410-412 (clip_grad_norm_).
+ * wm_clamp_quant_fwd: y = round(255*clamp(x,0,1))/255 (backward of both = identity: nothing to launch).
+ * wm_splice_fwd: q = clamp_quant(enc); fwd_q (may be NULL) = q; tampered (may be NULL) = q*(1-mask) + prev*mask with mask
+ *   [B,1,HW] broadcast over the C planes; psnr_partials [wm_splice_nparts(B*C*HW)] doubles (with real; both may be NULL) =
+ *   partial sums of (int(255*real) - int(255*q))^2.
+ * wm_psnr_gate: out2[0] = PSNR (0 when the images are equal, like metrics.py:41-42), out2[1] = PSNR < threshold ? w_below : w_above.
+ * wm_mse_fwd_bwd_gated: wm_mse_fwd_bwd with the gradient scale multiplied by the device scalar gate_dev[0].
+ * wm_bce_logits_target: *loss_out = mean BCE-with-logits(p, target), grad_out (may be NULL) = gscale * d loss / d p;
+ *   partials = scratch [nparts <= 2048]; chain_sigmoid != 0: p is a sigmoid output s(z) (the UNet head, network/UNet.py:65) and
+ *   grad_out is taken wrt z (multiplied by p*(1-p)).
+ * wm_masked_axpy: a += g * (1 - mask) (the splice's backward onto the gradient of the encoded image).
+ * wm_mask_threshold: out[i] = p[i] > threshold (uint8 tamper mask).
+ * wm_clip_coef: partials[k][nparts[k]] = wm_sumsq rows of up to 4 flat gradient buffers clipped TOGETHER;
+ *   out2[0] = min(1, max_norm / (total_norm + 1e-6)), out2[1] = total_norm.   wm_scale_dev: x *= scale_dev[0]. */
+int wm_clamp_quant_fwd(const float* x, float* y, size_t n, void* stream);
+int wm_splice_nparts(size_t n);
+int wm_splice_fwd(const float* enc, const float* real, const float* prev, const float* mask, float* fwd_q, float* tampered,
+                  double* psnr_partials, int B, int C, size_t HW, void* stream);
+int wm_psnr_gate(const double* psnr_partials, int nparts, double n, float threshold, float w_below, float w_above, float* out2,
+                 void* stream);
+int wm_mse_fwd_bwd_gated(const float* a, const float* b, float* grad_a, float gscale, const float* gate_dev, float* loss_partials,
+                         int nparts, size_t n, void* stream);
+int wm_bce_logits_target(const float* p, const float* target, size_t n, float gscale, float* partials, int nparts, float* loss_out,
+                         float* grad_out, int chain_sigmoid, void* stream);
+int wm_masked_axpy(float* a, const float* g, const float* mask, int B, int C, size_t HW, void* stream);
+int wm_mask_threshold(const float* p, float threshold, uint8_t* out, size_t n, void* stream);
+int wm_clip_coef(const float* const* partials, const int* nparts, int ngroups, float max_norm, float* out2, void* stream);
+int wm_scale_dev(float* x, size_t n, const float* scale_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,3 +27,12 @@ def golden():
             return self._c[name]
 
     return G()
+
+
+@pytest.fixture
+def debug_lib():
+    """the -DWM_DEBUG build of the kernel library for the duration of one test: every op of the test runs on it and its
+    wm_debug_* switches may be flipped (the release library, which everything else loads, has none)"""
+    from video_watermarking_forgery_detection_amd import _lib
+    with _lib.use_debug_library() as L:
+        yield L

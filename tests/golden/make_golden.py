@@ -406,6 +406,187 @@ def gen_unet(out):
                 m.reset_running_stats()
 
 
+# --------------------------------------------------------------------------- config C3: the HiDDeN-order step under the stencil / resample attacks
+def _ref_attacks():
+    """name -> callable image -> image built from the REFERENCE's noise layers (the C3 attack cycle of SURVEY §8d).  GaussianBlur's
+    forward hard-codes .cuda() (gaussian_blur.py:55): its own kernel builder is applied on CPU.  MiddleBlur is kornia (absent): the
+    fixture uses the build's definition (oracle/attacks_ref.median_blur, parity unpinned for that one op)."""
+    from noise_layers.gaussian_blur import GaussianBlur
+    from noise_layers.resize import Resize
+    from noise_layers.crop import Crop
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import attacks_ref
+    gconv = GaussianBlur().get_gaussian_kernel(channels=3)
+    rs, cr = Resize(), Crop()
+
+    def crop_fn(x):
+        H, W = x.shape[2], x.shape[3]
+        return cr(x, apex=(H // 8, H // 8 + int(0.75 * H), W // 8, W // 8 + int(0.75 * W)))[0]
+
+    return {"GaussianBlur": lambda x: gconv(x), "Resize0.7": lambda x: rs(x, resize_ratio=0.7), "Crop0.75": crop_fn,
+            "MiddleBlur3": lambda x: attacks_ref.median_blur(x, 3)}
+
+
+def _hidden_step(out, prefix, noise, Cfg, size=32, B=4, iters=2, stride=31):
+    """one HiDDeN-order GAN step (hidden.py:54-118) on the reference's Encoder / Decoder / Discriminator, like gen_step"""
+    from hidden_models.encoder import Encoder
+    from hidden_models.decoder import Decoder
+    from hidden_models.discriminator import Discriminator
+    cfg = Cfg(H=size, W=size)
+    enc = detgen.fill_module(Encoder(cfg)).train()
+    dec = detgen.fill_module(Decoder(cfg)).train()
+    dis = detgen.fill_module(Discriminator(cfg)).train()
+    opt_ed = torch.optim.Adam(list(enc.parameters()) + list(dec.parameters()))
+    opt_d = torch.optim.Adam(dis.parameters())
+    bce, mse = nn.BCEWithLogitsLoss(), nn.MSELoss()
+    images = detgen.uniform((B, 3, size, size), 2000)
+    messages = detgen.bits((B, 30), 2001)
+    t1, t0 = torch.full((B, 1), 1.0), torch.full((B, 1), 0.0)
+    for it in range(iters):
+        opt_d.zero_grad()
+        l_dc = bce(dis(images), t1)
+        l_dc.backward()
+        encoded = enc(images, messages.clone())
+        noised = noise(encoded)
+        decoded = dec(noised)
+        l_de = bce(dis(encoded.detach()), t0)
+        l_de.backward()
+        if it == 0:
+            for n, p in dis.named_parameters():
+                out[f"{prefix}/gD/{n}"] = npy(detgen.subsample(p.grad, stride))
+        opt_d.step()
+        opt_ed.zero_grad()
+        l_adv = bce(dis(encoded), t1)
+        l_enc = mse(encoded, images)
+        l_dec = mse(decoded, messages)
+        g_loss = cfg.adversarial_loss * l_adv + cfg.encoder_loss * l_enc + cfg.decoder_loss * l_dec
+        g_loss.backward()
+        if it == 0:
+            for n, p in enc.named_parameters():
+                out[f"{prefix}/gE/{n}"] = npy(detgen.subsample(p.grad, stride))
+            for n, p in dec.named_parameters():
+                out[f"{prefix}/gDec/{n}"] = npy(detgen.subsample(p.grad, stride))
+            out[f"{prefix}/encoded"] = npy(encoded)
+            out[f"{prefix}/noised"] = npy(noised)
+            out[f"{prefix}/decoded"] = npy(decoded)
+        opt_ed.step()
+        dr = decoded.detach().numpy().round().clip(0, 1)
+        biterr = np.sum(np.abs(dr - messages.numpy())) / (B * 30)
+        out[f"{prefix}/losses_it{it}"] = np.array(
+            [g_loss.item(), l_enc.item(), l_dec.item(), biterr, l_adv.item(), l_dc.item(), l_de.item()], dtype=np.float64)
+    for tag, m in (("wE", enc), ("wDec", dec), ("wD", dis)):
+        for n, p in list(m.state_dict().items()):
+            out[f"{prefix}/{tag}/{n}"] = npy(detgen.subsample(p.float(), stride))
+
+
+def gen_step_c3(out, Cfg):
+    for name, fn in _ref_attacks().items():
+        _hidden_step(out, f"step_{name}", fn, Cfg)
+
+
+# --------------------------------------------------------------------------- tamper-localisation branch (a18), composed from the reference's modules
+def gen_localise(out, Cfg):
+    """The composition models/IRNcrop_model.py:337-416 describes (it cannot run as written, SURVEY box) around the HiDDeN-order
+    step, built from the REFERENCE's modules: hidden_models.{Encoder,Decoder,Discriminator}, network.UNet, noise layers,
+    models.modules.Quantization, metrics.PSNR; clamp_with_grad / postprocess are the three-line helpers of IRNcrop_model.py:320-322,
+    660-664 restated.  Same order as oracle/localise_ref.py."""
+    from hidden_models.encoder import Encoder
+    from hidden_models.decoder import Decoder
+    from hidden_models.discriminator import Discriminator
+    from network.UNet import UNet
+    from models.modules.Quantization import Quantization
+    from noise_layers.jpeg import JpegSS
+    from metrics import PSNR
+
+    def clamp_with_grad(t):
+        return t + (torch.clamp(t, 0, 1) - t).clone().detach()
+
+    def postprocess(img):
+        return (img * 255.0).permute(0, 2, 3, 1).int()
+
+    attacks = dict(_ref_attacks())
+    jss = JpegSS(70)
+    attacks["JpegSS70"] = lambda x: jss(x)
+    quant = Quantization()
+    psnr = PSNR(255.0)
+    size, B = 32, 4
+    for case, (aname, clip, enc_gain) in {"jpegss_clip": ("JpegSS70", 1.0, 1.0), "resize": ("Resize0.7", None, 1.0),
+                                          "gauss_hipsnr": ("GaussianBlur", 0.5, 0.02)}.items():
+        attack = attacks[aname]
+        cfg = Cfg(H=size, W=size)
+        enc = detgen.fill_module(Encoder(cfg)).train()
+        dec = detgen.fill_module(Decoder(cfg)).train()
+        dis = detgen.fill_module(Discriminator(cfg)).train()
+        unet = detgen.fill_module(UNet(3, 1, 32)).train()
+        images = detgen.uniform((B, 3, size, size), 2100)
+        if enc_gain != 1.0:
+            # a near-identity embedder (final 1x1 conv ~ 0, its bias = a constant): PSNR above 33 dB needs encoded ~ images, which a
+            # random-init encoder never gives; instead the "cover" is made the constant image the encoder emits, so the gate's
+            # 0.8 branch (IRNcrop_model.py:387-388) is exercised
+            with torch.no_grad():
+                enc.final_layer.weight.mul_(enc_gain)
+                enc.final_layer.bias.copy_(torch.tensor([0.4, 0.5, 0.6]))
+            images = torch.tensor([0.4, 0.5, 0.6]).view(1, 3, 1, 1).expand(B, 3, size, size).contiguous() + 0.01 * (images - 0.5)
+        messages = detgen.bits((B, 30), 2101)
+        previous = detgen.uniform((B, 3, size, size), 2102)
+        mask = torch.zeros(B, 1, size, size)
+        mask[:, :, 8:24, 4:20] = 1.0
+        mask[1, :, :, :] = 0.0
+        opt_ed = torch.optim.Adam(list(enc.parameters()) + list(dec.parameters()))
+        opt_d = torch.optim.Adam(dis.parameters())
+        opt_u = torch.optim.Adam(unet.parameters())
+        bce, mse = nn.BCEWithLogitsLoss(), nn.MSELoss()
+        t1, t0 = torch.full((B, 1), 1.0), torch.full((B, 1), 0.0)
+        key = f"loc_{case}"
+        out[key + "/attack"] = np.array(aname)
+        out[key + "/clip"] = np.float64(clip or 0.0)
+        out[key + "/enc_gain"] = np.float64(enc_gain)
+        for it in range(2):
+            opt_d.zero_grad()
+            l_dc = bce(dis(images), t1)
+            l_dc.backward()
+            encoded = enc(images, messages.clone())
+            noised = attack(encoded)
+            decoded = dec(noised)
+            l_de = bce(dis(encoded.detach()), t0)
+            l_de.backward()
+            if clip:
+                nn.utils.clip_grad_norm_(dis.parameters(), clip)
+            opt_d.step()
+            opt_ed.zero_grad()
+            opt_u.zero_grad()
+            l_adv = bce(dis(encoded), t1)
+            l_enc = mse(encoded, images)
+            l_dec = mse(decoded, messages)
+            fwd_img = quant(clamp_with_grad(encoded))
+            pf = float(psnr(postprocess(images), postprocess(fwd_img)))
+            gate = 1.0 if pf < 33 else 0.8
+            tampered = fwd_img * (1 - mask) + previous * mask
+            attacked = quant(clamp_with_grad(attack(tampered)))
+            pred = unet(attacked)
+            l_loc = bce(pred, mask)
+            loss = cfg.adversarial_loss * l_adv + gate * cfg.encoder_loss * l_enc + cfg.decoder_loss * l_dec + 1.0 * l_loc
+            loss.backward()
+            if clip:
+                nn.utils.clip_grad_norm_(list(enc.parameters()) + list(dec.parameters()), clip)
+                nn.utils.clip_grad_norm_(unet.parameters(), clip)
+            if it == 0:
+                for tag, m, st in (("gE", enc, 31), ("gDec", dec, 31), ("gU", unet, 997)):
+                    for n, p in m.named_parameters():
+                        out[f"{key}/{tag}/{n}"] = npy(detgen.subsample(p.grad, st))
+                        out[f"{key}/{tag}norm/{n}"] = np.float64(p.grad.norm().item())
+                for nm, t in (("encoded", encoded), ("tampered", tampered), ("attacked", attacked), ("pred", pred), ("decoded", decoded)):
+                    out[f"{key}/{nm}"] = npy(t)
+            opt_ed.step()
+            opt_u.step()
+            g3 = cfg.adversarial_loss * l_adv + cfg.encoder_loss * l_enc + cfg.decoder_loss * l_dec
+            out[f"{key}/logs_it{it}"] = np.array([g3.item(), l_enc.item(), l_dec.item(), l_adv.item(), l_dc.item(), l_de.item(),
+                                                  pf, gate, l_loc.item()], dtype=np.float64)
+        for tag, m, st in (("wE", enc, 31), ("wDec", dec, 31), ("wD", dis, 31), ("wU", unet, 997)):
+            for n, p in list(m.state_dict().items()):
+                out[f"{key}/{tag}/{n}"] = npy(detgen.subsample(p.float(), st))
+
+
 def main():
     Cfg = install_shims()
     jobs = {
@@ -415,6 +596,8 @@ def main():
         "hidden": lambda o: gen_hidden(o, Cfg),
         "step": lambda o: gen_step(o, Cfg),
         "unet": lambda o: gen_unet(o),
+        "step_c3": lambda o: gen_step_c3(o, Cfg),
+        "localise": lambda o: gen_localise(o, Cfg),
     }
     which = sys.argv[1:] or list(jobs)
     for name in which:

@@ -314,7 +314,7 @@ def test_shape_errors():
 
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("case", [(2, 40, 52, 64, 64), (1, 20, 37, 32, 64), (2, 33, 18, 16, 64)])
-def test_ws_conv_mfma_shapes_agree(case, variant):
+def test_ws_conv_mfma_shapes_agree(case, variant, debug_lib):
     """the wave-specialised bf16 kernel: 16x16x32 consumers (default) and 32x32x16 consumers (debug knob) against
     conv2d on the same bf16-rounded operands, with the fused BN+ReLU input transform and the statistics."""
     import ctypes
@@ -327,7 +327,7 @@ def test_ws_conv_mfma_shapes_agree(case, variant):
     a = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).bfloat16().float()
     ref = F.conv2d(a, w, bias, padding=1)
     wp = ops.pack_w3x3(w.cuda(), Cout, Cin, torch.bfloat16)
-    L = _lib.lib()
+    L = debug_lib   # the -DWM_DEBUG build: the release library has no A/B switches
     L.wm_debug_ws_variant(ctypes.c_int(variant))
     try:
         y, st = ops.conv3x3_fwd(nhwc(x, torch.bfloat16), wp, bias.cuda(), sc.cuda(), sh.cuda(), True)
@@ -473,14 +473,14 @@ def test_pooled_layer_backward_with_fused_bn_apply(case):
     torch.testing.assert_close(dw1, 2 * dw0, rtol=1e-6, atol=1e-6 * dw0.abs().max().item())
 
 
-def test_pooled_layer_fusion_keeps_the_training_step():
+def test_pooled_layer_fusion_keeps_the_training_step(debug_lib):
     """the HiDDeN step with the fused pooled-layer backward gives the same losses and parameters as with the separate apply pass"""
     import ctypes
     from video_watermarking_forgery_detection_amd import _lib
     from video_watermarking_forgery_detection_amd.hidden_models import Hidden
     from video_watermarking_forgery_detection_amd import noise_layers as NL
     from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
-    L = _lib.lib()
+    L = debug_lib   # the -DWM_DEBUG build: the release library has no A/B switches
     outs = []
     try:
         for on in (1, 0):
@@ -546,7 +546,7 @@ def test_dgrad_that_reduces_the_feeding_layers_bn_backward_sums(case):
     torch.testing.assert_close(dg1, 2 * dg0, rtol=1e-4, atol=2e-5 * sc)
 
 
-def test_fused_bn_backward_reduce_keeps_the_training_step():
+def test_fused_bn_backward_reduce_keeps_the_training_step(debug_lib):
     """the HiDDeN step with the BatchNorm-backward reduce passes folded into the dgrad epilogues: same losses, and parameters
     within f32 summation-order noise of the step with separate reduce passes"""
     import ctypes
@@ -554,7 +554,7 @@ def test_fused_bn_backward_reduce_keeps_the_training_step():
     from video_watermarking_forgery_detection_amd.hidden_models import Hidden
     from video_watermarking_forgery_detection_amd import noise_layers as NL
     from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
-    L = _lib.lib()
+    L = debug_lib   # the -DWM_DEBUG build: the release library has no A/B switches
     outs = []
     try:
         for on in (1, 0):
@@ -618,14 +618,14 @@ def test_dgrad_with_fused_bn_backward_apply_tensor_gradient(case):
     assert dx2.float().abs().max().item() > 0 and torch.equal(dy0, dy3) and torch.equal(dx2, dx3)
 
 
-def test_fused_apply_keeps_the_training_step():
+def test_fused_apply_keeps_the_training_step(debug_lib):
     """the HiDDeN step with the apply pass inside the dgrad kernels is bit-identical to the step with the stand-alone pass"""
     import ctypes
     from video_watermarking_forgery_detection_amd import _lib
     from video_watermarking_forgery_detection_amd.hidden_models import Hidden
     from video_watermarking_forgery_detection_amd import noise_layers as NL
     from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
-    L = _lib.lib()
+    L = debug_lib   # the -DWM_DEBUG build: the release library has no A/B switches
     outs = []
     try:
         for on in (1, 0):
@@ -678,7 +678,7 @@ def test_pooled_layer_bn_backward_sums_from_forward_pool_statistics(case):
 
 @pytest.mark.parametrize("case", [(2, 40, 36), (1, 64, 64), (3, 17, 50)])
 def test_backward_sweep_hint_changes_only_the_summation_order(case):
-    """wm_conv3x3_sweep_hint: the next persistent conv / wgrad launch walks its tiles backwards (Infinity-Cache reuse along a
+    """sweep_reverse: a persistent conv / wgrad launch walks its tiles backwards (Infinity-Cache reuse along a
     chain of layers).  Outputs are bit-identical (the halo-edge reuse mirrors: right columns from the tile before);
     per-workgroup statistics rows and weight-gradient slabs only change their summation order."""
     from video_watermarking_forgery_detection_amd import ops
@@ -690,7 +690,7 @@ def test_backward_sweep_hint_changes_only_the_summation_order(case):
     wp = ops.pack_w3x3(w, C, C, torch.bfloat16)
     y0, st0 = ops.conv3x3_fwd(x, wp, None, xs, xt, want_stats=True)
     y1, st1 = ops.conv3x3_fwd(x, wp, None, xs, xt, want_stats=True, reverse=True)
-    y2, _ = ops.conv3x3_fwd(x, wp, None, xs, xt, want_stats=True)          # the hint is consumed by one launch
+    y2, _ = ops.conv3x3_fwd(x, wp, None, xs, xt, want_stats=True)          # a per-call argument: nothing lingers
     assert y0.float().abs().max().item() > 0 and torch.equal(y0, y1) and torch.equal(y0, y2)
     torch.testing.assert_close(st1.sum(0), st0.sum(0), rtol=1e-5, atol=1e-3)
     dy = nhwc(detgen.normal((B, C, H, W), 195), torch.bfloat16)
@@ -789,7 +789,7 @@ def test_bn_backward_finalisation_riding_on_the_weight_gradient_reduction(case):
         assert torch.equal(c0, c1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
 
 
-def test_finalisation_riders_keep_the_training_step():
+def test_finalisation_riders_keep_the_training_step(debug_lib):
     """the HiDDeN step with the feeding layers' BatchNorm-backward finalisations riding on the weight-gradient reductions is
     bit-identical to the step with stand-alone finalisation launches"""
     import ctypes
@@ -797,7 +797,7 @@ def test_finalisation_riders_keep_the_training_step():
     from video_watermarking_forgery_detection_amd.hidden_models import Hidden
     from video_watermarking_forgery_detection_amd import noise_layers as NL
     from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
-    L = _lib.lib()
+    L = debug_lib   # the -DWM_DEBUG build: the release library has no A/B switches
     outs = []
     try:
         for on in (1, 0):

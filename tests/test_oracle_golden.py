@@ -271,3 +271,81 @@ def test_unet(golden):
         close(x.grad, g[key + "/gx"], rtol=1e-3, atol=1e-5)
         for n, p in net.named_parameters():
             np.testing.assert_allclose(p.grad.norm().item(), float(g[f"{key}/gnorm/{n}"]), rtol=1e-3, atol=1e-5)
+
+
+def _c3_attacks():
+    """the C3 attack cycle on the oracle's restatements (same names as make_golden._ref_attacks)"""
+    def crop(x):
+        H, W = x.shape[2], x.shape[3]
+        return attacks_ref.crop(x, apex=(H // 8, H // 8 + int(0.75 * H), W // 8, W // 8 + int(0.75 * W)))[0]
+    return {"GaussianBlur": attacks_ref.gaussian_blur, "Resize0.7": lambda x: attacks_ref.resize(x, 0.7), "Crop0.75": crop,
+            "MiddleBlur3": lambda x: attacks_ref.median_blur(x, 3), "JpegSS70": lambda x: jpeg_ref.jpeg_layer(x, 70, "ss")}
+
+
+@pytest.mark.parametrize("nname", ["GaussianBlur", "Resize0.7", "Crop0.75", "MiddleBlur3"])
+def test_full_step_c3_attacks(golden, nname):
+    """config C3: the HiDDeN-order step under the stencil / resample attacks, oracle vs the fixture generated from the reference's
+    modules (MiddleBlur3: the build's own definition on both sides -- kornia absent, parity unpinned for that op)"""
+    g = golden("step_c3")
+    h = hidden_ref.HiddenRef(hidden_ref.HiDDenConfiguration(H=32, W=32), _c3_attacks()[nname])
+    for m in (h.encoder, h.decoder, h.discriminator):
+        detgen.fill_module(m)
+    images = detgen.uniform((4, 3, 32, 32), 2000)
+    messages = detgen.bits((4, 30), 2001)
+    for it in range(2):
+        losses, (enc, noised, dec), grads = h.train_on_batch(images, messages)
+        ref = g[f"step_{nname}/losses_it{it}"]
+        got = [losses[k] for k in ("loss           ", "encoder_mse    ", "dec_mse        ", "bitwise-error  ",
+                                   "adversarial_bce", "discr_cover_bce", "discr_encod_bce")]
+        np.testing.assert_allclose(got, ref, rtol=2e-3 if it else 1e-4, atol=1e-5)
+        if it == 0:
+            close(enc, g[f"step_{nname}/encoded"], atol=1e-5)
+            close(noised, g[f"step_{nname}/noised"], atol=1e-5)
+            close(dec, g[f"step_{nname}/decoded"], atol=1e-4)
+            for tag in ("D", "E", "Dec"):
+                for n, gr in grads[tag].items():
+                    close(detgen.subsample(gr, 31), g[f"step_{nname}/g{tag}/{n}"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", ["jpegss_clip", "resize", "gauss_hipsnr"])
+def test_localise_branch(golden, case):
+    """row a18: the HiDDeN-order step + tamper-localisation branch (oracle/localise_ref.py) against the fixture composed from the
+    reference's own modules (make_golden.gen_localise): clamp-STE -> Quantization -> splice -> attack -> clamp-STE -> Quantization ->
+    UNet -> BCEWithLogits on the sigmoid mask, PSNR-gated fidelity weight (both branches), joint gradient clipping."""
+    from oracle import localise_ref
+    g = golden("localise")
+    key = f"loc_{case}"
+    attack = _c3_attacks()[str(g[key + "/attack"])]
+    clip = float(g[key + "/clip"]) or None
+    gain = float(g[key + "/enc_gain"])
+    h = hidden_ref.HiddenRef(hidden_ref.HiDDenConfiguration(H=32, W=32), attack)
+    unet = detgen.fill_module(unet_ref.UNet(3, 1, 32))
+    for m in (h.encoder, h.decoder, h.discriminator):
+        detgen.fill_module(m)
+    B, size = 4, 32
+    images = detgen.uniform((B, 3, size, size), 2100)
+    if gain != 1.0:
+        with torch.no_grad():
+            h.encoder.final_layer.weight.mul_(gain)
+            h.encoder.final_layer.bias.copy_(torch.tensor([0.4, 0.5, 0.6]))
+        images = torch.tensor([0.4, 0.5, 0.6]).view(1, 3, 1, 1).expand(B, 3, size, size).contiguous() + 0.01 * (images - 0.5)
+    messages = detgen.bits((B, 30), 2101)
+    previous = detgen.uniform((B, 3, size, size), 2102)
+    mask = torch.zeros(B, 1, size, size)
+    mask[:, :, 8:24, 4:20] = 1.0
+    mask[1] = 0.0
+    loc = localise_ref.LocaliseRef(h, unet, attack, gradient_clipping=clip)
+    for it in range(2):
+        logs, outs, grads = loc.step(images, messages, previous, mask)
+        ref = g[f"{key}/logs_it{it}"]
+        got = [logs[k] for k in ("loss", "encoder_mse", "dec_mse", "adversarial_bce", "discr_cover_bce", "discr_encod_bce", "PF", "gate", "lB")]
+        np.testing.assert_allclose(got, ref, rtol=2e-3 if it else 1e-4, atol=1e-5)
+        if it == 0:
+            for nm in ("encoded", "tampered", "attacked", "pred", "decoded"):
+                close(outs[nm], g[f"{key}/{nm}"], atol=2e-5 if nm != "attacked" else 1.0 / 255 + 1e-6)
+            assert (np.abs(outs["attacked"].numpy() - g[f"{key}/attacked"]) > 1e-6).mean() < 1e-3   # a quantisation step may flip at .5
+            for tag, st in (("E", 31), ("Dec", 31), ("U", 997)):
+                for n, gr in grads[tag].items():
+                    np.testing.assert_allclose(gr.norm().item(), float(g[f"{key}/g{tag}norm/{n}"]), rtol=2e-3, atol=1e-6)
+                    close(detgen.subsample(gr, st), g[f"{key}/g{tag}/{n}"], rtol=2e-3, atol=2e-5)
+    assert {float(g[f"{key}/logs_it0"][7]), float(g[f"{key}/logs_it1"][7])} == ({0.8, 1.0} if case == "gauss_hipsnr" else {1.0})

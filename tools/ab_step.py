@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from video_watermarking_forgery_detection_amd import _lib, ops
+_lib._lib = _lib.debug_lib()   # the wm_debug_* switches exist only in the -DWM_DEBUG build (lib/libwm_hip_dbg.so)
 from video_watermarking_forgery_detection_amd.hidden_models import Hidden
 from video_watermarking_forgery_detection_amd import noise_layers as NL
 from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration

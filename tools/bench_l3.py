@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from video_watermarking_forgery_detection_amd import ops, _lib
+_lib._lib = _lib.debug_lib()   # the wm_debug_* switches exist only in the -DWM_DEBUG build (lib/libwm_hip_dbg.so)
 
 lib = _lib.lib()
 B, H, W, C = 16, 256, 256, 64

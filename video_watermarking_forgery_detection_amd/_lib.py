@@ -2,25 +2,60 @@
 
 There is NO fallback: if the library is missing or a call fails, a RuntimeError
 is raised.  Nothing under oracle/ is ever imported from here.
+
+Two builds of the same sources live in lib/: libwm_hip.so (release: no knobs, no environment variables, no state between
+calls) is what every product path loads; libwm_hip_dbg.so (-DWM_DEBUG: the wm_debug_* A/B switches) is loaded only on
+request, by tools/ and by the tests that compare a fused kernel with its unfused form (use_debug_library()).
 """
+import contextlib
 import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libwm_hip.so")
+DEBUG_LIB_PATH = os.path.join(_PKG, "lib", "libwm_hip_dbg.so")
 _lib = None
+_release = None
+_debug = None
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python -m video_watermarking_forgery_detection_amd.build` "
+            "(there is no CPU / PyTorch fallback for the HIP path)")
+    h = ctypes.CDLL(path)
+    h.wm_last_error_string.restype = ctypes.c_char_p
+    return h
 
 
 def lib():
-    global _lib
+    """the library every op goes through: the release build unless a use_debug_library() block is open"""
+    global _lib, _release
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} not found: build it with `python -m video_watermarking_forgery_detection_amd.build` "
-                "(there is no CPU / PyTorch fallback for the HIP path)")
-        _lib = ctypes.CDLL(LIB_PATH)
-        _lib.wm_last_error_string.restype = ctypes.c_char_p
+        if _release is None:
+            _release = _load(LIB_PATH)
+        _lib = _release
     return _lib
+
+
+def debug_lib():
+    global _debug
+    if _debug is None:
+        _debug = _load(DEBUG_LIB_PATH)
+    return _debug
+
+
+@contextlib.contextmanager
+def use_debug_library():
+    """inside the block every op runs on the -DWM_DEBUG build, whose wm_debug_* switches the caller may flip; yields its handle"""
+    global _lib
+    prev = lib()
+    _lib = debug_lib()
+    try:
+        yield _lib
+    finally:
+        _lib = prev
 
 
 def check(rc, name):

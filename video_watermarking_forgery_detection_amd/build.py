@@ -16,6 +16,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libwm_hip.so")
+LIB_DEBUG = os.path.join(LIBDIR, "libwm_hip_dbg.so")   # -DWM_DEBUG: the wm_debug_* A/B switches (tools/, fused-vs-unfused tests)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # MFMA kernels: keep the compiler from SLP-packing scalar f32 VALU into v_pk_*_f32 -- packed f32 issues far slower
@@ -33,12 +34,12 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ, src + ".o")
+def _compile(src, force, debug=False):
+    obj = os.path.join(OBJ, src + (".dbg.o" if debug else ".o"))
     sp = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), _deps_mtime()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + ["-x", "hip", "-c", sp, "-o", obj]
+    cmd = [HIPCC] + FLAGS + (["-DWM_DEBUG"] if debug else []) + EXTRA.get(src, []) + ["-x", "hip", "-c", sp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -47,21 +48,26 @@ def _compile(src, force):
     return obj, True
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, debug=True):
+    """release library, and (debug=True) the -DWM_DEBUG twin next to it"""
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = _sources()
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        res = list(ex.map(lambda s: _compile(s, force), srcs))
-    objs = [o for o, _ in res]
-    changed = any(c for _, c in res)
-    if changed or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    if verbose:
-        print(f"[wm build] {LIB} ({'rebuilt' if changed else 'up to date'}; {len(srcs)} sources)")
+    jobs = [(s, False) for s in srcs] + ([(s, True) for s in srcs] if debug else [])
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        res = list(ex.map(lambda j: _compile(j[0], force, j[1]), jobs))
+    for dbg, out in ((False, LIB), (True, LIB_DEBUG)):
+        part = [(o, c) for (o, c), j in zip(res, jobs) if j[1] == dbg]
+        if not part:
+            continue
+        changed = any(c for _, c in part)
+        if changed or not os.path.exists(out):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [o for o, _ in part]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[wm build] {out} ({'rebuilt' if changed else 'up to date'}; {len(srcs)} sources)")
     return LIB
 
 

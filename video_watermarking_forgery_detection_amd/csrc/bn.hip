@@ -393,8 +393,8 @@ extern "C" int wm_bn_finalize(const float* partials, int nparts, int C, int CP, 
 }
 
 constexpr int BWD_BT = 1024;
-static int g_bn_reverse = 1;   // bit 0: reduce pass sweeps backwards (it follows a forward-sweeping dgrad), bit 1: apply pass
-extern "C" void wm_debug_bn_reverse(int mask) { g_bn_reverse = mask; }
+WM_KNOB_INT(g_bn_reverse, "WM_BN_REVERSE", 1);   // bit 0: reduce pass sweeps backwards (it follows a forward-sweeping dgrad), bit 1: apply pass
+WM_KNOB_SETTER(wm_debug_bn_reverse, g_bn_reverse)
 extern "C" int wm_bn_bwd_nparts(size_t npix) {
     const size_t n = (npix + BWD_BT - 1) / BWD_BT;
     return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
@@ -501,8 +501,8 @@ extern "C" int wm_bnrelu_avgpool(const void* y, int ldy, const float* scale, con
     return WM_OK;
 }
 
-static int g_pool_stats = getenv("WM_NO_POOL_STATS") ? 0 : 1;
-extern "C" void wm_debug_pool_stats(int on) { g_pool_stats = on; }   // A/B knob (tools/ab_step.py)
+WM_KNOB_ON(g_pool_stats, "WM_NO_POOL_STATS");
+WM_KNOB_SETTER(wm_debug_pool_stats, g_pool_stats)   // A/B knob (tools/ab_step.py, debug build only)
 extern "C" int wm_pool_stats_enabled(void) { return g_pool_stats; }
 
 extern "C" int wm_bnrelu_avgpool_stats(const void* y, int ldy, const float* scale, const float* shift, float* out3, float* ws, int B,

@@ -30,11 +30,9 @@ int wm_launch_conv3x3_stream(const void* x, int ldx, const void* wp, const float
 // persistent wave-specialised kernel for bf16 Cin in {64,32,16}, Cout in {64,32} (conv3x3_ws.hip)
 int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void* wp, const float* bias, int nbias, const float* in_scale,
                          const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
-                         hipStream_t s, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
+                         hipStream_t s, int reverse, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
                          const float* bw_gvec = nullptr, const void* ry = nullptr, const float* r_scale = nullptr,
                          const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr);
-
-int wm_take_sweep_hint();   // conv3x3_ws.hip: the hint is consumed by the launch it was set for, whichever kernel takes it
 
 namespace {
 
@@ -251,11 +249,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs<T> a) {
 
 constexpr int WS_MAX_WGS = 256;  // one persistent workgroup per CU
 inline bool use_ws(int Cin, int CoutP, int dtype) {
-    static const bool off = getenv("WM_NO_WS") != nullptr;  // diagnostic knob: force the generic kernel
+    static const bool off = WM_ENV_FLAG("WM_NO_WS");  // diagnostic knob (debug build): force the generic kernel
     return !off && dtype == WM_BF16 && (((Cin == 64 || Cin == 32 || Cin == 16) && CoutP == 64) || (Cin == 64 && CoutP == 32));
 }  // + ldy == CoutP (a dense output tensor)
 inline bool use_stream(int Cin, int CoutP, int dtype) {
-    static const bool off = getenv("WM_NO_STREAM") != nullptr;  // diagnostic knob: force the generic kernel
+    static const bool off = WM_ENV_FLAG("WM_NO_STREAM");  // diagnostic knob (debug build): force the generic kernel
     return !off && dtype == WM_BF16 && !use_ws(Cin, CoutP, dtype) && wm_conv3x3_stream_supported(Cin, CoutP);
 }
 inline int ws_tiles_per_wg(int ntiles) { return (ntiles + WS_MAX_WGS - 1) / WS_MAX_WGS; }
@@ -327,7 +325,7 @@ __global__ void pack_w3x3_batch_kernel(const PackJob* __restrict__ jobs) {
 template <typename T>
 int launch_conv(const void* x, int ldx, const void* wp, const float* bias, int nbias, const float* in_scale,
                 const float* in_shift, void* y, int ldy, float* stat, int B, int H, int W, int Cin, int CoutP,
-                hipStream_t s) {
+                hipStream_t s, int reverse) {
     ConvArgs<T> a;
     a.x = (const T*)x; a.ldx = ldx; a.wp = (const T*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale; a.in_shift = in_shift;
     a.y = (T*)y; a.ldy = ldy; a.stat = stat; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.CoutP = CoutP;
@@ -337,7 +335,7 @@ int launch_conv(const void* x, int ldx, const void* wp, const float* bias, int n
         if (use_ws(Cin, CoutP, WM_BF16)) {
             const int ntiles = B * a.tilesX * a.tilesY;
             const int per = ws_tiles_per_wg(ntiles);
-            return wm_launch_conv3x3_ws(x, ldx, Cin, CoutP, wp, bias, nbias, in_scale, in_shift, y, stat, B, H, W, ws_wgs(ntiles), per, s);
+            return wm_launch_conv3x3_ws(x, ldx, Cin, CoutP, wp, bias, nbias, in_scale, in_shift, y, stat, B, H, W, ws_wgs(ntiles), per, s, reverse);
         }
     }
     if constexpr (sizeof(T) == 2) {
@@ -366,7 +364,7 @@ extern "C" int wm_conv3x3_nparts(int B, int H, int W, int Cin, int CoutP, int dt
 
 extern "C" int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const float* bias, int nbias, const float* in_scale,
                               const float* in_shift, void* y, int ldy, float* stat_partials, int B, int H, int W,
-                              int Cin, int CoutP, int dtype, void* stream) {
+                              int Cin, int CoutP, int dtype, int sweep_reverse, void* stream) {
     WM_REQUIRE(x && wp && y, WM_E_BADARG, "wm_conv3x3_fwd: null pointer");
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && CoutP > 0, WM_E_BADARG, "wm_conv3x3_fwd: bad shape");
     WM_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), WM_E_BADARG, "wm_conv3x3_fwd: in_scale/in_shift must come together");
@@ -381,9 +379,8 @@ extern "C" int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const floa
     WM_REQUIRE(!use_ws(Cin, CoutP, dtype) || ldy == CoutP, WM_E_SHAPE,
                "wm_conv3x3_fwd: the persistent bf16 path writes a dense output (ldy must equal CoutP=%d, got %d)", CoutP, ldy);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == WM_BF16) launch_conv<bf16_t>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s);
-    else launch_conv<float>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s);
-    wm_take_sweep_hint();   // (a no-op when the persistent kernel took it)
+    if (dtype == WM_BF16) launch_conv<bf16_t>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s, sweep_reverse ? 1 : 0);
+    else launch_conv<float>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s, 0);
     WM_LAUNCH_CHECK("wm_conv3x3_fwd");
     return WM_OK;
 }
@@ -400,7 +397,7 @@ extern "C" int wm_conv3x3_dgrad_gvfused(const void* y, int ldy, int CoutY, const
                "wm_conv3x3_dgrad_gvfused: bad stride / alignment");
     const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
     const int rc = wm_launch_conv3x3_ws(y, ldy, CoutY, CinP, wpt, nullptr, 0, nullptr, nullptr, dx, nullptr, B, H, W, ws_wgs(ntiles),
-                                        ws_tiles_per_wg(ntiles), (hipStream_t)stream, stats4, CoutY, coef, gvec);
+                                        ws_tiles_per_wg(ntiles), (hipStream_t)stream, 0, stats4, CoutY, coef, gvec);
     WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_dgrad_gvfused: no kernel for this shape");
     WM_LAUNCH_CHECK("wm_conv3x3_dgrad_gvfused");
     return WM_OK;
@@ -408,14 +405,14 @@ extern "C" int wm_conv3x3_dgrad_gvfused(const void* y, int ldy, int CoutY, const
 
 // input gradient whose epilogue also reduces the BatchNorm-backward sums of the layer it feeds.  src: dy [B,H,W,lds] of this
 // layer, or (gvec != NULL) this layer's raw output y with the apply pass fused as in wm_conv3x3_dgrad_gvfused.
-static int g_bwdst = getenv("WM_NO_BWDST") ? 0 : 1;
-extern "C" void wm_debug_bwdst(int on) { g_bwdst = on; }   // A/B knob (tools/ab_step.py)
+WM_KNOB_ON(g_bwdst, "WM_NO_BWDST");
+WM_KNOB_SETTER(wm_debug_bwdst, g_bwdst)   // A/B knob (tools/ab_step.py, debug build only)
 extern "C" int wm_conv3x3_dgrad_bwdstats_supported(int CoutY, int CinP, int dtype) {
     return (g_bwdst && dtype == WM_BF16 && (CoutY == 64 || CoutY == 32) && CinP == 64 && use_ws(CoutY, CinP, dtype)) ? 1 : 0;
 }
 extern "C" int wm_conv3x3_dgrad_bwdstats(const void* src, int lds, int CoutY, const void* wpt, const float* gvec, const float* stats4,
                                          const float* coef, const void* ry, const float* r_scale, const float* r_shift, void* dx,
-                                         float* partials, int B, int H, int W, int CinP, int dtype, void* stream) {
+                                         float* partials, int B, int H, int W, int CinP, int dtype, int sweep_reverse, void* stream) {
     WM_REQUIRE(src && wpt && ry && r_scale && r_shift && dx && partials, WM_E_BADARG, "wm_conv3x3_dgrad_bwdstats: null pointer");
     WM_REQUIRE((gvec == nullptr) == (stats4 == nullptr) && (gvec == nullptr) == (coef == nullptr), WM_E_BADARG,
                "wm_conv3x3_dgrad_bwdstats: gvec, stats4 and coef come together");
@@ -426,7 +423,7 @@ extern "C" int wm_conv3x3_dgrad_bwdstats(const void* src, int lds, int CoutY, co
                "wm_conv3x3_dgrad_bwdstats: bad stride / alignment");
     const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
     const int rc = wm_launch_conv3x3_ws(src, lds, CoutY, CinP, wpt, nullptr, 0, nullptr, nullptr, dx, partials, B, H, W, ws_wgs(ntiles),
-                                        ws_tiles_per_wg(ntiles), (hipStream_t)stream, stats4, CoutY, coef, gvec, ry, r_scale, r_shift);
+                                        ws_tiles_per_wg(ntiles), (hipStream_t)stream, sweep_reverse ? 1 : 0, stats4, CoutY, coef, gvec, ry, r_scale, r_shift);
     WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_dgrad_bwdstats: no kernel for this shape");
     WM_LAUNCH_CHECK("wm_conv3x3_dgrad_bwdstats");
     return WM_OK;
@@ -434,14 +431,14 @@ extern "C" int wm_conv3x3_dgrad_bwdstats(const void* src, int lds, int CoutY, co
 
 // input gradient of an ordinary 64 -> 64 ConvBNRelu with the BatchNorm-backward APPLY pass fused: reads g and the layer's raw
 // output y, writes dy (for the weight gradient that follows) and dx; optionally reduces the feeding layer's sums as above.
-static int g_applyfuse = getenv("WM_NO_APPLY_FUSE") ? 0 : 1;
-extern "C" void wm_debug_apply_fuse(int on) { g_applyfuse = on; }   // A/B knob (tools/ab_step.py)
+WM_KNOB_ON(g_applyfuse, "WM_NO_APPLY_FUSE");
+WM_KNOB_SETTER(wm_debug_apply_fuse, g_applyfuse)   // A/B knob (tools/ab_step.py, debug build only)
 extern "C" int wm_conv3x3_dgrad_applyfused_supported(int CoutY, int CinP, int dtype) {
     return (g_applyfuse && dtype == WM_BF16 && CoutY == 64 && (CinP == 64 || CinP == 32) && use_ws(CoutY, CinP, dtype)) ? 1 : 0;
 }
 extern "C" int wm_conv3x3_dgrad_applyfused(const void* g, const void* y, const float* stats4, const float* coef, const void* wpt,
                                            void* dy_out, void* dx, const void* ry, const float* r_scale, const float* r_shift,
-                                           float* partials, int B, int H, int W, int CinP, int dtype, void* stream) {
+                                           float* partials, int B, int H, int W, int CinP, int dtype, int sweep_reverse, void* stream) {
     WM_REQUIRE(g && y && stats4 && coef && wpt && dy_out && dx, WM_E_BADARG, "wm_conv3x3_dgrad_applyfused: null pointer");
     WM_REQUIRE((ry == nullptr) == (partials == nullptr) && (ry == nullptr) == (r_scale == nullptr) && (ry == nullptr) == (r_shift == nullptr),
                WM_E_BADARG, "wm_conv3x3_dgrad_applyfused: ry, r_scale, r_shift and partials come together");
@@ -452,7 +449,7 @@ extern "C" int wm_conv3x3_dgrad_applyfused(const void* g, const void* y, const f
                "wm_conv3x3_dgrad_applyfused: pointers must be 16-byte aligned");
     const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
     const int rc = wm_launch_conv3x3_ws(g, 64, 64, CinP, wpt, nullptr, 0, nullptr, nullptr, dx, partials, B, H, W, ws_wgs(ntiles),
-                                        ws_tiles_per_wg(ntiles), (hipStream_t)stream, stats4, 64, coef, nullptr, ry, r_scale, r_shift, y, dy_out);
+                                        ws_tiles_per_wg(ntiles), (hipStream_t)stream, sweep_reverse ? 1 : 0, stats4, 64, coef, nullptr, ry, r_scale, r_shift, y, dy_out);
     WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_dgrad_applyfused: no kernel for this shape");
     WM_LAUNCH_CHECK("wm_conv3x3_dgrad_applyfused");
     return WM_OK;

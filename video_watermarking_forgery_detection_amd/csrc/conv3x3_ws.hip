@@ -780,7 +780,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
 
 }  // namespace
 
-// diagnostic entry (tools/phase_ws.py): stamps [wgs][16] u64 = consumer {mfma, epilogue, barrier, -, cycles, realtime} at +0,
+#ifdef WM_DEBUG
+// diagnostic entry of the debug build (tools/phase_ws.py): stamps [wgs][16] u64 = consumer {mfma, epilogue, barrier, -, cycles, realtime} at +0,
 // producer {load issue, transform + LDS write, barrier, -, cycles, realtime} at +8
 extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const float* in_scale, const float* in_shift,
                                             void* y, float* stat, int B, int H, int W, unsigned long long* stamps, int dbg, void* stream) {
@@ -796,24 +797,23 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
     else hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
     return (int)grid.x;
 }
+#endif
 
-static int g_ws_reverse = -1;   // -1: follow the caller's sweep hint (default), 0 / 1: force forward / backward sweeps (A/B knob)
-static thread_local int g_sweep_hint = 0;
-// Optional hint for the NEXT persistent-conv launch issued from this thread: sweep the tiles backwards.  A kernel that starts
-// where its input's producer stopped finds the freshest part of that tensor in the Infinity Cache (256 MB; a layer's
-// tensor is 134 MB): the host alternates the direction along a chain of layers (engine.py).  Results do not depend on it
-// except for the summation order inside the per-workgroup statistics rows.
-extern "C" void wm_conv3x3_sweep_hint(int reverse) { g_sweep_hint = reverse ? 1 : 0; }
-int wm_take_sweep_hint() { const int h = g_sweep_hint; g_sweep_hint = 0; return g_ws_reverse >= 0 ? g_ws_reverse : h; }
-static int g_ws_variant = getenv("WM_WS_VARIANT") ? atoi(getenv("WM_WS_VARIANT")) : 0;   // A/B knobs -- 1: 32x32x16 MFMA consumers, 2: no XCD-aware run assignment, 3: producers at s_setprio 3, 8: no halo-edge reuse, 9: statistics sums not pinned, 10: filter committed to LDS before the first tile loads are issued
-extern "C" void wm_debug_ws_variant(int v) { g_ws_variant = v; }
-
-extern "C" void wm_debug_ws_direction(int reverse) { g_ws_reverse = (reverse == 0 || reverse == 1) ? reverse : -1; }
+// `sweep_reverse` of the conv / dgrad / wgrad entry points: sweep the tiles backwards.  A kernel that starts where its input's
+// producer stopped finds the freshest part of that tensor in the Infinity Cache (256 MB; a layer's tensor is 134 MB): the host
+// alternates the direction along a chain of layers (engine.py).  Results do not depend on it except for the summation order
+// inside the per-workgroup statistics rows.  (A per-call argument: the library keeps no state between calls.)
+WM_KNOB_INT(g_ws_reverse, "WM_WS_REVERSE", -1);   // debug build: -1 follow the caller (default), 0 / 1 force forward / backward sweeps
+WM_KNOB_SETTER(wm_debug_ws_direction, g_ws_reverse)
+int wm_sweep_dir(int reverse) { return (g_ws_reverse == 0 || g_ws_reverse == 1) ? g_ws_reverse : (reverse ? 1 : 0); }
+// debug build A/B knobs -- 1: 32x32x16 MFMA consumers, 2: no XCD-aware run assignment, 3: producers at s_setprio 3, 8: no halo-edge reuse, 9: statistics sums not pinned, 10: filter committed to LDS before the first tile loads are issued
+WM_KNOB_INT(g_ws_variant, "WM_WS_VARIANT", 0);
+WM_KNOB_SETTER(wm_debug_ws_variant, g_ws_variant)
 
 // launcher used by conv3x3.hip
 int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void* wp, const float* bias, int nbias, const float* in_scale,
                            const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
-                           hipStream_t s, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
+                           hipStream_t s, int reverse, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
                            const float* bw_gvec = nullptr, const void* ry = nullptr, const float* r_scale = nullptr,
                            const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr) {
     WsArgs a;
@@ -821,7 +821,7 @@ int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void*
     a.x = (const bf16_t*)x; a.ldx = ldx; a.wp = (const bf16_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
     a.in_shift = in_shift; a.y = (bf16_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY; a.tiles_per_wg = tiles_per_wg;
-    a.reverse = wm_take_sweep_hint();
+    a.reverse = wm_sweep_dir(reverse);
     a.bw_stats4 = bw_stats4; a.bw_ld = bw_ld; a.bw_coef = bw_coef; a.bw_gvec = bw_gvec;
     a.ry = (const bf16_t*)ry; a.r_scale = r_scale; a.r_shift = r_shift;
     a.ay = (const bf16_t*)ay; a.dy_out = (bf16_t*)dy_out;

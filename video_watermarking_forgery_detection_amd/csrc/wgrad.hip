@@ -26,11 +26,10 @@
 
 // wave-specialised bf16 kernel (wgrad_ws.hip)
 void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy,
-                        int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s, const void* yb = nullptr,
+                        int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s, int reverse, const void* yb = nullptr,
                         int ldyb = 0, const float* bstats4 = nullptr, int bstats_ld = 0, const float* bcoef = nullptr,
                         const float* gvec = nullptr);
 
-int wm_take_sweep_hint();   // conv3x3_ws.hip
 
 namespace {
 
@@ -369,7 +368,7 @@ extern "C" size_t wm_conv3x3_wgrad_ws_bytes(int B, int H, int W, int CinX, int C
 // never materialised -- it is formed from g (gradient wrt the ReLU output), y (raw conv output), the BatchNorm constants
 // stats4 = [scale | shift | mean | invstd] (4 rows of CP) and coef = wm_bn_bwd_finalize's [3][CP] while the tile is staged
 extern "C" int wm_conv3x3_wgrad_bnfused_supported(int CinX, int CoutY, int dtype) {
-    static const bool off = getenv("WM_NO_WGRAD_FUSE") != nullptr;
+    static const bool off = WM_ENV_FLAG("WM_NO_WGRAD_FUSE");
     return (!off && dtype == WM_BF16 && CinX <= 16 && CoutY % 64 == 0) ? 1 : 0;
 }
 
@@ -381,7 +380,7 @@ extern "C" int wm_conv3x3_wgrad_bnfused(const void* x, int ldx, int CinX, const 
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && CinX >= Cin && CoutY >= Cout && ldx >= CinX && ldg >= CoutY && ldy >= CoutY &&
                ldx % 8 == 0 && ldg % 8 == 0 && ldy % 8 == 0, WM_E_SHAPE, "wm_conv3x3_wgrad_bnfused: bad shape / strides");
     hipStream_t s = (hipStream_t)stream;
-    wm_launch_wgrad_ws(x, ldx, CinX, nullptr, nullptr, g, ldg, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, y, ldy, stats4, CoutY, coef);
+    wm_launch_wgrad_ws(x, ldx, CinX, nullptr, nullptr, g, ldg, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, 0, y, ldy, stats4, CoutY, coef);
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad_bnfused");
     const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
     launch_wgrad_reduce(ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout, nullptr, accumulate, nullptr, s);
@@ -389,12 +388,12 @@ extern "C" int wm_conv3x3_wgrad_bnfused(const void* x, int ldx, int CinX, const 
     return WM_OK;
 }
 
-static int g_fin_rider = getenv("WM_NO_FIN_RIDER") ? 0 : 1;
-extern "C" void wm_debug_fin_rider(int on) { g_fin_rider = on; }   // A/B knob (tools/ab_step.py)
+WM_KNOB_ON(g_fin_rider, "WM_NO_FIN_RIDER");
+WM_KNOB_SETTER(wm_debug_fin_rider, g_fin_rider)   // A/B knob (tools/ab_step.py, debug build only)
 extern "C" int wm_fin_rider_enabled(void) { return g_fin_rider; }
 
-static int g_gv_fuse = getenv("WM_NO_GV_FUSE") ? 0 : 1;
-extern "C" void wm_debug_gv_fuse(int on) { g_gv_fuse = on; }   // A/B knob (tools/ab_step.py)
+WM_KNOB_ON(g_gv_fuse, "WM_NO_GV_FUSE");
+WM_KNOB_SETTER(wm_debug_gv_fuse, g_gv_fuse)   // A/B knob (tools/ab_step.py, debug build only)
 
 extern "C" int wm_conv3x3_gvfused_supported(int CinX, int CoutY, int dtype) {
     return (g_gv_fuse && dtype == WM_BF16 && CinX == 64 && (CoutY == 64 || CoutY == 32)) ? 1 : 0;
@@ -410,7 +409,7 @@ extern "C" int wm_conv3x3_wgrad_gvfused_fin(const void* x, int ldx, int CinX, co
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && CinX >= Cin && CoutY >= Cout && ldx >= CinX && ldy >= CoutY &&
                ldx % 8 == 0 && ldy % 8 == 0, WM_E_SHAPE, "wm_conv3x3_wgrad_gvfused: bad shape / strides");
     hipStream_t s = (hipStream_t)stream;
-    wm_launch_wgrad_ws(x, ldx, CinX, in_scale, in_shift, nullptr, 0, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, y, ldy, stats4, CoutY, coef, gvec);
+    wm_launch_wgrad_ws(x, ldx, CinX, in_scale, in_shift, nullptr, 0, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, 0, y, ldy, stats4, CoutY, coef, gvec);
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad_gvfused");
     const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
     WM_REQUIRE(launch_wgrad_reduce(ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout, nullptr, accumulate, fin, s) == WM_OK, WM_E_BADARG,
@@ -427,7 +426,8 @@ extern "C" int wm_conv3x3_wgrad_gvfused(const void* x, int ldx, int CinX, const 
 
 extern "C" int wm_conv3x3_wgrad_fin(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift,
                                     const void* dy, int lddy, int CoutY, float* ws, float* dw, int accumulate, int B, int H,
-                                    int W, int Cin, int Cout, const int* perm_dev, int dtype, const WmBnBwdFin* fin, void* stream) {
+                                    int W, int Cin, int Cout, const int* perm_dev, int dtype, const WmBnBwdFin* fin, int sweep_reverse,
+                                    void* stream) {
     WM_REQUIRE(x && dy && ws && dw, WM_E_BADARG, "wm_conv3x3_wgrad: null pointer");
     WM_REQUIRE(fin_rider_ok(fin), WM_E_BADARG, "wm_conv3x3_wgrad: bad finalisation rider (null pointer, or more than 256 partial rows)");
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && CinX > 0 && CoutY >= Cout, WM_E_BADARG, "wm_conv3x3_wgrad: bad shape");
@@ -439,11 +439,10 @@ extern "C" int wm_conv3x3_wgrad_fin(const void* x, int ldx, int CinX, const floa
                "wm_conv3x3_wgrad: bad pixel strides ldx=%d lddy=%d", ldx, lddy);
     WM_REQUIRE(perm_dev || CinX >= Cin, WM_E_BADARG, "wm_conv3x3_wgrad: x has fewer channels than the weight");
     hipStream_t s = (hipStream_t)stream;
-    static const bool v1 = getenv("WM_WGRAD_V1") != nullptr;  // diagnostic knob: single-role kernel
-    if (dtype == WM_BF16 && !v1) wm_launch_wgrad_ws(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, nslabs_for(B, H, W), s);
+    static const bool v1 = WM_ENV_FLAG("WM_WGRAD_V1");  // diagnostic knob (debug build): single-role kernel
+    if (dtype == WM_BF16 && !v1) wm_launch_wgrad_ws(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, sweep_reverse ? 1 : 0);
     else if (dtype == WM_BF16) launch_wgrad<bf16_t>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
     else launch_wgrad<float>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
-    wm_take_sweep_hint();   // (a no-op when the persistent kernel took it)
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad");
     const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
     WM_REQUIRE(launch_wgrad_reduce(ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout, perm_dev, accumulate, fin, s) == WM_OK, WM_E_BADARG,
@@ -455,5 +454,5 @@ extern "C" int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* i
                                 const void* dy, int lddy, int CoutY, float* ws, float* dw, int accumulate, int B, int H,
                                 int W, int Cin, int Cout, const int* perm_dev, int dtype, void* stream) {
     return wm_conv3x3_wgrad_fin(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, dw, accumulate, B, H, W, Cin, Cout, perm_dev, dtype, nullptr,
-                                stream);
+                                0, stream);
 }

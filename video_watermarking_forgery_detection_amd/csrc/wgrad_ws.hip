@@ -9,7 +9,7 @@
 // producer variant of it 1.4 % slower still -- tools/ab_step.py.)
 #include "wm_common.h"
 
-int wm_take_sweep_hint();   // conv3x3_ws.hip
+int wm_sweep_dir(int reverse);   // conv3x3_ws.hip
 
 namespace {
 
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
 }  // namespace
 
 void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy,
-                        int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s, const void* yb = nullptr,
+                        int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s, int reverse, const void* yb = nullptr,
                         int ldyb = 0, const float* bstats4 = nullptr, int bstats_ld = 0, const float* bcoef = nullptr,
                         const float* gvec = nullptr) {
     WsWgArgs a;
@@ -346,7 +346,7 @@ void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale,
     a.bscale = bstats4; a.bshift = bstats4 ? bstats4 + bstats_ld : nullptr; a.bmean = bstats4 ? bstats4 + 2 * bstats_ld : nullptr;
     a.binvstd = bstats4 ? bstats4 + 3 * bstats_ld : nullptr; a.bcoef = bcoef; a.gvec = gvec; a.ldgv = bstats_ld;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
-    a.reverse = wm_take_sweep_hint();
+    a.reverse = wm_sweep_dir(reverse);
     a.ciBlocks = wm_cdiv(CinX, CB); a.coBlocks = wm_cdiv(CoutY, CB);
     const dim3 block(512);
     if (CinX <= 16) {   // one 16-channel input block; the slab keeps its 64-row pitch (rows >= 16 are never read back)

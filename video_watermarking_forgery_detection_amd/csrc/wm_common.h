@@ -30,6 +30,22 @@ void wm_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// ---- A/B knobs.  The release library (lib/libwm_hip.so) holds NO mutable global state and reads no environment variable: every
+// knob below is a compile-time constant there.  The -DWM_DEBUG build (lib/libwm_hip_dbg.so: tools/ab_step.py and the tests that
+// compare a fused kernel with its unfused form) turns them into process-global switches with wm_debug_* setters.
+#ifdef WM_DEBUG
+#include <stdlib.h>
+#define WM_KNOB_ON(var, envname) static int var = getenv(envname) ? 0 : 1          /* default on; the variable turns it off */
+#define WM_KNOB_INT(var, envname, dflt) static int var = getenv(envname) ? atoi(getenv(envname)) : (dflt)
+#define WM_KNOB_SETTER(fn, var) extern "C" void fn(int v) { var = v; }
+#define WM_ENV_FLAG(envname) (getenv(envname) != nullptr)
+#else
+#define WM_KNOB_ON(var, envname) static constexpr int var = 1
+#define WM_KNOB_INT(var, envname, dflt) static constexpr int var = (dflt)
+#define WM_KNOB_SETTER(fn, var)
+#define WM_ENV_FLAG(envname) false
+#endif
+
 static inline int wm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- BatchNorm+ReLU backward apply, folded (bf16 path).  With g one value per (sample, channel) -- a globally pooled layer:

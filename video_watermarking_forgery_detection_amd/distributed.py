@@ -36,30 +36,47 @@ def shard_indices(n, rank, world_size):
 
 
 class GradSync:
-    """callable(flat_grad): all-reduce SUM then / world, in place.  start() / finish() split the call so that a network's
-    bucket travels over xGMI while the backward of the next network still runs (hidden.py: the decoder's bucket overlaps the
-    attack + encoder backward): the collective is queued on RCCL's stream behind the work already on the current stream, and
-    finish() makes the current stream wait for it."""
+    """Gradient all-reduce of flat f32 buckets: SUM over the ranks on RCCL's stream, the division by the world size folded into
+    the optimiser kernel (`scale`, handed to wm_adam_step as grad_scale) instead of a pass of its own.
 
-    def __init__(self, group=None):
+    start(bucket) queues the collective behind the work already on the current stream and returns at once; finish(handle)
+    makes the current stream wait for it.  A bucket is any contiguous slice of a network's flat gradient buffer, so a network
+    can go out in several reverse-order buckets while the rest of its backward still runs:
+      * discriminator (0.30 MB): started after its second backward, travels under the decoder's forward;
+      * decoder (0.97 MB): started after its backward, travels under the attack's and the encoder's backward;
+      * encoder (0.68 MB): [after_concat, final] first, under the four body layers' backward, then [conv_layers];
+      * UNet (31 MB): four buckets in reverse layer order, started from inside its backward.
+    callable(bucket) = start + finish + the division applied in place (for callers that read the averaged gradients).
+    `force` runs the collectives at world size 1 too (tests exercise the exact multi-rank code path on one GPU)."""
+
+    def __init__(self, group=None, force=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
+        self.scale = 1.0 / self.world
 
     def start(self, flat):
-        if self.world == 1:
+        if not self.active:
             return None
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat
 
     def finish(self, handle):
-        if handle is None:
-            return
-        work, flat = handle
-        work.wait()
-        flat.mul_(1.0 / self.world)
+        if handle is not None:
+            handle[0].wait()
+
+    def finish_all(self, handles):
+        for h in handles:
+            self.finish(h)
+
+    def average_(self, flat):
+        """the division, in place (only where something other than the optimiser reads the gradients: clipping)"""
+        if self.world > 1:
+            flat.mul_(self.scale)
+        return flat
 
     def __call__(self, flat):
         self.finish(self.start(flat))
-        return flat
+        return self.average_(flat)
 
 
 def broadcast_parameters(modules, src=0, group=None):

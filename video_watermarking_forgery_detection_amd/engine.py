@@ -26,7 +26,7 @@ class Act:
 
     def __init__(self, t, C, scale=None, shift=None, rev=None, src=None):
         self.t, self.C, self.scale, self.shift = t, C, scale, shift
-        self.bwd = None   # backward: (g, partials, coef or None) left by the consumer's dgrad when it reduced this layer's BatchNorm sums
+        self.bwd = None   # backward: (g, partials, coef or None, g._version) left by the consumer's dgrad when it reduced this layer's BatchNorm sums
         self.src = src    # (bn module, ctx) of the ConvBNRelu that produced t (lets the consumer's backward finish this layer's statistics)
         self.rev = rev    # sweep direction of the conv that just wrote t (False forward, True backward, None: not fresh)
 
@@ -144,7 +144,13 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
     def coef_of():
         if gvec is not None and pool_stats is not None:   # (N+, S+) from the forward pool: no pass over y
             return ops.bn_bwd_coef_pooled(gvec, pool_stats, y, ctx.stats, Cout, gam, dgam, dbet, accumulate)
-        if pre is not None and g is not None and pre[0] is g:
+        if pre is not None:
+            # the consumer's input-gradient kernel already reduced this layer's sums over the tensor it returned: they are only
+            # valid for exactly that tensor, unmodified (a different or edited g would silently use stale sums, or -- when the
+            # rider already wrote dgamma / dbeta -- count them twice)
+            if g is None or pre[0] is not g or g._version != pre[3]:
+                raise RuntimeError("cbr_backward: the gradient handed to this layer is not the tensor its consumer's input-gradient "
+                                   "kernel produced (or it was modified in place since); its pre-reduced BatchNorm sums are stale")
             if pre[2] is not None:   # finished already, as a rider on the next layer's weight-gradient reduction (dgamma / dbeta written there)
                 return pre[2]
             return ops.bn_bwd_coef_raw(pre[1], y, ctx.stats, Cout, gam, dgam, dbet, accumulate)
@@ -177,7 +183,7 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
         if feed_stats:   # input gradient first: the sums it emits are finished by a rider on the weight gradient's reduction
             gx, part = ops.conv3x3_dgrad_bwdstats(y, wpt, x.t, x.scale, x.shift, gvec, ctx.stats, coef)
             pcoef = ops.conv3x3_wgrad_gvfused(x.t, x.scale, x.shift, gvec, y, ctx.stats, coef, grads[conv.weight], accumulate, fin=rider(part))
-            x.bwd = (gx, part, pcoef)
+            x.bwd = (gx, part, pcoef, gx._version)
             return tag(gx)
         ops.conv3x3_wgrad_gvfused(x.t, x.scale, x.shift, gvec, y, ctx.stats, coef, grads[conv.weight], accumulate)
         return tag(ops.conv3x3_dgrad_gvfused(y, wpt, gvec, ctx.stats, coef))
@@ -191,7 +197,7 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
         if feed_stats:
             dy, gx, part = ops.conv3x3_dgrad_applyfused(g, y, ctx.stats, coef, wpt, x.t, x.scale, x.shift, reverse=d)
             pcoef = ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, reverse=not d, fin=rider(part))
-            x.bwd = (gx, part, pcoef)
+            x.bwd = (gx, part, pcoef, gx._version)
         else:
             dy, gx, _ = ops.conv3x3_dgrad_applyfused(g, y, ctx.stats, coef, wpt, reverse=d)
             ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, reverse=not d)
@@ -203,7 +209,7 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
     wpt = _packed(conv, y.shape[-1], rows, dtype, ctx.perm, True)
     if feed_stats:
         gx, part = ops.conv3x3_dgrad_bwdstats(dy, wpt, x.t, x.scale, x.shift)
-        x.bwd = (gx, part, None)
+        x.bwd = (gx, part, None, gx._version)
         return tag(gx, False)
     gx, _ = ops.conv3x3_fwd(dy, wpt, None, None, None, want_stats=False)
     return tag(gx, False)

@@ -68,9 +68,15 @@ class Encoder(nn.Module, engine.FlatModule):
             engine.bump_bn_counters(self)
         return enc, ctx
 
-    def bwd(self, ctx, g_enc, grads, accumulate=False):
+    def body_param_count(self):
+        """number of parameters of conv_layers = offset of after_concat_layer in the flat buffers (parameters() order)"""
+        return sum(p.numel() for p in self.conv_layers.parameters())
+
+    def bwd(self, ctx, g_enc, grads, accumulate=False, after_head=None):
         """g_enc [B,3,H,W] f32: gradient wrt the encoded image.  Parameter gradients go to `grads`.
-        (No gradient wrt image/message: the reference's inputs do not require grad.)"""
+        (No gradient wrt image/message: the reference's inputs do not require grad.)
+        after_head: optional callable run once the gradients of final_layer and after_concat_layer are queued (data parallel:
+        their bucket leaves while the body layers run their backward)."""
         c = self.conv_channels
         if self._perm_dev is None or self._perm_dev.device != g_enc.device:
             self._perm_dev = torch.tensor(self._perm, dtype=torch.int32, device=g_enc.device)
@@ -81,6 +87,8 @@ class Encoder(nn.Module, engine.FlatModule):
         blk = self.after_concat_layer
         g = engine.cbr_backward(blk.layers[0], blk.layers[1], ctx.cat_ctx, grads, g=g, accumulate=accumulate,
                                 dgrad_channels=c, perm_dev=self._perm_dev)
+        if after_head is not None:
+            after_head()
         n = len(self.conv_layers)
         for i in range(n - 1, -1, -1):
             blk = self.conv_layers[i]

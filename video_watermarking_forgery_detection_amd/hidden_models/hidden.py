@@ -103,19 +103,75 @@ class _FlatAdam:
             ops.adam_step(mod.flat_params, mod.flat_grads, m, v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                           g["weight_decay"], self.step_count, decoupled=self.decoupled, grad_scale=grad_scale)
 
+    def _params(self):
+        return [p for mod in self.modules for p in mod.parameters()]
+
     def state_dict(self):
+        """torch.optim.Adam's layout (what the reference's `{iter}.state` files hold, base_model.py:129-150): per-parameter
+        {step, exp_avg, exp_avg_sq} sliced out of the flat moment buffers in parameters() order, one param group."""
         self._ensure()
-        return {"step": self.step_count, "param_groups": self.param_groups,
-                "exp_avg": [t.cpu() for t in self._m], "exp_avg_sq": [t.cpu() for t in self._v]}
+        state, i = {}, 0
+        for mod, m, v in zip(self.modules, self._m, self._v):
+            off = 0
+            for p in mod.parameters():
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m[off:off + n].view_as(p).detach().cpu().clone(),
+                            "exp_avg_sq": v[off:off + n].view_as(p).detach().cpu().clone()}
+                off += n
+                i += 1
+        g = dict(self.param_groups[0])
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": g["weight_decay"], "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": bool(self.decoupled), "initial_lr": g.get("initial_lr", g["lr"]), "params": list(range(i))}
+        return {"state": state if self.step_count else {}, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        """accepts torch.optim.Adam / AdamW state_dicts (the reference's files) and this class's round-1 flat layout"""
         self._ensure()
-        self.step_count = sd["step"]
-        self.param_groups = sd["param_groups"]
-        for t, s in zip(self._m, sd["exp_avg"]):
-            t.copy_(s)
-        for t, s in zip(self._v, sd["exp_avg_sq"]):
-            t.copy_(s)
+        if "state" not in sd:   # round-1 layout: {step, param_groups, exp_avg[list], exp_avg_sq[list]}
+            self.step_count = int(sd["step"])
+            self._update_group(sd["param_groups"][0])
+            for t, src in zip(self._m, sd["exp_avg"]):
+                t.copy_(src)
+            for t, src in zip(self._v, sd["exp_avg_sq"]):
+                t.copy_(src)
+            return
+        groups = sd["param_groups"]
+        if len(groups) != 1:
+            raise ValueError("expected one param group (torch.optim.Adam over one parameter list)")
+        params = self._params()
+        ids = list(groups[0].get("params", range(len(params))))
+        if len(ids) != len(params):
+            raise ValueError(f"optimizer state has {len(ids)} parameters, the networks have {len(params)}")
+        self._update_group(groups[0])
+        state = sd["state"]
+        steps = set()
+        i = 0
+        for mod, m, v in zip(self.modules, self._m, self._v):
+            off = 0
+            for p in mod.parameters():
+                n = p.numel()
+                st = state.get(ids[i], state.get(str(ids[i])))
+                if st is None:   # torch keeps no entry for a parameter that never received a gradient
+                    m[off:off + n].zero_(); v[off:off + n].zero_()
+                else:
+                    if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                        raise ValueError(f"optimizer state of parameter {i} has shape {tuple(st['exp_avg'].shape)}, expected {tuple(p.shape)}")
+                    m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                    v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps.add(int(float(st["step"])))
+                off += n
+                i += 1
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused flat-buffer step keeps one count")
+        self.step_count = steps.pop() if steps else 0
+
+    def _update_group(self, g):
+        for k in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
+            if k in g:
+                self.param_groups[0][k] = tuple(g[k]) if k == "betas" else g[k]
+        if "decoupled_weight_decay" in g:
+            self.decoupled = bool(g["decoupled_weight_decay"])
 
 
 def _noise_fwd(noiser, enc, cover):
@@ -139,6 +195,25 @@ def _noise_bwd(noiser, ctx, g):
         return torch.zeros_like(g)
     (gx,) = torch.autograd.grad(y, x, g, allow_unused=True)
     return gx if gx is not None else torch.zeros_like(g)
+
+
+def _accepts_id(fn):
+    """does fn(image, id=...) exist?  Looked up from the signature (cached per function), never by catching TypeError around
+    the call -- that would hide a TypeError raised inside the attack and run it twice."""
+    key = getattr(fn, "__func__", fn)
+    hit = _ACCEPTS_ID.get(key)
+    if hit is None:
+        import inspect
+        try:
+            ps = inspect.signature(fn).parameters
+            hit = "id" in ps or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in ps.values())
+        except (TypeError, ValueError):
+            hit = False
+        _ACCEPTS_ID[key] = hit
+    return hit
+
+
+_ACCEPTS_ID = {}
 
 
 class Hidden:
@@ -188,18 +263,21 @@ class Hidden:
     def _run_noiser(self, enc, cover):
         n = self.encoder_decoder.noiser
         if hasattr(n, "fwd") and hasattr(n, "bwd"):
-            try:
+            if _accepts_id(n.fwd):   # Combined / Noiser / the attack cycle take a deterministic choice; single layers do not
                 y, c = n.fwd(enc, id=self.noise_id)
-            except TypeError:
+            else:
                 y, c = n.fwd(enc)
             return y, ("explicit", c)
         return _noise_fwd(n, enc, cover)
 
     # ------------------------------------------------------------------ the step
-    def train_on_batch(self, batch: list, extra_encoded_grad=None, clip=None):
-        """extra_encoded_grad: optional callable(encoded, images) -> (gradient wrt encoded, [(name, value)]), run
-        after the encoder forward (the tamper-localisation branch of models/IRNrhi_model.py);
-        clip: optional callable(flat_grad) applied before each optimiser step (clip_grad_norm_)."""
+    def train_on_batch(self, batch: list, extra_encoded_grad=None, clip=None, enc_gate=None):
+        """extra_encoded_grad: optional callable(encoded, images, g_enc) -> [(name, value)] that ADDS its gradient wrt the
+        encoded image into g_enc (the tamper-localisation branch of models/IRNrhi_model.py), run after the decoder's backward;
+        clip: optional callable(list of flat gradient buffers) applied before each optimiser step -- the buffers of one call
+        are clipped TOGETHER by their joint norm (clip_grad_norm_ over netG.parameters(), IRNcrop_model.py:410-412);
+        enc_gate: optional callable(encoded, images) -> [2] device tensor (psnr, weight): the PSNR-gated weight of the
+        image-fidelity term (IRNcrop_model.py:379-388), multiplied into encoder_loss without a host sync."""
         images, messages = batch
         images = images.to(self.device, torch.float32).contiguous()
         messages = messages.to(self.device, torch.float32).contiguous()
@@ -219,12 +297,12 @@ class Hidden:
             for n in nets:
                 n.refresh_packs()
             with engine.defer_bn_counters(), engine.share_image_acts():
-                return self._train_step(images, messages, B, cfg, ed, enc_net, dec_net, D, gD, gE, gDec, extra_encoded_grad, clip)
+                return self._train_step(images, messages, B, cfg, ed, enc_net, dec_net, D, gD, gE, gDec, extra_encoded_grad, clip, enc_gate)
         finally:
             for n in nets:
                 n.invalidate_packs()
 
-    def _train_step(self, images, messages, B, cfg, ed, enc_net, dec_net, D, gD, gE, gDec, extra_encoded_grad, clip):
+    def _train_step(self, images, messages, B, cfg, ed, enc_net, dec_net, D, gD, gE, gDec, extra_encoded_grad, clip, enc_gate=None):
         # ---------------- train the discriminator (hidden.py:68-83)
         d_on_cover, c = D.fwd(images)
         d_loss_on_cover, g = self._bce_logits(d_on_cover, self.cover_label)
@@ -232,16 +310,25 @@ class Hidden:
 
         encoded, cE = enc_net.fwd(images, messages)
         noised, cN = self._run_noiser(encoded, images)
-        decoded, cDec = dec_net.fwd(noised)
 
         d_on_encoded, c = D.fwd(encoded)                                  # encoded.detach()
         d_loss_on_encoded, g = self._bce_logits(d_on_encoded, self.encoded_label)
         D.bwd(c, g, gD, accumulate=True, need_input_grad=False)
-        if self.grad_sync is not None:
-            self.grad_sync(D.flat_grads)
+        gs = self.grad_sync
+        # data parallel: the discriminator's bucket travels under the decoder's forward (independent of D; the reference runs it
+        # before D(encoded), the results are the same)
+        pending_d = gs.start(D.flat_grads) if gs is not None else None
+        decoded, cDec = dec_net.fwd(noised)
+        gscale = 1.0
+        if gs is not None:
+            gs.finish(pending_d)
+            gscale = gs.scale
+            if clip is not None:
+                gs.average_(D.flat_grads)
+                gscale = 1.0
         if clip is not None:
-            clip(D.flat_grads)
-        self.optimizer_discrim.step()
+            clip([D.flat_grads])
+        self.optimizer_discrim.step(grad_scale=gscale)
         D.refresh_packs()
 
         # ---------------- train the generator (hidden.py:85-103)
@@ -252,31 +339,42 @@ class Hidden:
         g_enc = D.bwd(c, g, gD, accumulate=True, need_input_grad=True)
 
         n_img = encoded.numel()
-        enc_part, g_mse = ops.mse_fwd_bwd(encoded, images, 2.0 * cfg.encoder_loss / n_img)
+        gate = enc_gate(encoded, images) if enc_gate is not None else None
+        if gate is None:
+            enc_part, g_mse = ops.mse_fwd_bwd(encoded, images, 2.0 * cfg.encoder_loss / n_img)
+        else:
+            enc_part, g_mse = ops.mse_fwd_bwd_gated(encoded, images, 2.0 * cfg.encoder_loss / n_img, gate[1:2])
         ops.axpy_(g_enc, g_mse)
         msg_out, g_dec = ops.message_loss(decoded, messages, 2.0 * cfg.decoder_loss / decoded.numel())   # mse, bit error, grad
         g_dec = g_dec.view_as(decoded)
         g_noised = dec_net.bwd(cDec, g_dec, gDec, accumulate=False, need_input_grad=True)
-        # data parallel: the decoder's gradient bucket goes out now and travels while the attack and the encoder run their backward
-        overlap = self.grad_sync is not None and hasattr(self.grad_sync, "start")
-        pending_dec = self.grad_sync.start(dec_net.flat_grads) if overlap else None
+        # data parallel: the decoder's bucket goes out now and travels while the attack and the encoder run their backward
+        pending = [gs.start(dec_net.flat_grads)] if gs is not None else []
         g_from_noise = _noise_bwd(ed.noiser, cN, g_noised)
         ops.axpy_(g_enc, g_from_noise.contiguous())
         extra_logs = []
         if extra_encoded_grad is not None:
-            g_extra, extra_logs = extra_encoded_grad(encoded, images)
-            ops.axpy_(g_enc, g_extra)
-        enc_net.bwd(cE, g_enc, gE, accumulate=False)
-        if self.grad_sync is not None:
-            self.grad_sync(enc_net.flat_grads)
-            if overlap:
-                self.grad_sync.finish(pending_dec)
-            else:
-                self.grad_sync(dec_net.flat_grads)
+            extra_logs = extra_encoded_grad(encoded, images, g_enc)
+        if gate is not None:
+            extra_logs = [('PF', gate[0:1])] + list(extra_logs)
+        if gs is not None:
+            # the encoder in two reverse-order buckets: [after_concat, final] leaves under the body layers' backward
+            cut = enc_net.body_param_count()
+            enc_net.bwd(cE, g_enc, gE, accumulate=False, after_head=lambda: pending.append(gs.start(enc_net.flat_grads[cut:])))
+            pending.append(gs.start(enc_net.flat_grads[:cut]))
+            gs.finish_all(pending)
+        else:
+            enc_net.bwd(cE, g_enc, gE, accumulate=False)
+        gscale = 1.0
+        if gs is not None:
+            gscale = gs.scale
+            if clip is not None:
+                gs.average_(enc_net.flat_grads)
+                gs.average_(dec_net.flat_grads)
+                gscale = 1.0
         if clip is not None:
-            clip(enc_net.flat_grads)
-            clip(dec_net.flat_grads)
-        self.optimizer_enc_dec.step()
+            clip([enc_net.flat_grads, dec_net.flat_grads])   # one norm over encoder_decoder.parameters()
+        self.optimizer_enc_dec.step(grad_scale=gscale)
 
         # ---------------- metrics: one host sync for all seven scalars (hidden.py:105-117)
         vals = ops.hidden_metrics(enc_part, n_img, msg_out, g_loss_adv, d_loss_on_cover, d_loss_on_encoded, cfg.adversarial_loss,

@@ -53,9 +53,16 @@ class _AttackCycle:
         self.k = 0
         self.name = "NotChosenYet"
 
-    def fwd(self, image, id=None):
+    def fwd(self, image, id=None, exclude=()):
         i = self.k % len(self.layers) if id is None else id
         layer = self.layers[i]
+        for _ in range(len(self.layers)):   # a layer type the caller cannot use (the localiser and Crop): take the next one in the cycle
+            if not isinstance(layer, exclude):
+                break
+            i = (i + 1) % len(self.layers)
+            layer = self.layers[i]
+        else:
+            layer = Identity()
         if isinstance(layer, Resize):
             y, c = layer.fwd(image, resize_ratio=0.7)
         elif isinstance(layer, Crop):
@@ -132,6 +139,11 @@ class IRNrhiModel(BaseModel):
             self.optimizer_localizer = _FlatAdam([self.localizer], lr=lr, betas=betas, weight_decay=wd)
             self.optimizers.append(self.optimizer_localizer)
             self.localizer_weight = _get(train_opt, 'localizer_weight', default=1.0)
+        self.psnr_gate = bool(_get(train_opt, 'psnr_gate', default=True))   # IRNcrop_model.py:379-388
+        self._loc = None
+        self.messages = None
+        self.keep_outputs = False    # tests / image dumps: keep the step's tensors in self.last_outputs
+        self.last_outputs = {}
         if opt['dist']:
             from ..distributed import broadcast_parameters
             nets = [self.netG.encoder, self.netG.decoder, self.discriminator] + ([self.localizer] if self.localizer else [])
@@ -146,8 +158,11 @@ class IRNrhiModel(BaseModel):
         {'GT': imgs, 'mask': mask} or the bare tensor.  Clips are folded into the batch (frames are
         independent units, IRNcrop_model.py:357-366)."""
         mask = None
+        self.messages = None
         if isinstance(batch, dict):
             imgs, mask = batch.get('GT', batch.get('imgs')), batch.get('mask')
+            if batch.get('messages') is not None:   # the watermark bits to embed ([B*T, L]); drawn at random per step when absent
+                self.messages = batch['messages'].to(self.device, torch.float32).contiguous()
         elif isinstance(batch, (tuple, list)):
             imgs = batch[0]
             mask = batch[1] if len(batch) > 1 and torch.is_tensor(batch[1]) and batch[1].dim() >= 4 else None
@@ -163,41 +178,75 @@ class IRNrhiModel(BaseModel):
         self.mask = mask.to(self.device, torch.float32).contiguous() if mask is not None else None
 
     # ------------------------------------------------------------------ localisation branch
-    def _localise(self, encoded, images):
-        """IRNcrop_model.py:344-393 on the HIP kernels.  Returns (gradient wrt `encoded`, logs)."""
-        net = self.localizer
-        prev = self.previous_images
+    def _gate(self, encoded, images):
+        """IRNcrop_model.py:344-348,379-388: one pass over the encoded batch forms Q(clamp(encoded)), the spliced (tampered)
+        batch for _localise and the PSNR partial sums; the 1.0 / 0.8 forward weight stays on the device."""
         mask = self.mask
         if mask is None:
             mask = torch.zeros(encoded.shape[0], 1, encoded.shape[2], encoded.shape[3], device=encoded.device)
-        inside = ((encoded >= 0) & (encoded <= 1)).float()      # kept for reference: STE clamp passes grad everywhere
-        fwd_img = ops.quant(encoded.clamp(0, 1))                  # clamp_with_grad (:320-322) + Quantization (:345)
-        tampered = fwd_img * (1 - mask) + prev * mask           # splice (:348)
-        attacked, cA = self.attack.fwd(tampered)
-        attacked_q = ops.quant(attacked)                          # Quantization (:373)
+        _, tampered, part = ops.splice_fwd(encoded, real=images, prev=self.previous_images, mask=mask)
+        self._loc = (tampered, mask)
+        return ops.psnr_gate(part, encoded.numel(), 33.0, 1.0, 0.8)
+
+    def _localise(self, encoded, images, g_enc):
+        """IRNcrop_model.py:344-393 on the HIP kernels: STE clamp -> Quantization -> splice with the previous batch by the
+        mask -> attack -> STE clamp -> Quantization -> UNet -> BCEWithLogits on the (sigmoid) mask.  Adds the gradient wrt
+        `encoded` into g_enc (the splice passes g*(1-mask); clamp_with_grad and Quantization are identities backwards),
+        steps the localiser, returns the logs."""
+        net = self.localizer
+        if self._loc is None:
+            self._gate(encoded, images)
+        (tampered, mask), self._loc = self._loc, None
+        kind = self.attack.name                                     # the step's attack (set by the embed -> attack -> extract pass)
+        attacked, cA = self.attack.fwd(tampered, exclude=(Crop,))   # the reference's localiser sees no geometric attack (:362-366)
+        attacked_q = ops.clamp_quant(attacked)                      # clamp_with_grad + Quantization (:372-373)
+        if self.keep_outputs:
+            self.last_outputs.update(tampered=tampered, attacked=attacked_q)
         net.refresh_packs()   # all conv weights of the localiser packed in one launch, valid until its optimiser step
         try:
             pred, cU = net.fwd(attacked_q)
-            # reference applies BCEWithLogits to the sigmoid output (:378,391-393)
-            loss = F.binary_cross_entropy_with_logits(pred, mask)
-            g_pred = (torch.sigmoid(pred) - mask) / pred.numel() * self.localizer_weight
+            if self.keep_outputs:
+                self.last_outputs["pred"] = pred
+            # the reference applies BCEWithLogits to the sigmoid output (:378,391-393); the kernel chains sigmoid'
+            loss, g_logit = ops.bce_logits_target(pred, mask, self.localizer_weight, chain_sigmoid=True)
             grads = engine.grad_dict(net)
-            g_att = net.bwd(cU, g_pred, grads, accumulate=False, need_input_grad=True)
+            # data parallel: the localiser's 31 MB of gradients leave in four reverse-order buckets from inside its backward
+            gs, pending = self.grad_sync, []
+            ready = (lambda lo, hi: pending.append(gs.start(net.flat_grads[lo:hi]))) if gs is not None else None
+            g_att = net.bwd(cU, g_logit.view_as(pred), grads, accumulate=False, need_input_grad=True, g_is_logit=True, bucket_ready=ready)
         finally:
             net.invalidate_packs()
-        if self.grad_sync is not None:
-            self.grad_sync(net.flat_grads)
-        self._clip(net.flat_grads)
-        self.optimizer_localizer.step()
-        g_tamp = self.attack.bwd(cA, g_att)                        # Quantization backward = identity
-        g_enc = g_tamp * (1 - mask)                              # splice; STE clamp + Quantization: identity
-        del inside
-        return g_enc.contiguous(), [('CE', loss), ('Kind', self.attack.name)]
+        gscale = 1.0
+        if gs is not None:
+            gs.finish_all(pending)
+            gscale = gs.scale
+            if self.gradient_clipping:
+                gs.average_(net.flat_grads)
+                gscale = 1.0
+        self._clip([net.flat_grads])
+        self.optimizer_localizer.step(grad_scale=gscale)
+        g_tamp = self.attack.bwd(cA, g_att)
+        ops.masked_axpy_(g_enc, g_tamp.contiguous(), mask)
+        return [('lB', loss), ('CE', loss), ('Kind', kind), ('LocKind', self.attack.name)]
 
-    def _clip(self, flat):
+    def _clip(self, flats):
         if self.gradient_clipping:
-            norm = ops.sumsq(flat).sum().sqrt()
-            flat.mul_(torch.clamp(self.gradient_clipping / (norm + 1e-6), max=1.0))  # clip_grad_norm_ without a host sync
+            ops.clip_grad_norm_(flats, self.gradient_clipping)   # joint norm, clip coefficient stays on the device
+
+    @torch.no_grad()
+    def localise_mask(self, images, threshold=0.5):
+        """integer tamper mask of a batch: the localiser in eval mode (running BatchNorm statistics), sigmoid output > threshold,
+        uint8 [B,1,H,W]"""
+        if self.localizer is None:
+            raise RuntimeError("this model was built without the localiser (train.localizer)")
+        x = images.to(self.device, torch.float32).contiguous()
+        was = self.localizer.training
+        self.localizer.eval()
+        try:
+            pred, _ = self.localizer.fwd(x, training=False)
+        finally:
+            self.localizer.train(was)
+        return ops.mask_threshold(pred, threshold)
 
     # ------------------------------------------------------------------ the step
     def optimize_parameters(self, step, latest_values=None, train=True, eval_dir=None):
@@ -208,11 +257,17 @@ class IRNrhiModel(BaseModel):
         if ready and train:
             B = self.real_H.shape[0]
             L = self.hidden.config.message_length
-            messages = torch.randint(0, 2, (B, L), device=self.device).float()
+            messages = self.messages if self.messages is not None else torch.randint(0, 2, (B, L), device=self.device).float()
             self.attack.k = step
             extra = self._localise if self.use_localizer else None
-            losses, _ = self.hidden.train_on_batch([self.real_H, messages], extra_encoded_grad=extra,
-                                                   clip=self._clip if self.gradient_clipping else None)
+            gate = self._gate if (self.use_localizer and self.psnr_gate) else None
+            self._loc = None
+            if self.keep_outputs:
+                self.last_outputs = {}
+            losses, outs = self.hidden.train_on_batch([self.real_H, messages], extra_encoded_grad=extra,
+                                                      clip=self._clip if self.gradient_clipping else None, enc_gate=gate)
+            if self.keep_outputs:
+                self.last_outputs.update(encoded=outs[0], noised=outs[1], decoded=outs[2])
             extra_logs = losses.pop('_extra', [])
             logs = [(k.strip(), v) for k, v in losses.items()]
             for name, v in extra_logs:

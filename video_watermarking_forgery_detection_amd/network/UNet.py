@@ -119,12 +119,26 @@ class UNet(nn.Module, engine.FlatModule):
             engine.bump_bn_counters(self)
         return out, ctx
 
-    def bwd(self, ctx, g_out, grads, accumulate=False, need_input_grad=True):
-        """g_out: gradient wrt the sigmoid output [B,out,H,W] f32 -> gradient wrt x [B,3,H,W] (or None)"""
+    def grad_buckets(self):
+        """four contiguous [lo, hi) ranges of the flat gradient buffer in the order the backward completes them (reverse
+        layer order; flat order = parameters() order: encoder1-4, bottleneck, upconv4, decoder4, ..., decoder1, conv):
+        [upconv3 .. conv], [upconv4, decoder4], [bottleneck], [encoder1-4] -- 0.75 / 2.3 / 3.5 / 1.2 M parameters (3 / 9 / 14 / 5 MB) at features=32"""
+        off, start = 0, {}
+        for name, mod in self.named_children():
+            start[name] = off
+            off += sum(p.numel() for p in mod.parameters())
+        return [(start["upconv3"], off), (start["upconv4"], start["upconv3"]), (start["bottleneck"], start["upconv4"]),
+                (0, start["bottleneck"])]
+
+    def bwd(self, ctx, g_out, grads, accumulate=False, need_input_grad=True, g_is_logit=False, bucket_ready=None):
+        """g_out: gradient wrt the sigmoid output [B,out,H,W] f32 (g_is_logit: wrt the 1x1 conv's output, the sigmoid already
+        chained by the loss kernel) -> gradient wrt x [B,3,H,W] (or None).
+        bucket_ready: optional callable(lo, hi) run when the gradients of flat range [lo, hi) (grad_buckets()) are queued."""
+        bk = self.grad_buckets() if bucket_ready is not None else None
         f = self.features
         oc = self.conv.weight.shape[0]
         y = ctx.out
-        g_logit = g_out * y * (1.0 - y)  # sigmoid' on the small mask tensor
+        g_logit = g_out if g_is_logit else g_out * y * (1.0 - y)  # sigmoid' on the small mask tensor
         a = ctx.last
         g = ops.conv1x1_head_bwd(a.t, a.scale, a.shift, self.conv.weight.data.view(oc, f), g_logit,
                                  grads[self.conv.weight].view(oc, f), grads[self.conv.bias], accumulate)
@@ -136,13 +150,19 @@ class UNet(nn.Module, engine.FlatModule):
             gcats[lvl] = gcat
             up = getattr(self, f"upconv{lvl}")
             g = ops.upconv2x2_bwd(a_in.t, a_in.scale, a_in.shift, up.weight.data, gcat, 0, grads[up.weight], grads[up.bias], accumulate)
+            if bk is not None and lvl in (3, 4):
+                bucket_ready(*bk[lvl - 3])
         g = self._block_bwd(self.bottleneck, ctx.bott, g, grads, accumulate)
+        if bk is not None:
+            bucket_ready(*bk[2])
         for lvl in (4, 3, 2, 1):
             C = f * (1 << (lvl - 1))
             a = ctx.encact[lvl - 1]
             g = ops.maxpool2_bwd(a.t, a.scale, a.shift, g, gcats[lvl], C, C)
             g = self._block_bwd(getattr(self, f"encoder{lvl}"), ctx.enc[lvl - 1], g, grads, accumulate,
                                 need_input_grad=(lvl > 1 or need_input_grad))
+        if bk is not None:
+            bucket_ready(*bk[3])
         if not need_input_grad:
             return None
         return ops.nhwc_to_nchw(g, 3, 0)

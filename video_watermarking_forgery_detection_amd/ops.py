@@ -252,15 +252,14 @@ def _fin_rider(fin):
 
 
 def _sweep(reverse):
-    """hint for the next conv / wgrad launch: sweep the tiles backwards (start where the producer of the input stopped)"""
-    if reverse:
-        _lib.lib().wm_conv3x3_sweep_hint(c_int(1))
+    """sweep_reverse argument of the conv / dgrad / wgrad entry points: walk the tiles backwards (start where the producer of the
+    input stopped -- its last tiles are still in the Infinity Cache)"""
+    return c_int(1 if reverse else 0)
 
 
 def conv3x3_fwd(x, wp, bias, in_scale, in_shift, want_stats, Cin=None, reverse=False):
     """x [B,H,W,ld]; wp [9,CoutP,Cin]; returns y [B,H,W,CoutP] and stat partials (or None)."""
     _need_cuda(x, wp)
-    _sweep(reverse)
     B, H, W, ldx = x.shape
     CoutP, CinW = wp.shape[1], wp.shape[2]
     Cin = CinW if Cin is None else Cin
@@ -270,7 +269,7 @@ def conv3x3_fwd(x, wp, bias, in_scale, in_shift, want_stats, Cin=None, reverse=F
     info = {"B": B, "H": H, "W": W, "Cin": Cin, "CoutP": CoutP, "xform": in_scale is not None, "dtype": x.dtype}
     rc = _timed("conv3x3_fwd", info, lambda: _lib.lib().wm_conv3x3_fwd(
         _p(x), c_int(ldx), _p(wp), _p(bias), c_int(0 if bias is None else bias.numel()), _p(in_scale), _p(in_shift),
-        _p(y), c_int(CoutP), _p(st), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(CoutP), c_int(dtype_id(x)), _stream()))
+        _p(y), c_int(CoutP), _p(st), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(CoutP), c_int(dtype_id(x)), _sweep(reverse), _stream()))
     _lib.check(rc, "wm_conv3x3_fwd")
     return y, st
 
@@ -409,10 +408,9 @@ def conv3x3_dgrad_bwdstats(src, wpt, ry, r_scale, r_shift, gvec=None, stats=None
     assert (gvec is None) == (stats is None) == (coef is None)
     dx = torch.empty(B, H, W, CinP, device=src.device, dtype=src.dtype)
     part = torch.empty(conv3x3_nparts(B, H, W, CoutY, CinP, src.dtype), 2, CinP, device=src.device, dtype=torch.float32)
-    _sweep(reverse)
     rc = _lib.lib().wm_conv3x3_dgrad_bwdstats(_p(src), c_int(lds), c_int(CoutY), _p(wpt), _p(gvec), _p(stats), _p(coef), _p(ry), _p(r_scale),
                                               _p(r_shift), _p(dx), _p(part), c_int(B), c_int(H), c_int(W), c_int(CinP),
-                                              c_int(dtype_id(src)), _stream())
+                                              c_int(dtype_id(src)), _sweep(reverse), _stream())
     _lib.check(rc, "wm_conv3x3_dgrad_bwdstats")
     return dx, part
 
@@ -433,10 +431,9 @@ def conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry=None, r_scale=None, r_sh
     dx = torch.empty(B, H, W, CinP, device=y.device, dtype=y.dtype)
     part = torch.empty(conv3x3_nparts(B, H, W, 64, 64, y.dtype), 2, 64, device=y.device, dtype=torch.float32) if ry is not None else None
     info = {"B": B, "H": H, "W": W, "feed": ry is not None, "dtype": y.dtype}
-    _sweep(reverse)
     rc = _timed("conv3x3_dgrad_applyfused", info, lambda: _lib.lib().wm_conv3x3_dgrad_applyfused(
         _p(g), _p(y), _p(stats), _p(coef), _p(wpt), _p(dy), _p(dx), _p(ry), _p(r_scale), _p(r_shift), _p(part), c_int(B), c_int(H), c_int(W),
-        c_int(CinP), c_int(dtype_id(y)), _stream()))
+        c_int(CinP), c_int(dtype_id(y)), _sweep(reverse), _stream()))
     _lib.check(rc, "wm_conv3x3_dgrad_applyfused")
     return dy, dx, part
 
@@ -505,7 +502,6 @@ def colsum(partials, C, ldp, out, accumulate):
 def conv3x3_wgrad(x, CinX, in_scale, in_shift, dy, dw, accumulate, perm_dev=None, reverse=False, fin=None):
     """dw [Cout,Cin,3,3] f32 view (written in place).  fin: see _fin_rider; then the rider's coef [3,CP] is returned."""
     fst, fcoef = _fin_rider(fin)
-    _sweep(reverse)
     B, H, W, ldx = x.shape
     CoutY = dy.shape[-1]
     L = _lib.lib()
@@ -516,7 +512,8 @@ def conv3x3_wgrad(x, CinX, in_scale, in_shift, dy, dw, accumulate, perm_dev=None
     assert dw.is_contiguous()
     rc = L.wm_conv3x3_wgrad_fin(_p(x), c_int(ldx), c_int(CinX), _p(in_scale), _p(in_shift), _p(dy), c_int(CoutY), c_int(CoutY),
                                 _p(ws), _p(dw), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W), c_int(Cin),
-                                c_int(Cout), _p(perm_dev), c_int(dtype_id(x)), ctypes.byref(fst) if fst is not None else None, _stream())
+                                c_int(Cout), _p(perm_dev), c_int(dtype_id(x)), ctypes.byref(fst) if fst is not None else None, _sweep(reverse),
+                                _stream())
     _lib.check(rc, "wm_conv3x3_wgrad")
     return fcoef
 
@@ -639,6 +636,112 @@ def sumsq(x):
     rc = _lib.lib().wm_sumsq(_p(x), c_size_t(n), _p(part), c_int(nparts), _stream())
     _lib.check(rc, "wm_sumsq")
     return part
+
+
+# ----------------------------------------------------------------------------- tamper-localisation branch
+def clamp_quant(x):
+    """round(255*clamp(x,0,1))/255: clamp_with_grad + Quantization (IRNcrop_model.py:320-322,344-345,372-373); backward = identity"""
+    _need_cuda(x)
+    x = x.contiguous().float()
+    y = torch.empty_like(x)
+    rc = _lib.lib().wm_clamp_quant_fwd(_p(x), _p(y), c_size_t(x.numel()), _stream())
+    _lib.check(rc, "wm_clamp_quant_fwd")
+    return y
+
+
+def splice_fwd(enc, real=None, prev=None, mask=None, want_fwd=False):
+    """q = clamp_quant(enc); tampered = q*(1-mask) + prev*mask (IRNcrop_model.py:344-348); with `real`, also the partial sums of
+    the squared difference of the int-truncated images for the PSNR.  Returns (fwd_q or None, tampered or None, psnr partials or None)."""
+    _need_cuda(enc)
+    enc = enc.contiguous()
+    B, C, H, W = enc.shape
+    L = _lib.lib()
+    fwd = torch.empty_like(enc) if want_fwd else None
+    tam = torch.empty_like(enc) if prev is not None else None
+    part = None
+    if real is not None:
+        part = torch.empty(L.wm_splice_nparts(c_size_t(enc.numel())), device=enc.device, dtype=torch.float64)
+        real = real.contiguous()
+    if prev is not None:
+        prev = prev.contiguous(); mask = mask.contiguous()
+        assert prev.shape == enc.shape and tuple(mask.shape) == (B, 1, H, W) and mask.dtype == torch.float32
+    rc = L.wm_splice_fwd(_p(enc), _p(real), _p(prev), _p(mask), _p(fwd), _p(tam), _p(part), c_int(B), c_int(C), c_size_t(H * W), _stream())
+    _lib.check(rc, "wm_splice_fwd")
+    return fwd, tam, part
+
+
+def psnr_gate(partials, n, threshold=33.0, w_below=1.0, w_above=0.8):
+    """[2] f32 device tensor: (PSNR, forward-loss weight) -- IRNcrop_model.py:379-388, no host sync"""
+    out = torch.empty(2, device=partials.device, dtype=torch.float32)
+    rc = _lib.lib().wm_psnr_gate(_p(partials), c_int(partials.numel()), c_double(float(n)), c_float(threshold), c_float(w_below),
+                                 c_float(w_above), _p(out), _stream())
+    _lib.check(rc, "wm_psnr_gate")
+    return out
+
+
+def mse_fwd_bwd_gated(a, b, gscale, gate):
+    """mse_fwd_bwd with the gradient scale multiplied by the device scalar gate[0]"""
+    a = a.contiguous(); b = b.contiguous()
+    n = a.numel()
+    nparts = max(1, min(1024, (n + 4095) // 4096))
+    part = torch.empty(nparts, device=a.device, dtype=torch.float32)
+    grad = torch.empty_like(a)
+    rc = _lib.lib().wm_mse_fwd_bwd_gated(_p(a), _p(b), _p(grad), c_float(gscale), _p(gate), _p(part), c_int(nparts), c_size_t(n), _stream())
+    _lib.check(rc, "wm_mse_fwd_bwd_gated")
+    return part, grad
+
+
+def bce_logits_target(p, target, gscale=1.0, want_grad=True, chain_sigmoid=False):
+    """BCEWithLogitsLoss(mean)(p, target) for tensors: (loss [1] device tensor, gscale * d loss / d p or None).
+    chain_sigmoid: p is a sigmoid output s(z) and the gradient returned is wrt z."""
+    _need_cuda(p, target)
+    p = p.contiguous().float(); target = target.contiguous().float()
+    assert p.numel() == target.numel()
+    n = p.numel()
+    nparts = max(1, min(1024, (n + 4095) // 4096))
+    part = torch.empty(nparts, device=p.device, dtype=torch.float32)
+    loss = torch.empty(1, device=p.device, dtype=torch.float32)
+    grad = torch.empty_like(p) if want_grad else None
+    rc = _lib.lib().wm_bce_logits_target(_p(p), _p(target), c_size_t(n), c_float(gscale), _p(part), c_int(nparts), _p(loss), _p(grad),
+                                         c_int(1 if chain_sigmoid else 0), _stream())
+    _lib.check(rc, "wm_bce_logits_target")
+    return loss, grad
+
+
+def masked_axpy_(a, g, mask):
+    """a += g * (1 - mask), mask [B,1,H,W] broadcast over channels"""
+    B, C, H, W = a.shape
+    assert a.is_contiguous() and g.is_contiguous() and g.shape == a.shape and mask.is_contiguous() and tuple(mask.shape) == (B, 1, H, W)
+    rc = _lib.lib().wm_masked_axpy(_p(a), _p(g), _p(mask), c_int(B), c_int(C), c_size_t(H * W), _stream())
+    _lib.check(rc, "wm_masked_axpy")
+    return a
+
+
+def mask_threshold(p, threshold=0.5):
+    """uint8 tamper mask: p > threshold"""
+    _need_cuda(p)
+    p = p.contiguous().float()
+    out = torch.empty(p.shape, device=p.device, dtype=torch.uint8)
+    rc = _lib.lib().wm_mask_threshold(_p(p), c_float(threshold), _p(out), c_size_t(p.numel()), _stream())
+    _lib.check(rc, "wm_mask_threshold")
+    return out
+
+
+def clip_grad_norm_(flats, max_norm):
+    """nn.utils.clip_grad_norm_ over the parameters of SEVERAL flat gradient buffers taken together (IRNcrop_model.py:410-412:
+    netG.parameters() is one group), without a host sync.  Returns the [2] device tensor (clip coefficient, total norm)."""
+    assert 1 <= len(flats) <= 4
+    parts = [sumsq(f) for f in flats]
+    arr = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+    ns = (ctypes.c_int * len(parts))(*[p.numel() for p in parts])
+    out = torch.empty(2, device=flats[0].device, dtype=torch.float32)
+    L = _lib.lib()
+    rc = L.wm_clip_coef(arr, ns, c_int(len(parts)), c_float(float(max_norm)), _p(out), _stream())
+    _lib.check(rc, "wm_clip_coef")
+    for f in flats:
+        rc = L.wm_scale_dev(_p(f), c_size_t(f.numel()), _p(out), _stream())
+        _lib.check(rc, "wm_scale_dev")
+    return out
 
 
 # ----------------------------------------------------------------------------- per-kernel timing hook
