@@ -37,6 +37,7 @@ extern "C" {
 
 #define WM_F32 0
 #define WM_BF16 1
+#define WM_F16 2   /* the reference's autocast dtype (IRNcrop_model.py:340); same kernels and rates as WM_BF16, 10-bit mantissa, needs loss scaling */
 
 #define WM_OK 0
 #define WM_E_BADARG (-1)   /* null pointer, non-positive size, unsupported dtype */

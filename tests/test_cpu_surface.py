@@ -113,3 +113,51 @@ def test_host_step_logic_without_a_gpu():
     h = gs.start(g)
     gs.finish(h)
     assert h is None and torch.equal(gs(g), torch.arange(6.0))
+
+
+def test_flat_adam_state_interchanges_with_torch_optim_adam():
+    """training-state files (base_model.py:129-150 of the reference hold torch.optim.Adam state_dicts): _FlatAdam emits and accepts
+    that layout -- per-parameter {step, exp_avg, exp_avg_sq} in parameters() order, one param group -- and still reads round 1's flat one"""
+    from video_watermarking_forgery_detection_amd.hidden_models import Decoder, Discriminator
+    from video_watermarking_forgery_detection_amd.hidden_models.hidden import _FlatAdam
+    from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
+    cfg = HiDDenConfiguration(H=16, W=16)
+    torch.manual_seed(0)
+    nets = [Discriminator(cfg), Decoder(cfg)]
+    for n in nets:
+        n.flatten_parameters_()
+    params = [p for n in nets for p in n.parameters()]
+    topt = torch.optim.Adam(params, lr=2e-3, betas=(0.8, 0.99), weight_decay=0.01)
+    for _ in range(3):
+        for p in params:
+            p.grad = torch.randn_like(p)
+        topt.step()
+    sd = topt.state_dict()
+    flat = _FlatAdam(nets)
+    flat.load_state_dict(sd)
+    assert flat.step_count == 3 and flat.param_groups[0]["lr"] == 2e-3 and tuple(flat.param_groups[0]["betas"]) == (0.8, 0.99)
+    assert flat.param_groups[0]["weight_decay"] == 0.01
+    off = 0
+    for i, p in enumerate(nets[0].parameters()):
+        n = p.numel()
+        assert torch.equal(flat._m[0][off:off + n].view_as(p), sd["state"][i]["exp_avg"])
+        assert torch.equal(flat._v[0][off:off + n].view_as(p), sd["state"][i]["exp_avg_sq"])
+        off += n
+    out = flat.state_dict()
+    fresh = torch.optim.Adam(params, lr=1.0)
+    fresh.load_state_dict(out)                      # torch accepts what we write
+    back = fresh.state_dict()
+    assert back["param_groups"][0]["lr"] == 2e-3 and len(back["state"]) == len(params)
+    for i in range(len(params)):
+        assert torch.equal(back["state"][i]["exp_avg"], sd["state"][i]["exp_avg"])
+        assert torch.equal(back["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"])
+        assert float(back["state"][i]["step"]) == 3.0
+    # a state with a different parameter list is refused, not silently truncated
+    with pytest.raises(ValueError):
+        _FlatAdam(nets[:1]).load_state_dict(sd)
+    # round 1's flat layout is still readable
+    legacy = {"step": 5, "param_groups": [{"lr": 1e-4, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0.0}],
+              "exp_avg": [t.clone() for t in flat._m], "exp_avg_sq": [t.clone() for t in flat._v]}
+    f2 = _FlatAdam(nets)
+    f2.load_state_dict(legacy)
+    assert f2.step_count == 5 and f2.param_groups[0]["lr"] == 1e-4 and torch.equal(f2._m[1], flat._m[1])

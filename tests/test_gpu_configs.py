@@ -283,6 +283,7 @@ def test_localise_branch_golden(golden, tmp_path, case):
         m.previous_images = previous
         m.previous_previous_images = previous
         m.feed_data({"GT": images, "mask": mask, "messages": messages})
+        unet_before = _unet_snapshot(m)
         logs, _ = m.optimize_parameters(it + 1, None)
         d = dict(logs)
         ref = g[f"{key}/logs_it{it}"]     # loss, enc, dec, adv, d_cover, d_enc, PF, gate, lB
@@ -293,19 +294,25 @@ def test_localise_branch_golden(golden, tmp_path, case):
             assert rel(o["encoded"], g[f"{key}/encoded"]) < 1e-3
             assert rel(o["decoded"], g[f"{key}/decoded"]) < 1e-3
             # quantised tensors: equal up to a flipped rounding step where 255*x sits within round-off of .5
-            for nm in ("tampered", "attacked"):
+            # (`attacked`: a flipped step of `tampered` goes through the attack first -- JpegSS's cubic rounding has slope up to 3 -- so a
+            # few of its pixels may land up to three steps away)
+            for nm, steps, frac in (("tampered", 1, 1e-3), ("attacked", 3, 5e-3)):
                 dq = np.abs(o[nm].cpu().numpy() - g[f"{key}/{nm}"])
-                assert dq.max() <= 1.0 / 255 + 1e-6 and (dq > 1e-6).mean() < 1e-3, nm
-            # the predicted mask: 1e-3 wherever no flipped quantisation step of the UNet's input reaches (a flipped input pixel
-            # moves the 3x3-conv stack's output in its neighbourhood by up to ~1e-2)
-            dp = np.abs(o["pred"].cpu().numpy() - g[f"{key}/pred"])
-            assert (dp > 1e-3).mean() < 2e-2 and dp.max() < 3e-2, (float((dp > 1e-3).mean()), float(dp.max()))
-            for tag, mod, st in (("gU", m.localizer, 997),):
-                for n, p in mod.named_parameters():
-                    ref_g = g[f"{key}/{tag}/{n}"]
-                    got_g = detgen.subsample(p.grad, st).cpu().numpy()
-                    assert np.linalg.norm(got_g - ref_g) < 3e-2 * np.linalg.norm(ref_g) + 1e-6, (tag, n)
-                    np.testing.assert_allclose(p.grad.norm().item(), float(g[f"{key}/{tag}norm/{n}"]), rtol=3e-2, atol=1e-6)
+                assert dq.max() <= steps / 255 + 1e-6 and (dq > 1e-6).mean() < frac, (nm, float(dq.max()), float((dq > 1e-6).mean()))
+            # the predicted mask: 1e-3 against the oracle UNet on the same input; against the fixture (whose input differs by the
+            # flipped steps above, which shift every BatchNorm's batch statistics) only a sanity bound
+            assert rel(o["pred"], _pred_on_same_input(unet_before, o["attacked"])) < 1e-3
+            assert np.abs(o["pred"].cpu().numpy() - g[f"{key}/pred"]).max() < 3e-2
+            # the UNet's parameter gradients: against the oracle UNet's autograd on the same input (the fixture's were taken on an
+            # input that differs by the flipped steps, and its 997-strided samples of the 64-element BatchNorm vectors are single values)
+            ref_u = unet_before
+            ref_u.zero_grad()
+            pr = ref_u(o["attacked"].detach().cpu().float())
+            torch.nn.BCEWithLogitsLoss()(pr, mask).backward()
+            if clip:
+                torch.nn.utils.clip_grad_norm_(ref_u.parameters(), clip)
+            for (n, p), (_, q) in zip(m.localizer.named_parameters(), ref_u.named_parameters()):
+                assert rel_l2(p.grad, q.grad) < 3e-2, ("gU", n, rel_l2(p.grad, q.grad))
     # parameters after two Adam steps
     for tag, mod, st in (("wE", m.netG.encoder, 31), ("wDec", m.netG.decoder, 31), ("wD", m.discriminator, 31), ("wU", m.localizer, 997)):
         diffs = []
@@ -321,6 +328,21 @@ def test_localise_branch_golden(golden, tmp_path, case):
         dd = np.concatenate(diffs)
         assert dd.mean() < 3e-4 and (dd > 1e-3).mean() < 0.1, (tag, dd.mean())
     _check_integer_mask(m, images)
+
+
+def _unet_snapshot(m):
+    """the oracle UNet holding the localiser's CURRENT parameters and running statistics (train mode)"""
+    ref = unet_ref.UNet(3, 1, 32)
+    ref.load_state_dict({k: v.detach().cpu().clone() for k, v in m.localizer.state_dict().items()})
+    return ref.train()
+
+
+def _pred_on_same_input(ref_unet, attacked):
+    """what the oracle UNet predicts from the SAME quantised input the HIP UNet saw.  (Comparing against a prediction made from the
+    oracle's own `attacked` would mix in the flipped quantisation steps: in training mode one flipped input pixel moves the batch
+    statistics of all 18 BatchNorm layers, i.e. every output pixel a little.)"""
+    with torch.no_grad():
+        return ref_unet(attacked.detach().cpu().float())
 
 
 def _check_integer_mask(m, images):
@@ -363,21 +385,24 @@ def test_c5_clip_256_vs_oracle(tmp_path):
         m.previous_previous_images = previous.cuda()
         m.feed_data({"GT": clip, "mask": mask5, "messages": messages})
         assert m.real_H.shape == (T, 3, S, S) and m.mask.shape == (T, 1, S, S)
+        unet_before = _unet_snapshot(m)
         logs, _ = m.optimize_parameters(1, None)
         d, o = dict(logs), m.last_outputs
-        res[name] = dict(enc=rel(o["encoded"], routs["encoded"]), dec=rel(o["decoded"], routs["decoded"]), pred=rel(o["pred"], routs["pred"]),
+        res[name] = dict(enc=rel(o["encoded"], routs["encoded"]), dec=rel(o["decoded"], routs["decoded"]),
+                         pred=rel(o["pred"], _pred_on_same_input(unet_before, o["attacked"])),
                          lB=abs(d["lB"] - rlogs["lB"]), PF=abs(d["PF"] - rlogs["PF"]), loss=abs(d["loss"] - rlogs["loss"]) / max(1.0, abs(rlogs["loss"])),
                          tampered=float((np.abs(o["tampered"].cpu().numpy() - routs["tampered"].numpy()) > 1e-6).mean()))
-        dp = np.abs(o["pred"].cpu().numpy() - routs["pred"].numpy())
-        res[name]["pred_gt1e-3"] = float((dp > 1e-3).mean())
+        res[name]["pred_vs_oracle_run"] = float(np.abs(o["pred"].cpu().numpy() - routs["pred"].numpy()).max())
         if name == "f32":
             _check_integer_mask(m, images)    # integer tamper mask: bit-exact
     print("C5", res)
     f, b = res["f32"], res["bf16"]
-    # (pred: a flipped quantisation step of the UNet's input moves its neighbourhood by up to ~1e-2, everything else is within 1e-3)
-    assert f["enc"] < 1e-3 and f["dec"] < 1e-3 and f["pred"] < 3e-2 and f["pred_gt1e-3"] < 2e-2 and f["lB"] < 1e-3 and f["PF"] < 1e-2 and f["loss"] < 1e-3, f
-    assert f["tampered"] < 1e-3, f
-    assert b["enc"] < 2e-2 and b["dec"] < 5e-2 and b["pred"] < 1e-1 and b["lB"] < 2e-2 and b["loss"] < 2e-2, b
+    # (pred: against the oracle UNet on the SAME quantised input -- see _pred_on_same_input; against the oracle's own run, whose input
+    # differs by a few flipped quantisation steps, a sanity bound)
+    assert f["enc"] < 1e-3 and f["dec"] < 1e-3 and f["pred"] < 1e-3 and f["lB"] < 1e-3 and f["PF"] < 1e-2 and f["loss"] < 1e-3, f
+    assert f["tampered"] < 1e-3 and f["pred_vs_oracle_run"] < 1e-1, f
+    # bf16: the 18-conv UNet rounds its activations to bf16 per layer
+    assert b["enc"] < 2e-2 and b["dec"] < 5e-2 and b["pred"] < 1.5e-1 and b["lB"] < 2e-2 and b["loss"] < 2e-2, b
 
 
 def test_grad_sync_one_rank_is_identity():

@@ -1,15 +1,29 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (gpurun): rocprofv3 kernel stats + the two PMC passes of the bench command, into gpurun_out/prof_final.
-# usage: bash tools/collect_profiles.sh   (then tools/summarise_profiles.py locally copies the summaries into profiles/)
-set -e
+# Runs ON THE GPU BOX (gpurun): rocprofv3 kernel stats + separate PMC passes of the bench command and of the attack kernels, into
+# gpurun_out/prof_final.  Then tools/summarise_profiles.py <tag> (locally) copies the summaries into profiles/.
+# Counters go in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; never combined with trace domains other than
+# the kernel trace).  The program itself follows `--` (no env / bash -c hop).
+# usage: bash tools/collect_profiles.sh
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_final
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+set -e
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 3 > $OUT/stats.log 2>&1
 echo "stats done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
 echo "write done"
-ls -R $OUT | head -30
+# MFMA utilisation as the counters report it: busy cycles of the matrix pipe against the cycles the dispatch kept the chip busy
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o m -- python3 $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_mfma.log 2>&1 || echo "mfma pass failed (see pmc_mfma.log)"
+echo "mfma done"
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_mfma2 -o m2 -- python3 $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_mfma2.log 2>&1 || echo "mfma2 pass failed (see pmc_mfma2.log)"
+echo "mfma2 done"
+# the attack kernels at B=16, 256x256
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/att_stats -o a -- python3 $ROOT/tools/attack_bench.py 20 > $OUT/att_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/att_fetch -o af -- python3 $ROOT/tools/attack_bench.py 5 > $OUT/att_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/att_write -o aw -- python3 $ROOT/tools/attack_bench.py 5 > $OUT/att_write.log 2>&1
+python3 $ROOT/tools/attack_bench.py 50 > $OUT/attack_bench.json 2> $OUT/attack_bench.err
+echo "attacks done"
+ls -R $OUT | head -40

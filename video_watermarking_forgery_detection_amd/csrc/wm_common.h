@@ -8,6 +8,8 @@
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short short4v __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -113,12 +115,15 @@ __device__ __forceinline__ void wm_bn_bwd_finalize_block(const WmBnBwdFin& j, in
 template <typename T> struct wm_dtype;
 template <> struct wm_dtype<float> { static constexpr int id = WM_F32; };
 template <> struct wm_dtype<bf16_t> { static constexpr int id = WM_BF16; };
+template <> struct wm_dtype<f16_t> { static constexpr int id = WM_F16; };
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
 
 // 16-byte vector of T: 4 floats or 8 bf16
 template <typename T> struct vec16;
@@ -135,6 +140,38 @@ template <> struct vec16<bf16_t> {
     __device__ __forceinline__ void set(int i, float f) { v[i] = (bf16_t)f; }
 };
 
+template <> struct vec16<f16_t> {
+    static constexpr int N = 8;
+    f16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float f) { v[i] = (f16_t)f; }
+};
+
+// ---- the 16-bit activation type of the MFMA kernels (bf16 = production default, f16 = the reference's autocast dtype, config C5):
+// everything that depends on the bit layout goes through these helpers, so one kernel source serves both
+template <typename H> struct h16;
+template <> struct h16<bf16_t> {
+    typedef bf16x8 x8;
+    typedef bf16_t x2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ float lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }             // low half of a packed pair
+    static __device__ __forceinline__ float hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+    static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct h16<f16_t> {
+    typedef f16x8 x8;
+    typedef f16_t x2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(f16_t, (unsigned short)(w & 0xffffu)); }
+    static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(f16_t, (unsigned short)(w >> 16)); }
+    static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+// two f32 -> one packed pair of H
+template <typename H> __device__ __forceinline__ unsigned h16_pack(float a, float b) {
+    const typename h16<H>::x2 p = {(H)a, (H)b};
+    return __builtin_bit_cast(unsigned, p);
+}
+
 // wave-level sum (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -149,6 +186,9 @@ __device__ __forceinline__ float wave_sum(float v) {
             __VA_ARGS__;                                                       \
         } else if ((dtype) == WM_BF16) {                                       \
             using T = bf16_t;                                                  \
+            __VA_ARGS__;                                                       \
+        } else if ((dtype) == WM_F16) {                                        \
+            using T = f16_t;                                                   \
             __VA_ARGS__;                                                       \
         } else {                                                               \
             wm_set_error("%s: unsupported dtype %d", NAME, (int)(dtype));      \

@@ -14,6 +14,7 @@ Data layout in HBM
   * parameters / gradients / Adam moments: f32, one flat buffer per network.
 """
 import contextlib
+import threading
 
 import torch
 
@@ -41,7 +42,8 @@ def round_up(n, m):
     return (n + m - 1) // m * m
 
 
-_image_acts = None   # id(image) -> (image, version, dtype, NHWC16 tensor) while a share_image_acts() block is open
+_tls = threading.local()   # per host thread: .image_acts = id(image) -> (image, version, dtype, NHWC16 tensor) while a share_image_acts()
+                            # block is open; .bumps = module -> pending count while a defer_bn_counters() block is open
 
 
 @contextlib.contextmanager
@@ -49,29 +51,29 @@ def share_image_acts():
     """inside the block, image_to_act converts an image tensor once: a training step feeds `images` to the discriminator and the
     encoder and `encoded` to two discriminator passes (the images are not modified in between -- checked through their
     version counters)"""
-    global _image_acts
-    if _image_acts is not None:
+    if getattr(_tls, "image_acts", None) is not None:
         yield
         return
-    _image_acts = {}
+    _tls.image_acts = {}
     try:
         yield
     finally:
-        _image_acts = None
+        _tls.image_acts = None
 
 
 def image_to_act(img, dtype):
     """[B,3,H,W] f32 (NCHW) -> Act over a [B,H,W,16] zero-padded NHWC tensor."""
     B, C, H, W = img.shape
     assert C == 3
-    if _image_acts is not None:
-        hit = _image_acts.get(id(img))
+    cache = getattr(_tls, "image_acts", None)
+    if cache is not None:
+        hit = cache.get(id(img))
         if hit is not None and hit[0] is img and hit[1] == img._version and hit[2] == dtype:
             return Act(hit[3], 3)
     t = torch.empty(B, H, W, 16, device=img.device, dtype=dtype)
     ops.nchw_to_nhwc(img, t, 0, 13)
-    if _image_acts is not None:
-        _image_acts[id(img)] = (img, img._version, dtype, t)
+    if cache is not None:
+        cache[id(img)] = (img, img._version, dtype, t)
     return Act(t, 3)
 
 
@@ -318,22 +320,18 @@ def set_compute_dtype(module, dtype):
     return module
 
 
-_deferred_bumps = None   # module -> pending count while a defer_bn_counters() block is open
-
-
 @contextlib.contextmanager
 def defer_bn_counters():
     """inside the block, bump_bn_counters only counts; one multi-tensor add applies everything at exit (a training step
     runs five network forwards: one launch instead of five)"""
-    global _deferred_bumps
-    if _deferred_bumps is not None:   # nested: the outer block flushes
+    if getattr(_tls, "bumps", None) is not None:   # nested: the outer block flushes
         yield
         return
-    _deferred_bumps = {}
+    _tls.bumps = {}
     try:
         yield
     finally:
-        pend, _deferred_bumps = _deferred_bumps, None
+        pend, _tls.bumps = _tls.bumps, None
         if pend:
             torch._foreach_add_([m._nbt for m in pend], [pend[m] for m in pend])
 
@@ -343,8 +341,9 @@ def bump_bn_counters(module):
     nbt = getattr(module, "_nbt", None)
     if nbt is not None and all(m.num_batches_tracked.data_ptr() == nbt[i].data_ptr() for i, m in enumerate(
             mm for mm in module.modules() if isinstance(mm, torch.nn.BatchNorm2d) and mm.num_batches_tracked is not None)):
-        if _deferred_bumps is not None:
-            _deferred_bumps[module] = _deferred_bumps.get(module, 0) + 1
+        pend = getattr(_tls, "bumps", None)
+        if pend is not None:
+            pend[module] = pend.get(module, 0) + 1
             return
         nbt += 1
         return
