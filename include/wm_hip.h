@@ -320,26 +320,28 @@ int wm_upconv2x2_bwd(const void* x, int ldx, const float* scale, const float* sh
                      const void* gy, int ldgy, int c0, void* gx, int ldgx, float* dw_partials,
                      int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
 /* MFMA form of the same layer for bf16 with Cin % 64 == 0 and Cout % 16 == 0 (network/UNet.py:14-38 at every level):
- * four 1x1 GEMMs over the input pixels + pixel shuffle.  wm_upconv2x2_pack builds the two bf16 operands from the
+ * four 1x1 GEMMs over the input pixels + pixel shuffle.  wm_upconv2x2_pack builds the two 16-bit (bf16 / f16) operands from the
  * PyTorch weight [Cin][Cout][2][2]: wf [(ij,co)][Cin] (forward) and wb [Cin][(ij,co)] (dgrad).
  *   fwd  : y[b,2h+i,2w+j,c0+co] = bias[co] + sum_ci relu(scale*x+shift)[b,h,w,ci] * w[ci,co,i,j]
  *   dgrad: gx[b,h,w,ci] = sum_(i,j,co) gy[b,2h+i,2w+j,c0+co] * w[ci,co,i,j]   (gradient wrt the ACTIVATED input)
  *   wgrad: dw[ci,co,i,j] (+)= sum_(b,h,w) relu(scale*x+shift)[b,h,w,ci] * gy[b,2h+i,2w+j,c0+co];  dbias[co] (+)= sum gy
  *          partial: f32[wm_upconv2x2_wgrad_nsplit][Cin][4*Cout], bias_partial: f32[nsplit][4*Cout] (scratch). */
 int wm_upconv2x2_mfma_supported(int Cin, int Cout, int dtype);
-int wm_upconv2x2_pack(const float* w, void* wf, void* wb, int Cin, int Cout, void* stream);
+int wm_upconv2x2_pack(const float* w, void* wf, void* wb, int Cin, int Cout, int dtype, void* stream);   /* dtype: WM_BF16 or WM_F16 */
 int wm_upconv2x2_fwd_mfma(const void* x, int ldx, const float* scale, const float* shift, const void* wf, const float* bias,
-                          void* y, int ldy, int c0, int B, int H, int W, int Cin, int Cout, void* stream);
+                          void* y, int ldy, int c0, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
 int wm_upconv2x2_dgrad_mfma(const void* gy, int ldgy, int c0, const void* wb, void* gx, int ldgx, int B, int H, int W, int Cin,
-                            int Cout, void* stream);
+                            int Cout, int dtype, void* stream);
 int wm_upconv2x2_wgrad_nsplit(int B, int H, int W, int Cin, int Cout);
 int wm_upconv2x2_wgrad_mfma(const void* x, int ldx, const float* scale, const float* shift, const void* gy, int ldgy, int c0,
                             float* partial, float* bias_partial, float* dw, float* dbias, int accumulate, int B, int H, int W,
-                            int Cin, int Cout, void* stream);
+                            int Cin, int Cout, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ losses / optimiser
- * sum((a-b)^2) partials and gradient 2*w*(a-b)/n of nn.MSELoss (hidden.py:37,90). */
-int wm_mse_fwd_bwd(const float* a, const float* b, float* grad_a, float gscale, float* loss_partials,
+ * sum((a-b)^2) partials and gradient 2*w*(a-b)/n of nn.MSELoss (hidden.py:37,90).
+ * gscale_dev (here and in wm_bce_logits / wm_message_loss / wm_bce_logits_target / wm_mse_fwd_bwd_gated; may be NULL): a device
+ * scalar multiplied into gscale -- the loss scale of mixed-precision training (wm_amp_*), which lives on the device. */
+int wm_mse_fwd_bwd(const float* a, const float* b, float* grad_a, float gscale, const float* gscale_dev, float* loss_partials,
                    int nparts, size_t n, void* stream);
 /* y = a + s*b (f32), used to combine image-space gradients. */
 int wm_axpy(float* a, const float* b, float s, size_t n, void* stream);
@@ -360,17 +362,34 @@ int wm_linear_head_bwd(const float* pooled, int ldp, const float* w, const float
                        int accumulate, float* gvec, int CP, float inv_hw, int B, int I, int O, void* stream);
 /* nn.BCEWithLogitsLoss (mean) of n logits against a constant label (hidden_models/hidden.py:68-97): *loss_out = the
  * loss, grad_out[n] (may be NULL) = gscale * d loss / d logits.  One small launch. */
-int wm_bce_logits(const float* logits, float target, int n, float gscale, float* loss_out, float* grad_out, void* stream);
+int wm_bce_logits(const float* logits, float target, int n, float gscale, const float* gscale_dev, float* loss_out, float* grad_out,
+                  void* stream);
 /* decoder message loss (hidden.py:96-99,109-111) on n = B*L values: out2[0] = mean (d-m)^2,
  * out2[1] = mean |clip(round(d),0,1) - m| (the bitwise error), grad_out[n] (may be NULL) = gscale * (d - m). */
-int wm_message_loss(const float* decoded, const float* messages, int n, float gscale, float* out2, float* grad_out,
-                    void* stream);
+int wm_message_loss(const float* decoded, const float* messages, int n, float gscale, const float* gscale_dev, float* out2,
+                    float* grad_out, void* stream);
 /* the seven scalars hidden.py:105-113 logs, in one launch: out7 = [w_adv*adv + w_enc*enc + w_dec*dec, enc, dec, bit error,
  * adv, d_cover, d_encoded] with enc = sum(enc_partials[nparts]) / n_img (wm_mse_fwd_bwd's rows), msg2 = wm_message_loss's
  * out2, adv / d_cover / d_enc = device scalars written by wm_bce_logits. */
 int wm_hidden_metrics(const float* enc_partials, int nparts, double n_img, const float* msg2, const float* adv,
                       const float* d_cover, const float* d_enc, float w_adv, float w_enc, float w_dec, float* out7, void* stream);
 int wm_sumsq(const float* x, size_t n, float* partials, int nparts, void* stream);
+
+/* ------------------------------------------------------------------ mixed precision: torch.cuda.amp.GradScaler on the device
+ * replaces: models/IRNcrop_model.py:143 (GradScaler()), :407 (scaler.scale(loss).backward()), :413-416 (scaler.step x2, scaler.update()).
+ * state: f32[WM_AMP_STATE] device array = [0] loss scale, [1] growth tracker, [2] growth_factor, [3] backoff_factor,
+ * [4] growth_interval, [8+k] found_inf of optimiser k, [12+k] step count of optimiser k (k < 4).  The loss kernels take &state[0]
+ * as gscale_dev, so every gradient of the backward is multiplied by the scale; then, per optimiser,
+ *   wm_amp_found_inf : found_inf[k] = !isfinite(sum of its wm_sumsq rows)       (GradScaler.unscale_'s inf check)
+ *   wm_adam_step_amp : the Adam step on g / scale, skipped when found_inf[k]; bias corrections from the device step count,
+ *                      which a skipped step does not advance (like torch's per-parameter `step`)
+ * and once per iteration wm_amp_update: GradScaler.update() (backoff on any inf, growth after growth_interval clean iterations),
+ * advances the step counts of the optimisers that stepped and clears the flags.  No host synchronisation anywhere. */
+#define WM_AMP_STATE 16
+int wm_amp_found_inf(const float* const* sumsq_partials, const int* nparts, int ngroups, float* state, int k, void* stream);
+int wm_adam_step_amp(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int decoupled, float grad_scale, const float* amp_state, int k, void* stream);
+int wm_amp_update(float* state, int noptimizers, void* stream);
 
 /* ------------------------------------------------------------------ tamper-localisation branch (elementwise, f32 NCHW planes)
  * replaces: models/IRNcrop_model.py:320-322 (clamp_with_grad), :344-345 / :372-373 (Quantization after the clamp),
@@ -395,10 +414,10 @@ int wm_splice_fwd(const float* enc, const float* real, const float* prev, const 
                   double* psnr_partials, int B, int C, size_t HW, void* stream);
 int wm_psnr_gate(const double* psnr_partials, int nparts, double n, float threshold, float w_below, float w_above, float* out2,
                  void* stream);
-int wm_mse_fwd_bwd_gated(const float* a, const float* b, float* grad_a, float gscale, const float* gate_dev, float* loss_partials,
-                         int nparts, size_t n, void* stream);
-int wm_bce_logits_target(const float* p, const float* target, size_t n, float gscale, float* partials, int nparts, float* loss_out,
-                         float* grad_out, int chain_sigmoid, void* stream);
+int wm_mse_fwd_bwd_gated(const float* a, const float* b, float* grad_a, float gscale, const float* gate_dev, const float* gscale_dev,
+                         float* loss_partials, int nparts, size_t n, void* stream);
+int wm_bce_logits_target(const float* p, const float* target, size_t n, float gscale, const float* gscale_dev, float* partials, int nparts,
+                         float* loss_out, float* grad_out, int chain_sigmoid, void* stream);
 int wm_masked_axpy(float* a, const float* g, const float* mask, int B, int C, size_t HW, void* stream);
 int wm_mask_threshold(const float* p, float threshold, uint8_t* out, size_t n, void* stream);
 int wm_clip_coef(const float* const* partials, const int* nparts, int ngroups, float max_norm, float* out2, void* stream);

@@ -323,6 +323,11 @@ def test_localise_branch_golden(golden, tmp_path, case):
                 assert np.array_equal(got_w, ref_w), (tag, n)
                 continue
             dd = np.abs(got_w - ref_w)
+            if tag == "wU" and n.endswith(("running_mean", "running_var")):
+                # running statistics are not Adam-stepped: they follow the batch statistics, which the flipped quantisation steps of
+                # the UNet's input shift a little (the UNet itself is pinned on identical inputs above)
+                assert dd.max() <= 2e-2 * max(1.0, np.abs(ref_w).max()), (tag, n)
+                continue
             assert dd.max() <= 4e-3 + 1e-3 * np.abs(ref_w).max(), (tag, n)
             diffs.append(dd)
         dd = np.concatenate(diffs)

@@ -24,6 +24,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 EXTRA = {"conv3x3_ws.hip": ["-fno-slp-vectorize"], "wgrad_ws.hip": ["-fno-slp-vectorize"], "upconv_mfma.hip": ["-fno-slp-vectorize"], "conv3x3_stream.hip": ["-fno-slp-vectorize"]}
 
 
+# kernels of these files exist for both 16-bit activation dtypes: compiled a second time with -DWM_H16_F16 (the f16 twins)
+TWICE = ("conv3x3_ws.hip", "wgrad_ws.hip", "conv3x3_stream.hip", "upconv_mfma.hip")
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
@@ -34,12 +38,12 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src, force, debug=False):
-    obj = os.path.join(OBJ, src + (".dbg.o" if debug else ".o"))
+def _compile(src, force, debug=False, f16=False):
+    obj = os.path.join(OBJ, src + (".f16" if f16 else "") + (".dbg.o" if debug else ".o"))
     sp = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), _deps_mtime()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + (["-DWM_DEBUG"] if debug else []) + EXTRA.get(src, []) + ["-x", "hip", "-c", sp, "-o", obj]
+    cmd = [HIPCC] + FLAGS + (["-DWM_DEBUG"] if debug else []) + (["-DWM_H16_F16"] if f16 else []) + EXTRA.get(src, []) + ["-x", "hip", "-c", sp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -53,9 +57,12 @@ def build(force=False, verbose=True, debug=True):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = _sources()
-    jobs = [(s, False) for s in srcs] + ([(s, True) for s in srcs] if debug else [])
+    jobs = []
+    for dbg in ((False, True) if debug else (False,)):
+        jobs += [(s, dbg, False) for s in srcs] + [(s, dbg, True) for s in srcs if s in TWICE]
+    jobs.sort(key=lambda j: -os.path.getsize(os.path.join(CSRC, j[0])))   # the long compilations first
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-        res = list(ex.map(lambda j: _compile(j[0], force, j[1]), jobs))
+        res = list(ex.map(lambda j: _compile(j[0], force, j[1], j[2]), jobs))
     for dbg, out in ((False, LIB), (True, LIB_DEBUG)):
         part = [(o, c) for (o, c), j in zip(res, jobs) if j[1] == dbg]
         if not part:

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void bnrelu_copy_kernel(const T* __restrict__ 
 }
 
 bool cp_ok(int CP, int dtype) {
-    const int ve = dtype == WM_BF16 ? 8 : 4;
+    const int ve = dtype != WM_F32 ? 8 : 4;
     if (CP <= 0 || CP % ve) return false;
     const int vpp = CP / ve;
     return vpp <= 256 && (256 % vpp) == 0;
@@ -541,7 +541,7 @@ extern "C" int wm_bnrelu_copy(const void* x, int ldx, const float* scale, const 
                               size_t npix, int C, int dtype, void* stream) {
     WM_REQUIRE(x && y, WM_E_BADARG, "wm_bnrelu_copy: null pointer");
     WM_REQUIRE((scale == nullptr) == (shift == nullptr), WM_E_BADARG, "wm_bnrelu_copy: scale/shift must come together");
-    const int ve = dtype == WM_BF16 ? 8 : 4;
+    const int ve = dtype != WM_F32 ? 8 : 4;
     WM_REQUIRE(C > 0 && C % ve == 0 && c0 % ve == 0 && ldx % ve == 0 && ldy % ve == 0, WM_E_SHAPE,
                "wm_bnrelu_copy: C=%d c0=%d ldx=%d ldy=%d must be multiples of %d", C, c0, ldx, ldy, ve);
     const size_t total = npix * (C / ve);

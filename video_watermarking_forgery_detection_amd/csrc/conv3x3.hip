@@ -24,15 +24,24 @@
 // streamed-filter wave-specialised kernel for bf16 Cin > 64 (conv3x3_stream.hip)
 int wm_conv3x3_stream_supported(int Cin, int CoutP);
 int wm_conv3x3_stream_nparts(int B, int H, int W);
-int wm_launch_conv3x3_stream(const void* x, int ldx, const void* wp, const float* bias, int nbias, const float* in_scale,
-                             const float* in_shift, void* y, int ldy, float* stat, int B, int H, int W, int Cin, int CoutP,
-                             hipStream_t s);
+#define WM_DECL_STREAM(sfx)                                                                                                        \
+    int wm_launch_conv3x3_stream##sfx(const void* x, int ldx, const void* wp, const float* bias, int nbias, const float* in_scale, \
+                                      const float* in_shift, void* y, int ldy, float* stat, int B, int H, int W, int Cin, int CoutP, hipStream_t s)
+WM_DECL_STREAM(_bf16);
+WM_DECL_STREAM(_f16);
 // persistent wave-specialised kernel for bf16 Cin in {64,32,16}, Cout in {64,32} (conv3x3_ws.hip)
-int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void* wp, const float* bias, int nbias, const float* in_scale,
-                         const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
-                         hipStream_t s, int reverse, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
-                         const float* bw_gvec = nullptr, const void* ry = nullptr, const float* r_scale = nullptr,
-                         const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr);
+#define WM_DECL_WS(sfx)                                                                                                                     \
+    int wm_launch_conv3x3_ws##sfx(const void* x, int ldx, int Cin, int CoutP, const void* wp, const float* bias, int nbias,                  \
+                                  const float* in_scale, const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs,          \
+                                  int tiles_per_wg, hipStream_t s, int reverse, const float* bw_stats4 = nullptr, int bw_ld = 0,            \
+                                  const float* bw_coef = nullptr, const float* bw_gvec = nullptr, const void* ry = nullptr,                 \
+                                  const float* r_scale = nullptr, const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr)
+WM_DECL_WS(_bf16);
+WM_DECL_WS(_f16);
+// the two compilations of conv3x3_ws.hip, by activation dtype (WM_BF16 / WM_F16)
+template <typename... A> static inline int wm_launch_conv3x3_ws(int dtype, A... args) {
+    return dtype == WM_F16 ? wm_launch_conv3x3_ws_f16(args...) : wm_launch_conv3x3_ws_bf16(args...);
+}
 
 namespace {
 
@@ -45,6 +54,7 @@ template <> struct Cfg<bf16_t> {
     static constexpr int VE = 8;    // elements per 16-byte vector
     static constexpr int PS = 40;   // LDS row stride in elements (80 B)
 };
+template <> struct Cfg<f16_t> : Cfg<bf16_t> {};
 template <> struct Cfg<float> {
     static constexpr int CK = 16;
     static constexpr int VE = 4;
@@ -160,20 +170,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs<T> a) {
             for (int tap = 0; tap < 9; ++tap) {
                 const int kh = tap / 3, kw = tap % 3;
                 for (int ks = 0; ks < ksteps; ++ks) {
-                    bf16x8 af[2], bfr[NF];
+                    typedef typename h16<T>::x8 hx8;
+                    hx8 af[2], bfr[NF];
 #pragma unroll
                     for (int mf = 0; mf < 2; ++mf) {
                         const int py = wave * 4 + mf * 2 + (r >> 4), px = r & 15;
-                        af[mf] = *reinterpret_cast<const bf16x8*>(sA + ((py + kh) * HW + px + kw) * PS + ks * 16 + h * 8);
+                        af[mf] = *reinterpret_cast<const hx8*>(sA + ((py + kh) * HW + px + kw) * PS + ks * 16 + h * 8);
                     }
 #pragma unroll
                     for (int nf = 0; nf < NF; ++nf)
-                        bfr[nf] = *reinterpret_cast<const bf16x8*>(sB + (tap * BN + nf * 32 + r) * PS + ks * 16 + h * 8);
+                        bfr[nf] = *reinterpret_cast<const hx8*>(sB + (tap * BN + nf * 32 + r) * PS + ks * 16 + h * 8);
 #pragma unroll
                     for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
                         for (int nf = 0; nf < NF; ++nf)
-                            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mf], bfr[nf], acc[mf][nf], 0, 0, 0);
+                            acc[mf][nf] = h16<T>::mfma32(af[mf], bfr[nf], acc[mf][nf]);
                 }
             }
         } else {
@@ -248,13 +259,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs<T> a) {
 }
 
 constexpr int WS_MAX_WGS = 256;  // one persistent workgroup per CU
+inline bool is16(int dtype) { return dtype == WM_BF16 || dtype == WM_F16; }   // the two 16-bit activation dtypes share every MFMA kernel
 inline bool use_ws(int Cin, int CoutP, int dtype) {
     static const bool off = WM_ENV_FLAG("WM_NO_WS");  // diagnostic knob (debug build): force the generic kernel
-    return !off && dtype == WM_BF16 && (((Cin == 64 || Cin == 32 || Cin == 16) && CoutP == 64) || (Cin == 64 && CoutP == 32));
+    return !off && is16(dtype) && (((Cin == 64 || Cin == 32 || Cin == 16) && CoutP == 64) || (Cin == 64 && CoutP == 32));
 }  // + ldy == CoutP (a dense output tensor)
 inline bool use_stream(int Cin, int CoutP, int dtype) {
     static const bool off = WM_ENV_FLAG("WM_NO_STREAM");  // diagnostic knob (debug build): force the generic kernel
-    return !off && dtype == WM_BF16 && !use_ws(Cin, CoutP, dtype) && wm_conv3x3_stream_supported(Cin, CoutP);
+    return !off && is16(dtype) && !use_ws(Cin, CoutP, dtype) && wm_conv3x3_stream_supported(Cin, CoutP);
 }
 inline int ws_tiles_per_wg(int ntiles) { return (ntiles + WS_MAX_WGS - 1) / WS_MAX_WGS; }
 inline int ws_wgs(int ntiles) { const int per = ws_tiles_per_wg(ntiles); return (ntiles + per - 1) / per; }
@@ -332,15 +344,15 @@ int launch_conv(const void* x, int ldx, const void* wp, const float* bias, int n
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH);
     const bool xf = in_scale != nullptr;
     if constexpr (sizeof(T) == 2) {
-        if (use_ws(Cin, CoutP, WM_BF16)) {
+        if (use_ws(Cin, CoutP, wm_dtype<T>::id)) {
             const int ntiles = B * a.tilesX * a.tilesY;
             const int per = ws_tiles_per_wg(ntiles);
-            return wm_launch_conv3x3_ws(x, ldx, Cin, CoutP, wp, bias, nbias, in_scale, in_shift, y, stat, B, H, W, ws_wgs(ntiles), per, s, reverse);
+            return wm_launch_conv3x3_ws(wm_dtype<T>::id, x, ldx, Cin, CoutP, wp, bias, nbias, in_scale, in_shift, y, stat, B, H, W, ws_wgs(ntiles), per, s, reverse);
         }
     }
     if constexpr (sizeof(T) == 2) {
-        if (use_stream(Cin, CoutP, WM_BF16))
-            return wm_launch_conv3x3_stream(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat, B, H, W, Cin, CoutP, s);
+        if (use_stream(Cin, CoutP, wm_dtype<T>::id))
+            return (wm_dtype<T>::id == WM_F16 ? wm_launch_conv3x3_stream_f16 : wm_launch_conv3x3_stream_bf16)(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat, B, H, W, Cin, CoutP, s);
     }
     const int BN = (CoutP % 64 == 0) ? 64 : 32;
     dim3 grid((unsigned)(B * a.tilesX * a.tilesY), (unsigned)(CoutP / BN)), block(256);
@@ -368,9 +380,9 @@ extern "C" int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const floa
     WM_REQUIRE(x && wp && y, WM_E_BADARG, "wm_conv3x3_fwd: null pointer");
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && CoutP > 0, WM_E_BADARG, "wm_conv3x3_fwd: bad shape");
     WM_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), WM_E_BADARG, "wm_conv3x3_fwd: in_scale/in_shift must come together");
-    WM_REQUIRE(dtype == WM_F32 || dtype == WM_BF16, WM_E_BADARG, "wm_conv3x3_fwd: unsupported dtype %d", dtype);
-    const int esz = dtype == WM_BF16 ? 2 : 4;
-    const int cmul = dtype == WM_BF16 ? 16 : 4;
+    WM_REQUIRE(dtype == WM_F32 || is16(dtype), WM_E_BADARG, "wm_conv3x3_fwd: unsupported dtype %d", dtype);
+    const int esz = is16(dtype) ? 2 : 4;
+    const int cmul = is16(dtype) ? 16 : 4;
     WM_REQUIRE(Cin % cmul == 0, WM_E_SHAPE, "wm_conv3x3_fwd: Cin=%d must be a multiple of %d (pad the channels)", Cin, cmul);
     WM_REQUIRE(CoutP % 32 == 0, WM_E_SHAPE, "wm_conv3x3_fwd: CoutP=%d must be a multiple of 32", CoutP);
     WM_REQUIRE(ldx >= Cin && ldy >= CoutP && (ldx * esz) % 16 == 0 && (ldy * esz) % 16 == 0, WM_E_SHAPE,
@@ -380,6 +392,7 @@ extern "C" int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const floa
                "wm_conv3x3_fwd: the persistent bf16 path writes a dense output (ldy must equal CoutP=%d, got %d)", CoutP, ldy);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == WM_BF16) launch_conv<bf16_t>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s, sweep_reverse ? 1 : 0);
+    else if (dtype == WM_F16) launch_conv<f16_t>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s, sweep_reverse ? 1 : 0);
     else launch_conv<float>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s, 0);
     WM_LAUNCH_CHECK("wm_conv3x3_fwd");
     return WM_OK;
@@ -391,12 +404,12 @@ extern "C" int wm_conv3x3_dgrad_gvfused(const void* y, int ldy, int CoutY, const
                                         const float* coef, void* dx, int B, int H, int W, int CinP, int dtype, void* stream) {
     WM_REQUIRE(y && wpt && gvec && stats4 && coef && dx, WM_E_BADARG, "wm_conv3x3_dgrad_gvfused: null pointer");
     WM_REQUIRE(B > 0 && H > 0 && W > 0, WM_E_BADARG, "wm_conv3x3_dgrad_gvfused: bad shape");
-    WM_REQUIRE(dtype == WM_BF16 && (CoutY == 64 || CoutY == 32) && CinP == 64 && use_ws(CoutY, CinP, dtype), WM_E_SHAPE,
+    WM_REQUIRE(is16(dtype) && (CoutY == 64 || CoutY == 32) && CinP == 64 && use_ws(CoutY, CinP, dtype), WM_E_SHAPE,
                "wm_conv3x3_dgrad_gvfused: unsupported shape CoutY=%d CinP=%d dtype=%d", CoutY, CinP, dtype);
     WM_REQUIRE(ldy >= CoutY && ldy % 8 == 0 && (((uintptr_t)y | (uintptr_t)wpt | (uintptr_t)dx) & 15) == 0, WM_E_SHAPE,
                "wm_conv3x3_dgrad_gvfused: bad stride / alignment");
     const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
-    const int rc = wm_launch_conv3x3_ws(y, ldy, CoutY, CinP, wpt, nullptr, 0, nullptr, nullptr, dx, nullptr, B, H, W, ws_wgs(ntiles),
+    const int rc = wm_launch_conv3x3_ws(dtype, y, ldy, CoutY, CinP, wpt, nullptr, 0, nullptr, nullptr, dx, nullptr, B, H, W, ws_wgs(ntiles),
                                         ws_tiles_per_wg(ntiles), (hipStream_t)stream, 0, stats4, CoutY, coef, gvec);
     WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_dgrad_gvfused: no kernel for this shape");
     WM_LAUNCH_CHECK("wm_conv3x3_dgrad_gvfused");
@@ -408,7 +421,7 @@ extern "C" int wm_conv3x3_dgrad_gvfused(const void* y, int ldy, int CoutY, const
 WM_KNOB_ON(g_bwdst, "WM_NO_BWDST");
 WM_KNOB_SETTER(wm_debug_bwdst, g_bwdst)   // A/B knob (tools/ab_step.py, debug build only)
 extern "C" int wm_conv3x3_dgrad_bwdstats_supported(int CoutY, int CinP, int dtype) {
-    return (g_bwdst && dtype == WM_BF16 && (CoutY == 64 || CoutY == 32) && CinP == 64 && use_ws(CoutY, CinP, dtype)) ? 1 : 0;
+    return (g_bwdst && is16(dtype) && (CoutY == 64 || CoutY == 32) && CinP == 64 && use_ws(CoutY, CinP, dtype)) ? 1 : 0;
 }
 extern "C" int wm_conv3x3_dgrad_bwdstats(const void* src, int lds, int CoutY, const void* wpt, const float* gvec, const float* stats4,
                                          const float* coef, const void* ry, const float* r_scale, const float* r_shift, void* dx,
@@ -422,7 +435,7 @@ extern "C" int wm_conv3x3_dgrad_bwdstats(const void* src, int lds, int CoutY, co
     WM_REQUIRE(lds >= CoutY && lds % 8 == 0 && (((uintptr_t)src | (uintptr_t)wpt | (uintptr_t)dx | (uintptr_t)ry) & 15) == 0, WM_E_SHAPE,
                "wm_conv3x3_dgrad_bwdstats: bad stride / alignment");
     const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
-    const int rc = wm_launch_conv3x3_ws(src, lds, CoutY, CinP, wpt, nullptr, 0, nullptr, nullptr, dx, partials, B, H, W, ws_wgs(ntiles),
+    const int rc = wm_launch_conv3x3_ws(dtype, src, lds, CoutY, CinP, wpt, nullptr, 0, nullptr, nullptr, dx, partials, B, H, W, ws_wgs(ntiles),
                                         ws_tiles_per_wg(ntiles), (hipStream_t)stream, sweep_reverse ? 1 : 0, stats4, CoutY, coef, gvec, ry, r_scale, r_shift);
     WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_dgrad_bwdstats: no kernel for this shape");
     WM_LAUNCH_CHECK("wm_conv3x3_dgrad_bwdstats");
@@ -434,7 +447,7 @@ extern "C" int wm_conv3x3_dgrad_bwdstats(const void* src, int lds, int CoutY, co
 WM_KNOB_ON(g_applyfuse, "WM_NO_APPLY_FUSE");
 WM_KNOB_SETTER(wm_debug_apply_fuse, g_applyfuse)   // A/B knob (tools/ab_step.py, debug build only)
 extern "C" int wm_conv3x3_dgrad_applyfused_supported(int CoutY, int CinP, int dtype) {
-    return (g_applyfuse && dtype == WM_BF16 && CoutY == 64 && (CinP == 64 || CinP == 32) && use_ws(CoutY, CinP, dtype)) ? 1 : 0;
+    return (g_applyfuse && is16(dtype) && CoutY == 64 && (CinP == 64 || CinP == 32) && use_ws(CoutY, CinP, dtype)) ? 1 : 0;
 }
 extern "C" int wm_conv3x3_dgrad_applyfused(const void* g, const void* y, const float* stats4, const float* coef, const void* wpt,
                                            void* dy_out, void* dx, const void* ry, const float* r_scale, const float* r_shift,
@@ -448,7 +461,7 @@ extern "C" int wm_conv3x3_dgrad_applyfused(const void* g, const void* y, const f
     WM_REQUIRE((((uintptr_t)g | (uintptr_t)y | (uintptr_t)wpt | (uintptr_t)dy_out | (uintptr_t)dx | (uintptr_t)ry) & 15) == 0, WM_E_SHAPE,
                "wm_conv3x3_dgrad_applyfused: pointers must be 16-byte aligned");
     const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
-    const int rc = wm_launch_conv3x3_ws(g, 64, 64, CinP, wpt, nullptr, 0, nullptr, nullptr, dx, partials, B, H, W, ws_wgs(ntiles),
+    const int rc = wm_launch_conv3x3_ws(dtype, g, 64, 64, CinP, wpt, nullptr, 0, nullptr, nullptr, dx, partials, B, H, W, ws_wgs(ntiles),
                                         ws_tiles_per_wg(ntiles), (hipStream_t)stream, sweep_reverse ? 1 : 0, stats4, 64, coef, nullptr, ry, r_scale, r_shift, y, dy_out);
     WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_dgrad_applyfused: no kernel for this shape");
     WM_LAUNCH_CHECK("wm_conv3x3_dgrad_applyfused");
@@ -473,6 +486,8 @@ extern "C" int wm_pack_w3x3(const float* w, void* wp, int Cout, int Cin, int Cou
     hipStream_t s = (hipStream_t)stream;
     if (dtype == WM_BF16)
         hipLaunchKernelGGL(pack_w3x3_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, (bf16_t*)wp, Cout, Cin, CoutP, CinP, transpose, pa, perm ? 1 : 0);
+    else if (dtype == WM_F16)
+        hipLaunchKernelGGL(pack_w3x3_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, w, (f16_t*)wp, Cout, Cin, CoutP, CinP, transpose, pa, perm ? 1 : 0);
     else if (dtype == WM_F32)
         hipLaunchKernelGGL(pack_w3x3_kernel<float>, dim3(blocks), dim3(256), 0, s, w, (float*)wp, Cout, Cin, CoutP, CinP, transpose, pa, perm ? 1 : 0);
     else { wm_set_error("wm_pack_w3x3: unsupported dtype %d", dtype); return WM_E_BADARG; }
@@ -488,6 +503,7 @@ extern "C" int wm_pack_w3x3_batch(const void* jobs_dev, int njobs, size_t max_el
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks, (unsigned)njobs);
     if (dtype == WM_BF16) hipLaunchKernelGGL(pack_w3x3_batch_kernel<bf16_t>, grid, dim3(256), 0, s, (const PackJob*)jobs_dev);
+    else if (dtype == WM_F16) hipLaunchKernelGGL(pack_w3x3_batch_kernel<f16_t>, grid, dim3(256), 0, s, (const PackJob*)jobs_dev);
     else if (dtype == WM_F32) hipLaunchKernelGGL(pack_w3x3_batch_kernel<float>, grid, dim3(256), 0, s, (const PackJob*)jobs_dev);
     else { wm_set_error("wm_pack_w3x3_batch: unsupported dtype %d", dtype); return WM_E_BADARG; }
     WM_LAUNCH_CHECK("wm_pack_w3x3_batch");

@@ -11,6 +11,19 @@
 #include <stdlib.h>
 #include "wm_common.h"
 
+// This file is compiled twice (build.py): plain for bf16 (production), and with -DWM_H16_F16 for the f16 twin of every kernel in
+// it (the reference's autocast dtype, BASELINE config C5).  Everything that depends on the 16-bit layout goes through h16<> (wm_common.h).
+#ifdef WM_H16_F16
+typedef f16_t hx_t;
+#define WM_HSYM(name) name##_f16
+#else
+typedef bf16_t hx_t;
+#define WM_HSYM(name) name##_bf16
+#endif
+typedef h16<hx_t> HX;
+typedef HX::x8 hx8;
+typedef HX::x2 hx2;
+
 namespace {
 
 constexpr int TH = 16, TW = 16, HH = 18, HW = 18, NPIX = HH * HW;
@@ -22,15 +35,14 @@ constexpr int XV = (NPIX * 4 + 255) / 256;   // halo vectors per producer thread
 constexpr int WV = 9 * NT * 4 / 256;         // filter vectors per producer thread (9)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 struct StArgs {
-    const bf16_t* x; int ldx;
-    const bf16_t* wp;            // [9][CoutP][Cin]
+    const hx_t* x; int ldx;
+    const hx_t* wp;            // [9][CoutP][Cin]
     const float* bias; int nbias;
     const float* in_scale; const float* in_shift;
-    bf16_t* y; int ldy;
+    hx_t* y; int ldy;
     float* stat;                 // [4 * ntiles][2][CoutP] or null: one partial row per (pixel tile, consumer wave)
     int B, H, W, Cin, CoutP, tilesX, tilesY, ntiles, nct, nitems, items_per_wg;
 };
@@ -68,35 +80,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StArgs a) {
         // ================================================================== PRODUCER waves
         const int ptid = tid - 256;
         const int vec = ptid & 3;                        // 16-byte vector (8 channels) inside the chunk
-        bf16x8 xA[XV], xB_[XV], wA[WV], wB_[WV];
+        hx8 xA[XV], xB_[XV], wA[WV], wB_[WV];
         unsigned okA = 0, okB = 0;
-        auto load_chunk = [&](int s, bf16x8 (&xd)[XV], bf16x8 (&wd)[WV], unsigned& okbits) {
+        auto load_chunk = [&](int s, hx8 (&xd)[XV], hx8 (&wd)[WV], unsigned& okbits) {
             const int it = i_begin + s / nch, c = s - (s / nch) * nch;
             const Item g = item_of(it);
             const int cb = c * CK + vec * 8;
             const bool cok = cb < a.Cin;
             const int cl = cok ? cb : 0;
             okbits = 0;
-            const bf16_t* xb = a.x + (size_t)g.b * a.H * a.W * a.ldx + cl;
+            const hx_t* xb = a.x + (size_t)g.b * a.H * a.W * a.ldx + cl;
 #pragma unroll
             for (int k = 0; k < XV; ++k) {
                 const int pix = min((ptid + 256 * k) >> 2, NPIX - 1);
                 const int py = pix / HW, px = pix - py * HW;
                 const int gy = g.ty0 - 1 + py, gx = g.tx0 - 1 + px;
                 const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
-                xd[k] = *reinterpret_cast<const bf16x8*>(xb + (size_t)(gyc * a.W + gxc) * a.ldx);
+                xd[k] = *reinterpret_cast<const hx8*>(xb + (size_t)(gyc * a.W + gxc) * a.ldx);
                 okbits |= ((cok && gy == gyc && gx == gxc) ? 1u : 0u) << k;
             }
-            const bf16_t* wb = a.wp + (size_t)g.n0 * a.Cin + cl;
+            const hx_t* wb = a.wp + (size_t)g.n0 * a.Cin + cl;
 #pragma unroll
             for (int k = 0; k < WV; ++k) {
                 const int row = (ptid + 256 * k) >> 2;   // tap * 64 + n
                 const int tap = row >> 6, n = row & 63;
-                wd[k] = *reinterpret_cast<const bf16x8*>(wb + ((size_t)tap * a.CoutP + n) * a.Cin);
+                wd[k] = *reinterpret_cast<const hx8*>(wb + ((size_t)tap * a.CoutP + n) * a.Cin);
             }
             if (cok) okbits |= 0x80000000u;              // the filter vectors of this thread are real channels
         };
-        auto put_chunk = [&](int s, const bf16x8 (&xd)[XV], const bf16x8 (&wd)[WV], unsigned okbits) {
+        auto put_chunk = [&](int s, const hx8 (&xd)[XV], const hx8 (&wd)[WV], unsigned okbits) {
             unsigned char* bx = smem + (s & 1) * (XB + WB);
             unsigned char* bw = bx + XB;
             float sc[8], sh[8];
@@ -113,9 +125,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StArgs a) {
                 if (XFORM) {
 #pragma unroll
                     for (int pq = 0; pq < 4; ++pq) {
-                        const float f0 = __builtin_fmaf(__builtin_bit_cast(float, w[pq] << 16), sc[2 * pq], sh[2 * pq]);
-                        const float f1 = __builtin_fmaf(__builtin_bit_cast(float, w[pq] & 0xffff0000u), sc[2 * pq + 1], sh[2 * pq + 1]);
-                        const bf16x2 pk = {(bf16_t)f0, (bf16_t)f1};
+                        const float f0 = __builtin_fmaf(HX::lo(w[pq]), sc[2 * pq], sh[2 * pq]);
+                        const float f1 = __builtin_fmaf(HX::hi(w[pq]), sc[2 * pq + 1], sh[2 * pq + 1]);
+                        const hx2 pk = {(hx_t)f0, (hx_t)f1};
                         const i16x2 z = {0, 0};
                         w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
                     }
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StArgs a) {
         if (nstream > 0) put_chunk(0, xA, wA, okA);
         __syncthreads();
         // iteration s: the consumers compute chunk s; fetch chunk s+2, publish chunk s+1
-        auto iter = [&](int s, bf16x8 (&xn)[XV], bf16x8 (&wn)[WV], unsigned& okn, const bf16x8 (&xc)[XV], const bf16x8 (&wc)[WV], unsigned okc) {
+        auto iter = [&](int s, hx8 (&xn)[XV], hx8 (&wn)[WV], unsigned& okn, const hx8 (&xc)[XV], const hx8 (&wc)[WV], unsigned okc) {
             if (s + 2 < nstream) load_chunk(s + 2, xn, wn, okn);
             if (s + 1 < nstream) put_chunk(s + 1, xc, wc, okc);
             __syncthreads();
@@ -177,16 +189,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StArgs a) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int kh = tap / 3, kw = tap - kh * 3;
-                bf16x8 pix[4], fil[4];
+                hx8 pix[4], fil[4];
 #pragma unroll
-                for (int mf = 0; mf < 4; ++mf) pix[mf] = *reinterpret_cast<const bf16x8*>(bx + aoff[kw] + (mf + kh) * (HW * 64));
+                for (int mf = 0; mf < 4; ++mf) pix[mf] = *reinterpret_cast<const hx8*>(bx + aoff[kw] + (mf + kh) * (HW * 64));
 #pragma unroll
-                for (int nf = 0; nf < 4; ++nf) fil[nf] = *reinterpret_cast<const bf16x8*>(bw + boff + (tap * 64 + nf * 16) * 64);
+                for (int nf = 0; nf < 4; ++nf) fil[nf] = *reinterpret_cast<const hx8*>(bw + boff + (tap * 64 + nf * 16) * 64);
 #pragma unroll
                 for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
                     for (int nf = 0; nf < 4; ++nf)
-                        acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fil[nf], pix[mf], acc[mf][nf], 0, 0, 0);
+                        acc[mf][nf] = HX::mfma16(fil[nf], pix[mf], acc[mf][nf]);
             }
             __syncthreads();   // chunk s consumed, chunk s+1 published
         }
@@ -214,11 +226,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StArgs a) {
                     s2[2 * j] = __builtin_fmaf(t0, v0, s2[2 * j]);
                     s2[2 * j + 1] = __builtin_fmaf(t1, v1, s2[2 * j + 1]);
                 }
-                const bf16x2 p2 = {(bf16_t)v0, (bf16_t)v1};
+                const hx2 p2 = {(hx_t)v0, (hx_t)v1};
                 pk[j] = __builtin_bit_cast(unsigned, p2);
             }
             if (inb) {
-                bf16_t* yp = a.y + (((size_t)g.b * a.H + gy) * a.W + gx) * a.ldy + g.n0 + 16 * q;
+                hx_t* yp = a.y + (((size_t)g.b * a.H + gy) * a.W + gx) * a.ldy + g.n0 + 16 * q;
                 *reinterpret_cast<u32x4*>(yp) = u32x4{pk[0], pk[1], pk[2], pk[3]};
                 *reinterpret_cast<u32x4*>(yp + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
             }
@@ -241,15 +253,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StArgs a) {
 }  // namespace
 
 // launcher used by conv3x3.hip
+#ifndef WM_H16_F16
 int wm_conv3x3_stream_supported(int Cin, int CoutP) { return (Cin % 16 == 0 && Cin >= 32 && CoutP % 64 == 0) ? 1 : 0; }
 int wm_conv3x3_stream_nparts(int B, int H, int W) { return 4 * B * wm_cdiv(H, TH) * wm_cdiv(W, TW); }
+#endif
 
-int wm_launch_conv3x3_stream(const void* x, int ldx, const void* wp, const float* bias, int nbias, const float* in_scale,
+int WM_HSYM(wm_launch_conv3x3_stream)(const void* x, int ldx, const void* wp, const float* bias, int nbias, const float* in_scale,
                              const float* in_shift, void* y, int ldy, float* stat, int B, int H, int W, int Cin, int CoutP,
                              hipStream_t s) {
     StArgs a;
-    a.x = (const bf16_t*)x; a.ldx = ldx; a.wp = (const bf16_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
-    a.in_shift = in_shift; a.y = (bf16_t*)y; a.ldy = ldy; a.stat = stat; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.CoutP = CoutP;
+    a.x = (const hx_t*)x; a.ldx = ldx; a.wp = (const hx_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
+    a.in_shift = in_shift; a.y = (hx_t*)y; a.ldy = ldy; a.stat = stat; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.CoutP = CoutP;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
     a.nct = CoutP / NT; a.nitems = a.ntiles * a.nct;
     const int wgs_max = 256;

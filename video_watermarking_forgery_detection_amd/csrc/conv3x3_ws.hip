@@ -19,6 +19,19 @@
 #include <stdlib.h>
 #include "wm_common.h"
 
+// This file is compiled twice (build.py): plain for bf16 (production), and with -DWM_H16_F16 for the f16 twin of every kernel in
+// it (the reference's autocast dtype, BASELINE config C5).  Everything that depends on the 16-bit layout goes through h16<> (wm_common.h).
+#ifdef WM_H16_F16
+typedef f16_t hx_t;
+#define WM_HSYM(name) name##_f16
+#else
+typedef bf16_t hx_t;
+#define WM_HSYM(name) name##_bf16
+#endif
+typedef h16<hx_t> HX;
+typedef HX::x8 hx8;
+typedef HX::x2 hx2;
+
 namespace {
 
 constexpr int TH = 16, TW = 16, HH = 18, HW = 18;
@@ -26,18 +39,18 @@ constexpr int C64 = 64;
 constexpr int NPIX = HH * HW;                  // 324 halo pixels
 
 struct WsArgs {
-    const bf16_t* x; int ldx;
-    const bf16_t* wp;            // [9][64][64]
+    const hx_t* x; int ldx;
+    const hx_t* wp;            // [9][64][64]
     const float* bias; int nbias;
     const float* in_scale; const float* in_shift;
-    bf16_t* y;                   // dense [B,H,W,64]
+    hx_t* y;                   // dense [B,H,W,64]
     float* stat;                 // [gridDim.x][2][64] or null
     int B, H, W, tilesX, tilesY, ntiles, tiles_per_wg;
     int dbg;      // STAMPS build only: 1 = skip the MFMA loop, 2 = skip the stores, 4 = skip the halo loads
     int xcd_map;
     const float* bw_stats4; int bw_ld; const float* bw_coef; const float* bw_gvec;   // BNBWD: [scale|shift|mean|invstd][bw_ld], coef [3][bw_ld], gvec [B][bw_ld]
-    const bf16_t* ry; const float* r_scale; const float* r_shift;   // BWDST: raw output [B,H,W,COUT] and scale / shift of the layer whose output gradient this kernel writes
-    const bf16_t* ay; bf16_t* dy_out;   // BNBWD == 2: x is g [B,H,W,64]; ay the layer's raw output, dy_out where dy is written (both dense)
+    const hx_t* ry; const float* r_scale; const float* r_shift;   // BWDST: raw output [B,H,W,COUT] and scale / shift of the layer whose output gradient this kernel writes
+    const hx_t* ay; hx_t* dy_out;   // BNBWD == 2: x is g [B,H,W,64]; ay the layer's raw output, dy_out where dy is written (both dense)
     int reverse;  // walk the workgroup's run of tiles backwards (Infinity Cache reuse of the previous kernel's tail)
 };
 
@@ -51,7 +64,6 @@ template <int CIN> __device__ __forceinline__ int swz(int row, int slot) { retur
 template <int CIN> __device__ __forceinline__ int swz_px(int px, int slot) { return CIN == 64 ? slot ^ ((px >> 1) & 7) : slot; }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 
@@ -97,8 +109,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
     }
     constexpr int SW_BYTES = 9 * COUT * CIN * 2, SX_BYTES = NPIX * CIN * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SW_BYTES + 2 * SX_BYTES + 4 * 2 * C64 * 4 + C64 * 4];
-    bf16_t* sW = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* sX0 = reinterpret_cast<bf16_t*>(smem + SW_BYTES);  // two halo tiles back to back
+    hx_t* sW = reinterpret_cast<hx_t*>(smem);
+    hx_t* sX0 = reinterpret_cast<hx_t*>(smem + SW_BYTES);  // two halo tiles back to back
     float* sRed = reinterpret_cast<float*>(smem + SW_BYTES + 2 * SX_BYTES);
     float* sBias = sRed + 4 * 2 * C64;   // the accumulators start from the bias
 
@@ -114,11 +126,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
     // The loads are issued here; the LDS stores (commit_filter) come after the producers have issued their first tile loads,
     // so the filter's trip from L2 and the first halo tiles' trip from HBM overlap at the start of every launch.
     constexpr int NV = 9 * COUT * VPP, WV = (NV + 511) / 512;
-    bf16x8 wv[WV];
+    hx8 wv[WV];
 #pragma unroll
     for (int k = 0; k < WV; ++k) {
         const int i = min(tid + 512 * k, NV - 1);
-        wv[k] = *reinterpret_cast<const bf16x8*>(a.wp + (size_t)(i / VPP) * CIN + (i % VPP) * 8);
+        wv[k] = *reinterpret_cast<const hx8*>(a.wp + (size_t)(i / VPP) * CIN + (i % VPP) * 8);
     }
     auto commit_filter = [&]() {
 #pragma unroll
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             // adjacent channels
             constexpr int CPL = COUT / 4, NFR = COUT / 16;
             const int lrow = M16 ? tap * COUT + ((n >> 2) % NFR) * 16 + 4 * (n / CPL) + (n & 3) : tap * COUT + (n >> 5) * 32 + rho;
-            if (i < NV) *reinterpret_cast<bf16x8*>(sW + lrow * CIN + swz<CIN>(lrow, i % VPP) * 8) = wv[k];
+            if (i < NV) *reinterpret_cast<hx8*>(sW + lrow * CIN + swz<CIN>(lrow, i % VPP) * 8) = wv[k];
         }
     };
     const bool early_filter = (a.dbg & 128) != 0;   // A/B knob (variant 10): the filter committed before anything else is issued
@@ -225,19 +237,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         auto is_interior = [&](const TileGeo& g) {
             return g.ty0 >= 1 && g.ty0 + TH + 1 <= a.H && g.tx0 >= 1 && g.tx0 + TW + 1 <= a.W;
         };
-        auto load_interior = [&](const bf16_t* xt, int k, bf16x8& d) { d = *reinterpret_cast<const bf16x8*>(xt + rel[k]); };
-        auto load_border = [&](const TileGeo& g, const bf16_t* xb, int k, bf16x8& d, unsigned& okbits) {
+        auto load_interior = [&](const hx_t* xt, int k, hx8& d) { d = *reinterpret_cast<const hx8*>(xt + rel[k]); };
+        auto load_border = [&](const TileGeo& g, const hx_t* xb, int k, hx8& d, unsigned& okbits) {
             const int gy = g.ty0 - 1 + hpy[k], gx = g.tx0 - 1 + hpx[k];
             const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
-            d = *reinterpret_cast<const bf16x8*>(xb + (gyc * a.W + gxc) * a.ldx + vec * 8);
+            d = *reinterpret_cast<const hx8*>(xb + (gyc * a.W + gxc) * a.ldx + vec * 8);
             okbits |= ((gy == gyc && gx == gxc) ? 1u : 0u) << k;
         };
         auto tile_ptr = [&](const TileGeo& g) { return a.x + ((size_t)(g.b * a.H + g.ty0 - 1) * a.W + (g.tx0 - 1)) * a.ldx; };
         auto image_ptr = [&](const TileGeo& g) { return a.x + (size_t)g.b * a.H * a.W * a.ldx; };
-        auto load_tile = [&](const TileGeo& g, bf16x8 (&d)[XVP], unsigned& okbits, bool reuse) {
+        auto load_tile = [&](const TileGeo& g, hx8 (&d)[XVP], unsigned& okbits, bool reuse) {
             if (STAMPS && (a.dbg & 4)) { okbits = 0xffffffffu; return; }
             if (is_interior(g)) {
-                const bf16_t* xt = tile_ptr(g);
+                const hx_t* xt = tile_ptr(g);
 #pragma unroll
                 for (int k = 0; k < KMAIN; ++k) load_interior(xt, k, d[k]);
                 if (!reuse) {
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 }
                 okbits = 0xffffffffu;
             } else {
-                const bf16_t* xb = image_ptr(g);
+                const hx_t* xb = image_ptr(g);
                 okbits = 0;
 #pragma unroll
                 for (int k = 0; k < KMAIN; ++k) load_border(g, xb, k, d[k], okbits);
@@ -257,21 +269,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             }
         };
         // edge vector k of the tile being published <- columns 16..17 of the tile in the other buffer
-        auto copy_edge = [&](bf16_t* sX, const bf16_t* sPrev, int k) {
+        auto copy_edge = [&](hx_t* sX, const hx_t* sPrev, int k) {
             const int px = hpx[k] + (a.reverse ? -16 : 16);
             const u32x4 w = *reinterpret_cast<const u32x4*>(sPrev + (hpy[k] * HW + px) * CIN + swz_px<CIN>(px, vec) * 8);
             if (k + 1 < XVP || last_live) *reinterpret_cast<u32x4*>(sX + lds[k]) = w;
         };
         // fused BN + ReLU (ReLU on the packed bf16 pair as a signed 16-bit max), zero padding AFTER the activation
-        auto put_one = [&](bf16_t* sX, int k, const bf16x8& d, unsigned okbits) {
+        auto put_one = [&](hx_t* sX, int k, const hx8& d, unsigned okbits) {
             u32x4 w = __builtin_bit_cast(u32x4, d);
             if (XFORM) {
 #pragma unroll
                 for (int pq = 0; pq < 4; ++pq) {
                     // scalar v_fma_f32 on purpose: packed f32 VALU beside the partner wave's MFMAs costs far more than two scalar ops
-                    const float f0 = __builtin_fmaf(__builtin_bit_cast(float, w[pq] << 16), sc2[pq][0], sh2[pq][0]);
-                    const float f1 = __builtin_fmaf(__builtin_bit_cast(float, w[pq] & 0xffff0000u), sc2[pq][1], sh2[pq][1]);
-                    const bf16x2 pk = {(bf16_t)f0, (bf16_t)f1};
+                    const float f0 = __builtin_fmaf(HX::lo(w[pq]), sc2[pq][0], sh2[pq][0]);
+                    const float f1 = __builtin_fmaf(HX::hi(w[pq]), sc2[pq][1], sh2[pq][1]);
+                    const hx2 pk = {(hx_t)f0, (hx_t)f1};
                     const i16x2 z = {0, 0};
                     w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
                 }
@@ -279,10 +291,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             if (BNBWD == 1) {
 #pragma unroll
                 for (int pq = 0; pq < 4; ++pq) {
-                    const float d0 = wm_bn_fold_dy(__builtin_bit_cast(float, w[pq] << 16), kb[0][2 * pq], kb[1][2 * pq], kb[2][2 * pq], kb[3][2 * pq], k3g[2 * pq]);
-                    const float d1 = wm_bn_fold_dy(__builtin_bit_cast(float, w[pq] & 0xffff0000u), kb[0][2 * pq + 1], kb[1][2 * pq + 1], kb[2][2 * pq + 1],
+                    const float d0 = wm_bn_fold_dy(HX::lo(w[pq]), kb[0][2 * pq], kb[1][2 * pq], kb[2][2 * pq], kb[3][2 * pq], k3g[2 * pq]);
+                    const float d1 = wm_bn_fold_dy(HX::hi(w[pq]), kb[0][2 * pq + 1], kb[1][2 * pq + 1], kb[2][2 * pq + 1],
                                                    kb[3][2 * pq + 1], k3g[2 * pq + 1]);
-                    const bf16x2 pk = {(bf16_t)d0, (bf16_t)d1};
+                    const hx2 pk = {(hx_t)d0, (hx_t)d1};
                     w[pq] = __builtin_bit_cast(unsigned, pk);
                 }
             }
@@ -297,25 +309,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
 #pragma unroll
             for (int k = 0; k < XVP; ++k)
                 if (hpy[k] >= 1 && hpy[k] <= TH && hpx[k] >= 1 && hpx[k] <= TW && (k + 1 < XVP || last_live)) wmask |= 1u << k;
-            bf16x8 dG[XVP], dY[XVP];
+            hx8 dG[XVP], dY[XVP];
             unsigned ok = 0;
             auto load_both = [&](const TileGeo& g) {
                 if (is_interior(g)) {
-                    const bf16_t* gt = tile_ptr(g);
-                    const bf16_t* yt = a.ay + (gt - a.x);
+                    const hx_t* gt = tile_ptr(g);
+                    const hx_t* yt = a.ay + (gt - a.x);
 #pragma unroll
                     for (int k = 0; k < XVP; ++k) { load_interior(gt, k, dG[k]); load_interior(yt, k, dY[k]); }
                     ok = 0xffffffffu;
                 } else {
-                    const bf16_t* gb = image_ptr(g);
-                    const bf16_t* yb = a.ay + (gb - a.x);
+                    const hx_t* gb = image_ptr(g);
+                    const hx_t* yb = a.ay + (gb - a.x);
                     unsigned unused = 0;
                     ok = 0;
 #pragma unroll
                     for (int k = 0; k < XVP; ++k) { load_border(g, gb, k, dG[k], ok); load_border(g, yb, k, dY[k], unused); }
                 }
             };
-            auto put_both = [&](bf16_t* sX, const TileGeo& g) {
+            auto put_both = [&](hx_t* sX, const TileGeo& g) {
                 const long tofs = ((long)(g.b * a.H + g.ty0 - 1) * a.W + (g.tx0 - 1)) * CIN;   // + rel[k] (ldx == CIN): the pixel's offset
 #pragma unroll
                 for (int k = 0; k < XVP; ++k) {
@@ -323,11 +335,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                     const u32x4 wy = __builtin_bit_cast(u32x4, dY[k]);
 #pragma unroll
                     for (int pq = 0; pq < 4; ++pq) {
-                        const float d0 = wm_bn_fold_dyg(__builtin_bit_cast(float, wy[pq] << 16), __builtin_bit_cast(float, w[pq] << 16), kb[0][2 * pq],
+                        const float d0 = wm_bn_fold_dyg(HX::lo(wy[pq]), HX::lo(w[pq]), kb[0][2 * pq],
                                                         kb[1][2 * pq], kca[2 * pq], kb[2][2 * pq], kb[3][2 * pq]);
-                        const float d1 = wm_bn_fold_dyg(__builtin_bit_cast(float, wy[pq] & 0xffff0000u), __builtin_bit_cast(float, w[pq] & 0xffff0000u),
+                        const float d1 = wm_bn_fold_dyg(HX::hi(wy[pq]), HX::hi(w[pq]),
                                                         kb[0][2 * pq + 1], kb[1][2 * pq + 1], kca[2 * pq + 1], kb[2][2 * pq + 1], kb[3][2 * pq + 1]);
-                        const bf16x2 pk = {(bf16_t)d0, (bf16_t)d1};
+                        const hx2 pk = {(hx_t)d0, (hx_t)d1};
                         w[pq] = __builtin_bit_cast(unsigned, pk);
                     }
                     const unsigned inimg = (ok >> k) & 1u, keep = 0u - inimg;
@@ -356,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             if (STATS || BWDST) __syncthreads();
             return;
         }
-        bf16x8 dA[XVP], dB[XVP];
+        hx8 dA[XVP], dB[XVP];
         unsigned okA = 0, okB = 0;
         if (t_begin < t_end) load_tile(geo(t_begin), dA, okA, false);
         if (t_begin + 1 < t_end) load_tile(geo(t_begin + 1), dB, okB, reuse_of(t_begin + 1));
@@ -371,16 +383,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         // iteration `tile`: `cur` holds tile+1 (loaded one iteration ago) and is published (transform + LDS write) while
         // the loads of tile+2 go into `nxt`; one load, one vector of VALU work, alternating, so the memory queue is fed
         // at an even pace and never holds the whole burst
-        auto iter = [&](int tile, bf16x8 (&nxt)[XVP], unsigned& oknxt, const bf16x8 (&cur)[XVP], unsigned okcur) {
-            bf16_t* sXn = sX0 + (((tile - t_begin) & 1) ^ 1) * (NPIX * CIN);
-            const bf16_t* sXc = sX0 + ((tile - t_begin) & 1) * (NPIX * CIN);   // the tile the consumers are on: left neighbour of tile+1
+        auto iter = [&](int tile, hx8 (&nxt)[XVP], unsigned& oknxt, const hx8 (&cur)[XVP], unsigned okcur) {
+            hx_t* sXn = sX0 + (((tile - t_begin) & 1) ^ 1) * (NPIX * CIN);
+            const hx_t* sXc = sX0 + ((tile - t_begin) & 1) * (NPIX * CIN);   // the tile the consumers are on: left neighbour of tile+1
             const bool have_next = tile + 2 < t_end && !(STAMPS && (a.dbg & 4));
             const bool reuse_cur = reuse_of(tile + 1), reuse_nxt = reuse_of(tile + 2);
             if (BNBWD == 1 && tile + 1 < t_end) load_gvec(geo(tile + 1).b);
             if (have_next) {
                 const TileGeo g2 = geo(tile + 2);
                 if (is_interior(g2)) {
-                    const bf16_t* xt = tile_ptr(g2);
+                    const hx_t* xt = tile_ptr(g2);
                     oknxt = 0xffffffffu;
 #pragma unroll
                     for (int k = 0; k < KMAIN; ++k) {
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                         for (int k = KMAIN; k < XVP; ++k) load_interior(xt, k, nxt[k]);
                     }
                 } else {
-                    const bf16_t* xb = image_ptr(g2);
+                    const hx_t* xb = image_ptr(g2);
                     oknxt = 0;
 #pragma unroll
                     for (int k = 0; k < KMAIN; ++k) {
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
 
         f32x4 acc[4][NFR];   // [pixel fragment mf = tile row][channel fragment nf]
         static_assert(!BWDST || (!STATS && COUT == 64), "BWDST: 64-channel dgrads");
-        struct Drain { bf16_t* yp; float mk; bool inb; };
+        struct Drain { hx_t* yp; float mk; bool inb; };
         float rsc[CPL], rsh[CPL];
         if (BWDST) {
 #pragma unroll
@@ -481,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             if (BWDST) {
 #pragma unroll
                 for (int ml = 0; ml < 2; ++ml) {
-                    const bf16_t* src = a.ry + (d[ml].inb ? (d[ml].yp - a.y) : (ptrdiff_t)(CPL * q));
+                    const hx_t* src = a.ry + (d[ml].inb ? (d[ml].yp - a.y) : (ptrdiff_t)(CPL * q));
 #pragma unroll
                     for (int v = 0; v < NPAIR / 4; ++v) {
                         const u32x4 t = *reinterpret_cast<const u32x4*>(src + 8 * v);
@@ -514,12 +526,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                     // are pure arithmetic, the sched_barriers do not hold them), out of the matrix pipe's shadow
                     if (PIN) asm volatile("" : "+v"(s1[2 * j]), "+v"(s1[2 * j + 1]), "+v"(s2[2 * j]), "+v"(s2[2 * j + 1]));
                 }
-                const bf16x2 p2 = {(bf16_t)v0, (bf16_t)v1};
+                const hx2 p2 = {(hx_t)v0, (hx_t)v1};
                 pk[j] = __builtin_bit_cast(unsigned, p2);
                 if (BWDST) {   // scalar f32, as above
                     const unsigned gm = d[ml].inb ? pk[j] : 0u;
-                    const float g0 = __builtin_bit_cast(float, gm << 16), g1 = __builtin_bit_cast(float, gm & 0xffff0000u);
-                    const float y0 = __builtin_bit_cast(float, ryv[ml][j] << 16), y1 = __builtin_bit_cast(float, ryv[ml][j] & 0xffff0000u);
+                    const float g0 = HX::lo(gm), g1 = HX::hi(gm);
+                    const float y0 = HX::lo(ryv[ml][j]), y1 = HX::hi(ryv[ml][j]);
                     const float z0 = __builtin_fmaf(rsc[2 * j], y0, rsh[2 * j]), z1 = __builtin_fmaf(rsc[2 * j + 1], y1, rsh[2 * j + 1]);
                     const float gz0 = z0 > 0.f ? g0 : 0.f, gz1 = z1 > 0.f ? g1 : 0.f;
                     s1[2 * j] += gz0; s1[2 * j + 1] += gz1;
@@ -534,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             }
         };
         // one pass over K for the tile rows {2*half, 2*half+1}; optionally drains half dh on the way
-        auto pass = [&](const bf16_t* sX, int half, bool drain, int dh, const Drain (&d)[2]) {
+        auto pass = [&](const hx_t* sX, int half, bool drain, int dh, const Drain (&d)[2]) {
 #pragma unroll
             for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
@@ -551,16 +563,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             constexpr int DS0 = BWDST ? 6 : 0;
             if (drain) load_ry(d);
             constexpr int PF = 2;   // a deeper ring measured the same
-            bf16x8 pix[PF][2], fil[PF][NFR];
+            hx8 pix[PF][2], fil[PF][NFR];
             auto load_frags = [&](int sidx, int buf) {
                 const int tap = sidx / KS2, ks = sidx % KS2;
                 const int kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
                 for (int ml = 0; ml < 2; ++ml)
-                    pix[buf][ml] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sX) + aoff[kw][ks] + (2 * half + ml + kh) * (HW * CIN * 2));
+                    pix[buf][ml] = *reinterpret_cast<const hx8*>(reinterpret_cast<const char*>(sX) + aoff[kw][ks] + (2 * half + ml + kh) * (HW * CIN * 2));
 #pragma unroll
                 for (int nf = 0; nf < NFR; ++nf)
-                    fil[buf][nf] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sW) + boff[ks] + (tap * COUT + nf * 16) * (CIN * 2));
+                    fil[buf][nf] = *reinterpret_cast<const hx8*>(reinterpret_cast<const char*>(sW) + boff[ks] + (tap * COUT + nf * 16) * (CIN * 2));
             };
 #pragma unroll
             for (int i = 0; i < PF - 1; ++i) load_frags(i, i);
@@ -573,7 +585,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
                     for (int nf = 0; nf < NFR; ++nf)
-                        acc[2 * half + ml][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fil[cb][nf], pix[cb][ml], acc[2 * half + ml][nf], 0, 0, 0);
+                        acc[2 * half + ml][nf] = HX::mfma16(fil[cb][nf], pix[cb][ml], acc[2 * half + ml][nf]);
                 if (drain) {
 #pragma unroll
                     for (int m = max(sidx - DS0, 0) * NDR / (NSTEP2 - DS0); m < max(sidx + 1 - DS0, 0) * NDR / (NSTEP2 - DS0); ++m) drain_step(m, dh, d);
@@ -590,7 +602,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             stamp(0);
             for (int tile = t_begin; tile < t_end; ++tile) {
                 const TileGeo g = geo(tile);
-                const bf16_t* sX = sX0 + ((tile - t_begin) & 1) * (NPIX * CIN);
+                const hx_t* sX = sX0 + ((tile - t_begin) & 1) * (NPIX * CIN);
                 const Drain d0[2] = {drain_of(g, 0), drain_of(g, 1)};
                 pass(sX, 1, true, 0, d0);
                 stamp(1);
@@ -654,7 +666,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
     for (int ks = 0; ks < KS; ++ks) boff[ks] = (r * CIN + swz<CIN>(r, ks * 2 + h) * 8) * 2;
 
     f32x16 acc[2][2];   // [pixel fragment mf][channel fragment nf]
-    struct Drain { bf16_t* yp; float mk; bool inb; };
+    struct Drain { hx_t* yp; float mk; bool inb; };
     auto drain_of = [&](const TileGeo& g, int mf) {
         Drain d;
         const int gy = g.ty0 + wave * 4 + mf * 2 + (r >> 4), gx = g.tx0 + (r & 15);
@@ -675,7 +687,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 s2[nf][j][0] = __builtin_fmaf(t0, v0, s2[nf][j][0]);
                 s2[nf][j][1] = __builtin_fmaf(t1, v1, s2[nf][j][1]);
             }
-            const bf16x2 p2 = {(bf16_t)v0, (bf16_t)v1};
+            const hx2 p2 = {(hx_t)v0, (hx_t)v1};
             pk[j] = __builtin_bit_cast(unsigned, p2);
         } else if (d.inb && !(STAMPS && (a.dbg & 2))) {
             *reinterpret_cast<u32x4*>(d.yp + nf * 32) = u32x4{pk[0], pk[1], pk[2], pk[3]};
@@ -683,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         }
     };
     // one pass over K for pixel fragment mf of the halo tile sX; optionally drains half dmf of `d` on the way
-    auto pass = [&](const bf16_t* sX, int mf, bool drain, int dmf, const Drain& d) {
+    auto pass = [&](const hx_t* sX, int mf, bool drain, int dmf, const Drain& d) {
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) acc[mf][nf] = *reinterpret_cast<const f32x16*>(sBias + nf * 32 + 16 * h);
         if (STAMPS && (a.dbg & 1)) {
@@ -694,14 +706,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             return;
         }
         constexpr int PF = STATS ? 2 : 3;   // fragment ring: fetched PF-1 steps ahead of use (the statistics take the registers)
-        bf16x8 af[PF], bfr[PF][2];
+        hx8 af[PF], bfr[PF][2];
         auto load_frags = [&](int sidx, int buf) {
             const int tap = sidx / KS, ks = sidx % KS;
             const int kh = tap / 3, kw = tap - kh * 3;
-            af[buf] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sX) + aoff[kw][ks] + (mf * 2 + kh) * (HW * CIN * 2));
+            af[buf] = *reinterpret_cast<const hx8*>(reinterpret_cast<const char*>(sX) + aoff[kw][ks] + (mf * 2 + kh) * (HW * CIN * 2));
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf)
-                bfr[buf][nf] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sW) + boff[ks] + (tap * C64 + nf * 32) * (CIN * 2));
+                bfr[buf][nf] = *reinterpret_cast<const hx8*>(reinterpret_cast<const char*>(sW) + boff[ks] + (tap * C64 + nf * 32) * (CIN * 2));
         };
 #pragma unroll
         for (int i = 0; i < PF - 1; ++i) load_frags(i, i);
@@ -712,7 +724,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             __builtin_amdgcn_sched_barrier(0);  // reads of later steps stay ahead of the MFMAs of step s
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf)
-                acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cb][nf], af[cb], acc[mf][nf], 0, 0, 0);
+                acc[mf][nf] = HX::mfma32(bfr[cb][nf], af[cb], acc[mf][nf]);
             if (drain) {   // the 18 drain micro-steps, spread evenly over the pass
 #pragma unroll
                 for (int m = sidx * 18 / NSTEP; m < (sidx + 1) * 18 / NSTEP; ++m) drain_step(m, dmf, d);
@@ -729,7 +741,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         stamp(0);
         for (int tile = t_begin; tile < t_end; ++tile) {
             const TileGeo g = geo(tile);
-            const bf16_t* sX = sX0 + ((tile - t_begin) & 1) * (NPIX * CIN);
+            const hx_t* sX = sX0 + ((tile - t_begin) & 1) * (NPIX * CIN);
             pass(sX, 1, true, 0, drain_of(g, 0));            // second half; drain the first
             stamp(1);
             __syncthreads();  // X[t&1] is free for the producers, X[(t+1)&1] is ready
@@ -780,15 +792,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
 
 }  // namespace
 
-#ifdef WM_DEBUG
+#if defined(WM_DEBUG) && !defined(WM_H16_F16)
 // diagnostic entry of the debug build (tools/phase_ws.py): stamps [wgs][16] u64 = consumer {mfma, epilogue, barrier, -, cycles, realtime} at +0,
 // producer {load issue, transform + LDS write, barrier, -, cycles, realtime} at +8
 extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const float* in_scale, const float* in_shift,
                                             void* y, float* stat, int B, int H, int W, unsigned long long* stamps, int dbg, void* stream) {
     WsArgs a;
     a.dbg = dbg; a.xcd_map = 1;
-    a.x = (const bf16_t*)x; a.ldx = 64; a.wp = (const bf16_t*)wp; a.bias = nullptr; a.nbias = 0; a.in_scale = in_scale;
-    a.in_shift = in_shift; a.y = (bf16_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
+    a.x = (const hx_t*)x; a.ldx = 64; a.wp = (const hx_t*)wp; a.bias = nullptr; a.nbias = 0; a.in_scale = in_scale;
+    a.in_shift = in_shift; a.y = (hx_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
     const int wgs = a.ntiles < 256 ? a.ntiles : 256;
     a.tiles_per_wg = wm_cdiv(a.ntiles, wgs); a.reverse = 0; a.bw_stats4 = nullptr; a.bw_ld = 0; a.bw_coef = nullptr; a.bw_gvec = nullptr; a.ry = nullptr; a.r_scale = nullptr; a.r_shift = nullptr; a.ay = nullptr; a.dy_out = nullptr;
@@ -803,28 +815,36 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
 // producer stopped finds the freshest part of that tensor in the Infinity Cache (256 MB; a layer's tensor is 134 MB): the host
 // alternates the direction along a chain of layers (engine.py).  Results do not depend on it except for the summation order
 // inside the per-workgroup statistics rows.  (A per-call argument: the library keeps no state between calls.)
+#ifndef WM_H16_F16
 WM_KNOB_INT(g_ws_reverse, "WM_WS_REVERSE", -1);   // debug build: -1 follow the caller (default), 0 / 1 force forward / backward sweeps
 WM_KNOB_SETTER(wm_debug_ws_direction, g_ws_reverse)
 int wm_sweep_dir(int reverse) { return (g_ws_reverse == 0 || g_ws_reverse == 1) ? g_ws_reverse : (reverse ? 1 : 0); }
+#else
+int wm_sweep_dir(int reverse);
+#endif
 // debug build A/B knobs -- 1: 32x32x16 MFMA consumers, 2: no XCD-aware run assignment, 3: producers at s_setprio 3, 8: no halo-edge reuse, 9: statistics sums not pinned, 10: filter committed to LDS before the first tile loads are issued
+#ifndef WM_H16_F16
 WM_KNOB_INT(g_ws_variant, "WM_WS_VARIANT", 0);
 WM_KNOB_SETTER(wm_debug_ws_variant, g_ws_variant)
+#else
+static constexpr int g_ws_variant = 0;
+#endif
 
 // launcher used by conv3x3.hip
-int wm_launch_conv3x3_ws(const void* x, int ldx, int Cin, int CoutP, const void* wp, const float* bias, int nbias, const float* in_scale,
+int WM_HSYM(wm_launch_conv3x3_ws)(const void* x, int ldx, int Cin, int CoutP, const void* wp, const float* bias, int nbias, const float* in_scale,
                            const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
                            hipStream_t s, int reverse, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
                            const float* bw_gvec = nullptr, const void* ry = nullptr, const float* r_scale = nullptr,
                            const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr) {
     WsArgs a;
     a.dbg = g_ws_variant == 3 ? 8 : (g_ws_variant == 8 ? 64 : (g_ws_variant == 10 ? 128 : 0)); a.xcd_map = g_ws_variant != 2;
-    a.x = (const bf16_t*)x; a.ldx = ldx; a.wp = (const bf16_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
-    a.in_shift = in_shift; a.y = (bf16_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
+    a.x = (const hx_t*)x; a.ldx = ldx; a.wp = (const hx_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
+    a.in_shift = in_shift; a.y = (hx_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY; a.tiles_per_wg = tiles_per_wg;
     a.reverse = wm_sweep_dir(reverse);
     a.bw_stats4 = bw_stats4; a.bw_ld = bw_ld; a.bw_coef = bw_coef; a.bw_gvec = bw_gvec;
-    a.ry = (const bf16_t*)ry; a.r_scale = r_scale; a.r_shift = r_shift;
-    a.ay = (const bf16_t*)ay; a.dy_out = (bf16_t*)dy_out;
+    a.ry = (const hx_t*)ry; a.r_scale = r_scale; a.r_shift = r_shift;
+    a.ay = (const hx_t*)ay; a.dy_out = (hx_t*)dy_out;
     const dim3 grid((unsigned)wgs), block(512);
     if (ay) {   // dgrad with the BatchNorm-backward apply (tensor gradient) fused; x = g, dy written out for the weight gradient
         if (Cin != 64 || (CoutP != 64 && CoutP != 32) || ldx != 64 || in_scale || !bw_stats4 || !bw_coef || bw_gvec || !dy_out ||

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ y, 
 }
 
 bool cin_ok(int Cin, int dtype) {
-    const int ve = dtype == WM_BF16 ? 8 : 4;
+    const int ve = dtype != WM_F32 ? 8 : 4;
     if (Cin <= 0 || Cin % ve) return false;
     const int vpp = Cin / ve;
     return vpp <= 64 && (vpp & (vpp - 1)) == 0;

@@ -154,7 +154,7 @@ extern "C" int wm_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int
                "wm_nchw_to_nhwc: bad shape (ld=%d c0=%d C=%d tail=%d)", ld, c0, C, zero_tail);
     const size_t hw = (size_t)H * W;
     hipStream_t s = (hipStream_t)stream;
-    const int esz = dtype == WM_BF16 ? 2 : 4;
+    const int esz = dtype != WM_F32 ? 2 : 4;
     const bool fast = C == 3 && c0 == 0 && zero_tail == 13 && (ld * esz) % 16 == 0 && ((uintptr_t)y & 15) == 0;
     WM_DISPATCH_DTYPE(dtype, "wm_nchw_to_nhwc",
         if (fast) hipLaunchKernelGGL((nchw3_to_nhwc16_kernel<T>), dim3(grid_for(B * hw)), dim3(256), 0, s, x, (T*)y, B, hw, ld);
@@ -190,7 +190,7 @@ extern "C" int wm_broadcast_to_nhwc(const float* v, void* y, int B, int L, int H
 extern "C" int wm_concat_tail(const float* msg, const float* img, void* y, int B, int L, int H, int W, int ld, int c0,
                               int tail, int dtype, void* stream) {
     WM_REQUIRE(msg && img && y, WM_E_BADARG, "wm_concat_tail: null pointer");
-    const int ve = dtype == WM_BF16 ? 8 : 4;
+    const int ve = dtype != WM_F32 ? 8 : 4;
     WM_REQUIRE(B > 0 && L > 0 && H > 0 && W > 0 && tail >= L + 3 && ld >= c0 + tail, WM_E_BADARG, "wm_concat_tail: bad shape");
     WM_REQUIRE(c0 % ve == 0 && tail % ve == 0 && ld % ve == 0, WM_E_SHAPE, "wm_concat_tail: c0=%d tail=%d ld=%d must be multiples of %d", c0, tail, ld, ve);
     const size_t hw = (size_t)H * W;
@@ -204,12 +204,12 @@ extern "C" int wm_concat_tail(const float* msg, const float* img, void* y, int B
 extern "C" int wm_concat_full(const void* x, int ldx, const float* scale, const float* shift, const float* msg, const float* img,
                               void* y, int B, int C, int L, int H, int W, int ld, int dtype, void* stream) {
     WM_REQUIRE(x && scale && shift && msg && img && y, WM_E_BADARG, "wm_concat_full: null pointer");
-    const int ve = dtype == WM_BF16 ? 8 : 4;
+    const int ve = dtype != WM_F32 ? 8 : 4;
     WM_REQUIRE(B > 0 && C > 0 && L > 0 && H > 0 && W > 0 && ld >= C + L + 3 && ldx >= C, WM_E_BADARG, "wm_concat_full: bad shape");
     WM_REQUIRE(C % ve == 0 && ld % ve == 0 && ldx % ve == 0, WM_E_SHAPE, "wm_concat_full: C=%d ld=%d ldx=%d must be multiples of %d", C, ld, ldx, ve);
     const size_t hw = (size_t)H * W;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)64 * ld * (dtype == WM_BF16 ? 2 : 4) + (size_t)2 * C * 4;
+    const size_t lds = (size_t)64 * ld * (dtype != WM_F32 ? 2 : 4) + (size_t)2 * C * 4;
     WM_REQUIRE(lds <= 64 * 1024, WM_E_SHAPE, "wm_concat_full: row of %d channels is too wide", ld);
     const size_t nb = ((size_t)B * hw + 63) / 64;
     const int grid = (int)(nb > 2048 ? 2048 : nb);

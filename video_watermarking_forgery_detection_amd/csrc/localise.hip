@@ -84,7 +84,9 @@ __global__ void psnr_gate_kernel(const double* __restrict__ partials, int nparts
 // grad = gscale * (sigmoid(p) - t) / n
 // chain != 0: p is itself a sigmoid output s(z) (the UNet head, UNet.py:65) and grad is taken wrt z: multiplied by p*(1-p)
 __global__ __launch_bounds__(256) void bce_target_kernel(const float* __restrict__ p, const float* __restrict__ t, size_t n, float gscale,
-                                                         float* __restrict__ partials, float* __restrict__ grad, int chain) {
+                                                         float* __restrict__ partials, float* __restrict__ grad, int chain,
+                                                         const float* __restrict__ gscale_dev) {
+    if (gscale_dev) gscale *= gscale_dev[0];
     float acc = 0.f;
     const float inv = 1.f / (float)n;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -157,8 +159,9 @@ __global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, s
 
 // grad = (gscale * gate[0]) * (a - b) with the gate a device scalar; partial sums of (a-b)^2 as wm_mse_fwd_bwd
 __global__ __launch_bounds__(256) void mse_gated_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ grad_a,
-                                                        float gscale, const float* __restrict__ gate, float* __restrict__ partials, size_t n) {
-    const float gs = gscale * gate[0];
+                                                        float gscale, const float* __restrict__ gate, float* __restrict__ partials, size_t n,
+                                                        const float* __restrict__ gscale_dev) {
+    const float gs = gscale * gate[0] * (gscale_dev ? gscale_dev[0] : 1.f);
     float acc = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float d = a[i] - b[i];
@@ -203,10 +206,10 @@ extern "C" int wm_psnr_gate(const double* psnr_partials, int nparts, double n, f
     return WM_OK;
 }
 
-extern "C" int wm_bce_logits_target(const float* p, const float* target, size_t n, float gscale, float* partials, int nparts, float* loss_out,
-                                    float* grad_out, int chain_sigmoid, void* stream) {
+extern "C" int wm_bce_logits_target(const float* p, const float* target, size_t n, float gscale, const float* gscale_dev, float* partials,
+                                    int nparts, float* loss_out, float* grad_out, int chain_sigmoid, void* stream) {
     WM_REQUIRE(p && target && partials && loss_out && n > 0 && nparts > 0 && nparts <= 2048, WM_E_BADARG, "wm_bce_logits_target: bad arguments");
-    hipLaunchKernelGGL(bce_target_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, p, target, n, gscale, partials, grad_out, chain_sigmoid);
+    hipLaunchKernelGGL(bce_target_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, p, target, n, gscale, partials, grad_out, chain_sigmoid, gscale_dev);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nparts, loss_out);
     WM_LAUNCH_CHECK("wm_bce_logits_target");
     return WM_OK;
@@ -244,11 +247,11 @@ extern "C" int wm_scale_dev(float* x, size_t n, const float* scale_dev, void* st
     return WM_OK;
 }
 
-extern "C" int wm_mse_fwd_bwd_gated(const float* a, const float* b, float* grad_a, float gscale, const float* gate_dev, float* loss_partials,
-                                    int nparts, size_t n, void* stream) {
+extern "C" int wm_mse_fwd_bwd_gated(const float* a, const float* b, float* grad_a, float gscale, const float* gate_dev, const float* gscale_dev,
+                                    float* loss_partials, int nparts, size_t n, void* stream) {
     WM_REQUIRE(a && b && grad_a && gate_dev && n > 0, WM_E_BADARG, "wm_mse_fwd_bwd_gated: bad arguments");
     WM_REQUIRE(nparts > 0 && nparts <= 2048, WM_E_BADARG, "wm_mse_fwd_bwd_gated: nparts must be in 1..2048");
-    hipLaunchKernelGGL(mse_gated_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, a, b, grad_a, gscale, gate_dev, loss_partials, n);
+    hipLaunchKernelGGL(mse_gated_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, a, b, grad_a, gscale, gate_dev, loss_partials, n, gscale_dev);
     WM_LAUNCH_CHECK("wm_mse_fwd_bwd_gated");
     return WM_OK;
 }

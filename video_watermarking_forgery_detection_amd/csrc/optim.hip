@@ -10,7 +10,8 @@ namespace {
 
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ grad_a, float gscale, float* __restrict__ partials,
-                                                  size_t n) {
+                                                  size_t n, const float* __restrict__ gscale_dev) {
+    if (gscale_dev) gscale *= gscale_dev[0];
     float acc = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float d = a[i] - b[i];
@@ -27,7 +28,9 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, c
 // nn.BCEWithLogitsLoss (mean) of a small logit vector against a constant label, value and gradient in one launch
 // (hidden_models/hidden.py:68-97: three of them per step on [B,1] tensors)
 __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ x, float target, int n, float gscale,
-                                                         float* __restrict__ loss_out, float* __restrict__ grad_out) {
+                                                         float* __restrict__ loss_out, float* __restrict__ grad_out,
+                                                         const float* __restrict__ gscale_dev) {
+    if (gscale_dev) gscale *= gscale_dev[0];
     float acc = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) {
         const float v = x[i];
@@ -44,7 +47,9 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
 // decoder message loss (hidden.py:96-99,109-111): out[0] = mean (d-m)^2, out[1] = sum |clip(round(d),0,1) - m| / n,
 // grad = (d-m) * gscale
 __global__ __launch_bounds__(256) void message_loss_kernel(const float* __restrict__ d, const float* __restrict__ m, int n,
-                                                           float gscale, float* __restrict__ out, float* __restrict__ grad) {
+                                                           float gscale, float* __restrict__ out, float* __restrict__ grad,
+                                                           const float* __restrict__ gscale_dev) {
+    if (gscale_dev) gscale *= gscale_dev[0];
     float a1 = 0.f, a2 = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) {
         const float df = d[i] - m[i];
@@ -100,6 +105,67 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// ---- torch.cuda.amp.GradScaler (models/IRNcrop_model.py:143,407-416) kept on the device.  state (f32[WM_AMP_STATE]):
+//   [0] scale  [1] growth tracker  [2] growth_factor  [3] backoff_factor  [4] growth_interval
+//   [8 + k] found_inf of optimiser k (k < 4)   [12 + k] step count of optimiser k (torch's `step`: not advanced by a skipped step)
+// found_inf[k] = !isfinite(sum of squares of optimiser k's gradients) -- the rows wm_sumsq wrote (shared with clip_grad_norm_)
+struct AmpGroups { const float* parts[4]; int n[4]; };
+__global__ void amp_found_inf_kernel(AmpGroups g, int ngroups, float* __restrict__ state, int k) {
+    __shared__ float s[256];
+    float a = 0.f;
+    for (int q = 0; q < ngroups; ++q)
+        for (int i = threadIdx.x; i < g.n[q]; i += 256) a += g.parts[q][i];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) state[8 + k] = isfinite(s[0]) ? 0.f : 1.f;
+}
+
+// GradScaler.update(): any found_inf -> scale *= backoff, tracker = 0; else tracker += 1 and at growth_interval scale *= growth.
+// Also advances the step count of every optimiser that did step, and clears the flags for the next iteration.
+__global__ void amp_update_kernel(float* __restrict__ state, int nopt) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    bool inf = false;
+    for (int k = 0; k < nopt; ++k) {
+        if (state[8 + k] != 0.f) inf = true;
+        else state[12 + k] += 1.f;
+        state[8 + k] = 0.f;
+    }
+    if (inf) { state[0] *= state[3]; state[1] = 0.f; }
+    else {
+        state[1] += 1.f;
+        if (state[1] >= state[4]) { state[0] *= state[2]; state[1] = 0.f; }
+    }
+}
+
+// Adam / AdamW under the scaler: the gradients in g are still multiplied by state[0]; skipped entirely when found_inf[k]
+__global__ __launch_bounds__(256) void adam_amp_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                                                       int decoupled, float grad_scale, const float* __restrict__ state, int k) {
+    if (state[8 + k] != 0.f) return;
+    const float t = state[12 + k] + 1.f;
+    const float bc1 = 1.f - powf(b1, t), bc2_sqrt = sqrtf(1.f - powf(b2, t));
+    const float step_size = lr / bc1;
+    const float gs = grad_scale / state[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float gg = g[i] * gs;
+        float pp = p[i];
+        if (wd != 0.f) {
+            if (decoupled) pp *= 1.f - lr * wd;
+            else gg += wd * pp;
+        }
+        const float mm = b1 * m[i] + (1.f - b1) * gg;
+        const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+        m[i] = mm;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[i] = pp - step_size * (mm / denom);
+    }
+}
+
 inline int grid_for(size_t n, int cap = 2048) {
     const size_t g = (n + 255) / 256;
     return (int)(g > (size_t)cap ? cap : (g < 1 ? 1 : g));
@@ -107,27 +173,27 @@ inline int grid_for(size_t n, int cap = 2048) {
 
 }  // namespace
 
-extern "C" int wm_mse_fwd_bwd(const float* a, const float* b, float* grad_a, float gscale, float* loss_partials,
+extern "C" int wm_mse_fwd_bwd(const float* a, const float* b, float* grad_a, float gscale, const float* gscale_dev, float* loss_partials,
                               int nparts, size_t n, void* stream) {
     WM_REQUIRE(a && b && n > 0, WM_E_BADARG, "wm_mse_fwd_bwd: bad arguments");
     WM_REQUIRE(nparts > 0 && nparts <= 2048, WM_E_BADARG, "wm_mse_fwd_bwd: nparts must be in 1..2048");
-    hipLaunchKernelGGL(mse_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, a, b, grad_a, gscale, loss_partials, n);
+    hipLaunchKernelGGL(mse_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, a, b, grad_a, gscale, loss_partials, n, gscale_dev);
     WM_LAUNCH_CHECK("wm_mse_fwd_bwd");
     return WM_OK;
 }
 
-extern "C" int wm_bce_logits(const float* logits, float target, int n, float gscale, float* loss_out, float* grad_out,
-                             void* stream) {
+extern "C" int wm_bce_logits(const float* logits, float target, int n, float gscale, const float* gscale_dev, float* loss_out,
+                             float* grad_out, void* stream) {
     WM_REQUIRE(logits && loss_out && n > 0, WM_E_BADARG, "wm_bce_logits: bad arguments");
-    hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, n, gscale, loss_out, grad_out);
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, n, gscale, loss_out, grad_out, gscale_dev);
     WM_LAUNCH_CHECK("wm_bce_logits");
     return WM_OK;
 }
 
-extern "C" int wm_message_loss(const float* decoded, const float* messages, int n, float gscale, float* out2, float* grad_out,
-                               void* stream) {
+extern "C" int wm_message_loss(const float* decoded, const float* messages, int n, float gscale, const float* gscale_dev, float* out2,
+                               float* grad_out, void* stream) {
     WM_REQUIRE(decoded && messages && out2 && n > 0, WM_E_BADARG, "wm_message_loss: bad arguments");
-    hipLaunchKernelGGL(message_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, decoded, messages, n, gscale, out2, grad_out);
+    hipLaunchKernelGGL(message_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, decoded, messages, n, gscale, out2, grad_out, gscale_dev);
     WM_LAUNCH_CHECK("wm_message_loss");
     return WM_OK;
 }
@@ -188,5 +254,32 @@ extern "C" int wm_adam_step(float* p, const float* g, float* m, float* v, size_t
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
                        weight_decay, decoupled, step_size, bc2_sqrt, grad_scale);
     WM_LAUNCH_CHECK("wm_adam_step");
+    return WM_OK;
+}
+
+
+extern "C" int wm_amp_found_inf(const float* const* sumsq_partials, const int* nparts, int ngroups, float* state, int k, void* stream) {
+    WM_REQUIRE(sumsq_partials && nparts && state && ngroups >= 1 && ngroups <= 4 && k >= 0 && k < 4, WM_E_BADARG, "wm_amp_found_inf: bad arguments");
+    AmpGroups g;
+    for (int q = 0; q < 4; ++q) { g.parts[q] = q < ngroups ? sumsq_partials[q] : nullptr; g.n[q] = q < ngroups ? nparts[q] : 0; }
+    for (int q = 0; q < ngroups; ++q) WM_REQUIRE(g.parts[q] && g.n[q] > 0, WM_E_BADARG, "wm_amp_found_inf: null group");
+    hipLaunchKernelGGL(amp_found_inf_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, g, ngroups, state, k);
+    WM_LAUNCH_CHECK("wm_amp_found_inf");
+    return WM_OK;
+}
+
+extern "C" int wm_amp_update(float* state, int noptimizers, void* stream) {
+    WM_REQUIRE(state && noptimizers >= 1 && noptimizers <= 4, WM_E_BADARG, "wm_amp_update: bad arguments");
+    hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, noptimizers);
+    WM_LAUNCH_CHECK("wm_amp_update");
+    return WM_OK;
+}
+
+extern "C" int wm_adam_step_amp(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, int decoupled, float grad_scale, const float* amp_state, int k, void* stream) {
+    WM_REQUIRE(p && g && m && v && amp_state && n > 0 && k >= 0 && k < 4, WM_E_BADARG, "wm_adam_step_amp: bad arguments");
+    hipLaunchKernelGGL(adam_amp_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                       decoupled, grad_scale, amp_state, k);
+    WM_LAUNCH_CHECK("wm_adam_step_amp");
     return WM_OK;
 }

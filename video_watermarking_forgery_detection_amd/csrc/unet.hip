@@ -216,7 +216,7 @@ inline int grid_for(size_t n) {
 }
 
 bool vec_ok(int C, int ld, int dtype) {
-    const int ve = dtype == WM_BF16 ? 8 : 4;
+    const int ve = dtype != WM_F32 ? 8 : 4;
     return C > 0 && C % ve == 0 && ld % ve == 0;
 }
 
@@ -226,9 +226,9 @@ extern "C" int wm_bnrelu_maxpool2(const void* y, int ldy, const float* scale, co
                                   void* act_out, int lda, int c0a, int B, int H, int W, int C, int dtype, void* stream) {
     WM_REQUIRE(y && scale && shift && pooled, WM_E_BADARG, "wm_bnrelu_maxpool2: null pointer");
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, WM_E_SHAPE, "wm_bnrelu_maxpool2: H, W must be even (got %dx%d)", H, W);
-    WM_REQUIRE(vec_ok(C, ldy, dtype) && vec_ok(C, ldp, dtype) && (!act_out || (vec_ok(C, lda, dtype) && c0a % (dtype == WM_BF16 ? 8 : 4) == 0)),
+    WM_REQUIRE(vec_ok(C, ldy, dtype) && vec_ok(C, ldp, dtype) && (!act_out || (vec_ok(C, lda, dtype) && c0a % (dtype != WM_F32 ? 8 : 4) == 0)),
                WM_E_SHAPE, "wm_bnrelu_maxpool2: channel counts / strides must be 16-byte multiples");
-    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / (dtype == WM_BF16 ? 8 : 4));
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / (dtype != WM_F32 ? 8 : 4));
     hipStream_t s = (hipStream_t)stream;
     WM_DISPATCH_DTYPE(dtype, "wm_bnrelu_maxpool2",
         hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)y, ldy, scale, shift,
@@ -244,7 +244,7 @@ extern "C" int wm_maxpool2_bwd(const void* y, int ldy, const float* scale, const
     WM_REQUIRE(B > 0 && H % 2 == 0 && W % 2 == 0, WM_E_SHAPE, "wm_maxpool2_bwd: H, W must be even");
     WM_REQUIRE(vec_ok(C, ldy, dtype) && vec_ok(C, ldgp, dtype) && vec_ok(C, ldg, dtype) && (!g_skip || vec_ok(C, ldgs, dtype)), WM_E_SHAPE,
                "wm_maxpool2_bwd: channel counts / strides must be 16-byte multiples");
-    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / (dtype == WM_BF16 ? 8 : 4));
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / (dtype != WM_F32 ? 8 : 4));
     hipStream_t s = (hipStream_t)stream;
     WM_DISPATCH_DTYPE(dtype, "wm_maxpool2_bwd",
         hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)y, ldy, scale, shift,

@@ -25,10 +25,19 @@
 #include "wm_common.h"
 
 // wave-specialised bf16 kernel (wgrad_ws.hip)
-void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy,
-                        int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s, int reverse, const void* yb = nullptr,
-                        int ldyb = 0, const float* bstats4 = nullptr, int bstats_ld = 0, const float* bcoef = nullptr,
-                        const float* gvec = nullptr);
+#define WM_DECL_WGWS(sfx)                                                                                                              \
+    void wm_launch_wgrad_ws##sfx(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy, int lddy,  \
+                                 int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s, int reverse,                       \
+                                 const void* yb = nullptr, int ldyb = 0, const float* bstats4 = nullptr, int bstats_ld = 0,               \
+                                 const float* bcoef = nullptr, const float* gvec = nullptr)
+WM_DECL_WGWS(_bf16);
+WM_DECL_WGWS(_f16);
+// the two compilations of wgrad_ws.hip, by activation dtype (WM_BF16 / WM_F16)
+template <typename... A> static inline void wm_launch_wgrad_ws(int dtype, A... args) {
+    if (dtype == WM_F16) wm_launch_wgrad_ws_f16(args...);
+    else wm_launch_wgrad_ws_bf16(args...);
+}
+static inline bool is16(int dtype) { return dtype == WM_BF16 || dtype == WM_F16; }
 
 
 namespace {
@@ -39,6 +48,7 @@ constexpr int CB = 64;  // channel block (both ci and co)
 
 template <typename T> struct WCfg;
 template <> struct WCfg<bf16_t> { static constexpr int TH = 16, VE = 8, PS = 72; };   // 144-byte pixel rows
+template <> struct WCfg<f16_t> : WCfg<bf16_t> {};
 template <> struct WCfg<float>  { static constexpr int TH = 8,  VE = 4, PS = 68; };   // 272-byte pixel rows
 
 template <typename T>
@@ -52,13 +62,14 @@ struct WgArgs {
     int ciBlocks, coBlocks;
 };
 
-__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* p0, const bf16_t* p1) {
+template <typename T>
+__device__ __forceinline__ typename h16<T>::x8 tr_frag(const T* p0, const T* p1) {
     typedef short s4 __attribute__((ext_vector_type(4)));
     const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p0));
     const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p1));
     typedef short s8 __attribute__((ext_vector_type(8)));
     s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(typename h16<T>::x8, v);
 }
 
 template <typename T, bool XFORM>
@@ -201,16 +212,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgArgs<T> a) {
                 const int pk = 8 * (g >> 1) + q;        // pixel offset inside the 16-pixel K step (+4 for the 2nd read)
 #pragma unroll
                 for (int kr = 0; kr < TH; ++kr) {
-                    const bf16_t* pd = sD + (kr * TW + pk) * PS + ni * 32 + chan;
-                    const bf16x8 bfrag = tr_frag(pd, pd + 4 * PS);
+                    const T* pd = sD + (kr * TW + pk) * PS + ni * 32 + chan;
+                    const auto bfrag = tr_frag(pd, pd + 4 * PS);
 #pragma unroll
                     for (int tap = 0; tap < 9; ++tap) {
                         const int kh = tap / 3, kw = tap % 3;
-                        const bf16_t* px_ = sX + ((kr + kh) * HW_ + pk + kw) * PS + mi * 32 + chan;
-                        const bf16x8 afrag = tr_frag(px_, px_ + 4 * PS);
+                        const T* px_ = sX + ((kr + kh) * HW_ + pk + kw) * PS + mi * 32 + chan;
+                        const auto afrag = tr_frag(px_, px_ + 4 * PS);
                         if (tap == 2) slot(2 * kr, steady_tag);
                         if (tap == 6) slot(2 * kr + 1, steady_tag);
-                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[tap], 0, 0, 0);
+                        acc[tap] = h16<T>::mfma32(afrag, bfrag, acc[tap]);
                     }
                 }
             } else {
@@ -369,7 +380,7 @@ extern "C" size_t wm_conv3x3_wgrad_ws_bytes(int B, int H, int W, int CinX, int C
 // stats4 = [scale | shift | mean | invstd] (4 rows of CP) and coef = wm_bn_bwd_finalize's [3][CP] while the tile is staged
 extern "C" int wm_conv3x3_wgrad_bnfused_supported(int CinX, int CoutY, int dtype) {
     static const bool off = WM_ENV_FLAG("WM_NO_WGRAD_FUSE");
-    return (!off && dtype == WM_BF16 && CinX <= 16 && CoutY % 64 == 0) ? 1 : 0;
+    return (!off && is16(dtype) && CinX <= 16 && CoutY % 64 == 0) ? 1 : 0;
 }
 
 extern "C" int wm_conv3x3_wgrad_bnfused(const void* x, int ldx, int CinX, const void* g, int ldg, const void* y, int ldy, int CoutY,
@@ -380,7 +391,7 @@ extern "C" int wm_conv3x3_wgrad_bnfused(const void* x, int ldx, int CinX, const 
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && CinX >= Cin && CoutY >= Cout && ldx >= CinX && ldg >= CoutY && ldy >= CoutY &&
                ldx % 8 == 0 && ldg % 8 == 0 && ldy % 8 == 0, WM_E_SHAPE, "wm_conv3x3_wgrad_bnfused: bad shape / strides");
     hipStream_t s = (hipStream_t)stream;
-    wm_launch_wgrad_ws(x, ldx, CinX, nullptr, nullptr, g, ldg, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, 0, y, ldy, stats4, CoutY, coef);
+    wm_launch_wgrad_ws(dtype, x, ldx, CinX, nullptr, nullptr, g, ldg, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, 0, y, ldy, stats4, CoutY, coef);
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad_bnfused");
     const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
     launch_wgrad_reduce(ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout, nullptr, accumulate, nullptr, s);
@@ -396,7 +407,7 @@ WM_KNOB_ON(g_gv_fuse, "WM_NO_GV_FUSE");
 WM_KNOB_SETTER(wm_debug_gv_fuse, g_gv_fuse)   // A/B knob (tools/ab_step.py, debug build only)
 
 extern "C" int wm_conv3x3_gvfused_supported(int CinX, int CoutY, int dtype) {
-    return (g_gv_fuse && dtype == WM_BF16 && CinX == 64 && (CoutY == 64 || CoutY == 32)) ? 1 : 0;
+    return (g_gv_fuse && is16(dtype) && CinX == 64 && (CoutY == 64 || CoutY == 32)) ? 1 : 0;
 }
 
 extern "C" int wm_conv3x3_wgrad_gvfused_fin(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const float* gvec,
@@ -409,7 +420,7 @@ extern "C" int wm_conv3x3_wgrad_gvfused_fin(const void* x, int ldx, int CinX, co
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && CinX >= Cin && CoutY >= Cout && ldx >= CinX && ldy >= CoutY &&
                ldx % 8 == 0 && ldy % 8 == 0, WM_E_SHAPE, "wm_conv3x3_wgrad_gvfused: bad shape / strides");
     hipStream_t s = (hipStream_t)stream;
-    wm_launch_wgrad_ws(x, ldx, CinX, in_scale, in_shift, nullptr, 0, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, 0, y, ldy, stats4, CoutY, coef, gvec);
+    wm_launch_wgrad_ws(dtype, x, ldx, CinX, in_scale, in_shift, nullptr, 0, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, 0, y, ldy, stats4, CoutY, coef, gvec);
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad_gvfused");
     const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
     WM_REQUIRE(launch_wgrad_reduce(ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout, nullptr, accumulate, fin, s) == WM_OK, WM_E_BADARG,
@@ -432,16 +443,17 @@ extern "C" int wm_conv3x3_wgrad_fin(const void* x, int ldx, int CinX, const floa
     WM_REQUIRE(fin_rider_ok(fin), WM_E_BADARG, "wm_conv3x3_wgrad: bad finalisation rider (null pointer, or more than 256 partial rows)");
     WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && CinX > 0 && CoutY >= Cout, WM_E_BADARG, "wm_conv3x3_wgrad: bad shape");
     WM_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), WM_E_BADARG, "wm_conv3x3_wgrad: in_scale/in_shift must come together");
-    WM_REQUIRE(dtype == WM_F32 || dtype == WM_BF16, WM_E_BADARG, "wm_conv3x3_wgrad: unsupported dtype %d", dtype);
-    const int ve = dtype == WM_BF16 ? 8 : 4, esz = dtype == WM_BF16 ? 2 : 4;
+    WM_REQUIRE(dtype == WM_F32 || is16(dtype), WM_E_BADARG, "wm_conv3x3_wgrad: unsupported dtype %d", dtype);
+    const int ve = is16(dtype) ? 8 : 4, esz = is16(dtype) ? 2 : 4;
     WM_REQUIRE(CinX % ve == 0 && CoutY % ve == 0, WM_E_SHAPE, "wm_conv3x3_wgrad: channel counts %d/%d must be multiples of %d", CinX, CoutY, ve);
     WM_REQUIRE(ldx >= CinX && lddy >= CoutY && (ldx * esz) % 16 == 0 && (lddy * esz) % 16 == 0, WM_E_SHAPE,
                "wm_conv3x3_wgrad: bad pixel strides ldx=%d lddy=%d", ldx, lddy);
     WM_REQUIRE(perm_dev || CinX >= Cin, WM_E_BADARG, "wm_conv3x3_wgrad: x has fewer channels than the weight");
     hipStream_t s = (hipStream_t)stream;
     static const bool v1 = WM_ENV_FLAG("WM_WGRAD_V1");  // diagnostic knob (debug build): single-role kernel
-    if (dtype == WM_BF16 && !v1) wm_launch_wgrad_ws(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, sweep_reverse ? 1 : 0);
+    if (is16(dtype) && !v1) wm_launch_wgrad_ws(dtype, x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, sweep_reverse ? 1 : 0);
     else if (dtype == WM_BF16) launch_wgrad<bf16_t>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
+    else if (dtype == WM_F16) launch_wgrad<f16_t>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
     else launch_wgrad<float>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad");
     const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;

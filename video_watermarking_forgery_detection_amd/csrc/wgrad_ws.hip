@@ -9,6 +9,19 @@
 // producer variant of it 1.4 % slower still -- tools/ab_step.py.)
 #include "wm_common.h"
 
+// This file is compiled twice (build.py): plain for bf16 (production), and with -DWM_H16_F16 for the f16 twin of every kernel in
+// it (the reference's autocast dtype, BASELINE config C5).  Everything that depends on the 16-bit layout goes through h16<> (wm_common.h).
+#ifdef WM_H16_F16
+typedef f16_t hx_t;
+#define WM_HSYM(name) name##_f16
+#else
+typedef bf16_t hx_t;
+#define WM_HSYM(name) name##_bf16
+#endif
+typedef h16<hx_t> HX;
+typedef HX::x8 hx8;
+typedef HX::x2 hx2;
+
 int wm_sweep_dir(int reverse);   // conv3x3_ws.hip
 
 namespace {
@@ -19,24 +32,24 @@ constexpr int DVP = TH * TW * 8 / 256;        // dy vectors per producer thread 
 constexpr int D_BYTES = TH * TW * CB * 2;
 
 struct WsWgArgs {
-    const bf16_t* x; int ldx; int CinX;
+    const hx_t* x; int ldx; int CinX;
     const float* in_scale; const float* in_shift;
-    const bf16_t* dy; int lddy; int CoutY;   // DYF: the gradient wrt the layer's ReLU output (g), not dy
+    const hx_t* dy; int lddy; int CoutY;   // DYF: the gradient wrt the layer's ReLU output (g), not dy
     // DYF (fused BatchNorm-backward apply): the layer's raw conv output and its BatchNorm constants
-    const bf16_t* yb; int ldyb; const float* bscale; const float* bshift; const float* bmean; const float* binvstd; const float* bcoef;
+    const hx_t* yb; int ldyb; const float* bscale; const float* bshift; const float* bmean; const float* binvstd; const float* bcoef;
     const float* gvec; int ldgv;   // DYF == 2: g is one row per sample (the layer's output was globally pooled); dy/lddy unused
     float* ws;           // [gridDim.x][9][CinP][CoutP]
     int B, H, W, tilesX, tilesY, ntiles, ciBlocks, coBlocks;
     int reverse;
 };
 
-__device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
+__device__ __forceinline__ hx8 tr_frag(const char* p0, const char* p1) {
     typedef short s4 __attribute__((ext_vector_type(4)));
     const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p0));
     const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p1));
     typedef short s8 __attribute__((ext_vector_type(8)));
     s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(hx8, v);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -93,8 +106,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
         return g;
     };
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
-    typedef short i16x2 __attribute__((ext_vector_type(2)));
+        typedef short i16x2 __attribute__((ext_vector_type(2)));
 
     if (producer) {
         // ================================================================== PRODUCER waves
@@ -110,12 +122,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { sc[e] = a.in_scale[cx + e]; sh[e] = a.in_shift[cx + e]; }
         }
-        auto load_x = [&](const TileGeo& g, int k, bf16x8& dst, unsigned& okbits) {
+        auto load_x = [&](const TileGeo& g, int k, hx8& dst, unsigned& okbits) {
             const int pix = min((ptid + 256 * k) / VPX, NPIX - 1);
             const int py = pix / HW, px = pix - py * HW;
             const int gy = g.ty0 - 1 + py, gx = g.tx0 - 1 + px;
             const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
-            dst = *reinterpret_cast<const bf16x8*>(a.x + ((size_t)(g.b * a.H + gyc) * a.W + gxc) * a.ldx + cxl);
+            dst = *reinterpret_cast<const hx8*>(a.x + ((size_t)(g.b * a.H + gyc) * a.W + gxc) * a.ldx + cxl);
             okbits |= ((cxok && gy == gyc && gx == gxc) ? 1u : 0u) << k;
         };
         float bsc[8], bsh[8], bca[8], bk2[8], bk3[8];   // DYF == 1: scale, shift, ca and the folded k2, k3 (wm_bn_fold) of this thread's 8 channels
@@ -127,26 +139,26 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
                 wm_bn_fold(a.bmean[cdl + e], a.binvstd[cdl + e], bca[e], a.bcoef[CP + cdl + e], a.bcoef[2 * CP + cdl + e], bk2[e], bk3[e]);
             }
         }
-        auto load_d = [&](const TileGeo& g, int k, bf16x8& dst, bf16x8& ydst, unsigned& okbits) {
+        auto load_d = [&](const TileGeo& g, int k, hx8& dst, hx8& ydst, unsigned& okbits) {
             const int pix = (ptid + 256 * k) >> 3;
             const int gy = g.ty0 + (pix >> 4), gx = g.tx0 + (pix & 15);
             const int gyc = min(gy, a.H - 1), gxc = min(gx, a.W - 1);
             const size_t pofs = (size_t)(g.b * a.H + gyc) * a.W + gxc;
-            if (DYF == 2) dst = *reinterpret_cast<const bf16x8*>(a.yb + pofs * a.ldyb + cdl);
-            else dst = *reinterpret_cast<const bf16x8*>(a.dy + pofs * a.lddy + cdl);
-            if (DYF == 1) ydst = *reinterpret_cast<const bf16x8*>(a.yb + pofs * a.ldyb + cdl);
+            if (DYF == 2) dst = *reinterpret_cast<const hx8*>(a.yb + pofs * a.ldyb + cdl);
+            else dst = *reinterpret_cast<const hx8*>(a.dy + pofs * a.lddy + cdl);
+            if (DYF == 1) ydst = *reinterpret_cast<const hx8*>(a.yb + pofs * a.ldyb + cdl);
             okbits |= ((cdok && gy == gyc && gx == gxc) ? 1u : 0u) << k;
         };
-        auto put_x = [&](unsigned char* base, int k, const bf16x8& src, bool ok) {
+        auto put_x = [&](unsigned char* base, int k, const hx8& src, bool ok) {
             const int pix = (ptid + 256 * k) / VPX;
             const int py = pix / HW, px = pix - py * HW;
             u32x4 w = __builtin_bit_cast(u32x4, src);
             if (XFORM) {
 #pragma unroll
                 for (int pq = 0; pq < 4; ++pq) {
-                    const float f0 = __builtin_fmaf(__builtin_bit_cast(float, w[pq] << 16), sc[2 * pq], sh[2 * pq]);
-                    const float f1 = __builtin_fmaf(__builtin_bit_cast(float, w[pq] & 0xffff0000u), sc[2 * pq + 1], sh[2 * pq + 1]);
-                    const bf16x2 pk = {(bf16_t)f0, (bf16_t)f1};
+                    const float f0 = __builtin_fmaf(HX::lo(w[pq]), sc[2 * pq], sh[2 * pq]);
+                    const float f1 = __builtin_fmaf(HX::hi(w[pq]), sc[2 * pq + 1], sh[2 * pq + 1]);
+                    const hx2 pk = {(hx_t)f0, (hx_t)f1};
                     const i16x2 z = {0, 0};
                     w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
                 }
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
             const int off = CI == 64 ? (py * HW + px) * 128 + ((vx * 16) ^ swz16(px)) : (py * HW + slot16(px)) * 32 + vx * 16;
             if (pix < NPIX) *reinterpret_cast<u32x4*>(base + off) = w;
         };
-        auto put_d = [&](unsigned char* base, int k, const bf16x8& src, const bf16x8& ysrc, bool ok) {
+        auto put_d = [&](unsigned char* base, int k, const hx8& src, const hx8& ysrc, bool ok) {
             const int pix = (ptid + 256 * k) >> 3;
             u32x4 w = __builtin_bit_cast(u32x4, src);
             if (DYF == 1) {
@@ -168,11 +180,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
 #pragma unroll
                     for (int hlf = 0; hlf < 2; ++hlf) {
                         const int e = 2 * pq + hlf;
-                        const float gg = __builtin_bit_cast(float, hlf ? (w[pq] & 0xffff0000u) : (w[pq] << 16));
-                        const float yy = __builtin_bit_cast(float, hlf ? (yw[pq] & 0xffff0000u) : (yw[pq] << 16));
+                        const float gg = hlf ? HX::hi(w[pq]) : HX::lo(w[pq]);
+                        const float yy = hlf ? HX::hi(yw[pq]) : HX::lo(yw[pq]);
                         dd[hlf] = wm_bn_fold_dyg(yy, gg, bsc[e], bsh[e], bca[e], bk2[e], bk3[e]);
                     }
-                    const bf16x2 pk = {(bf16_t)dd[0], (bf16_t)dd[1]};
+                    const hx2 pk = {(hx_t)dd[0], (hx_t)dd[1]};
                     w[pq] = __builtin_bit_cast(unsigned, pk);
                 }
             }
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
         };
         // DYF == 2: the 8 staged y vectors of a tile -> dy, in place, one channel pair at a time (its constants come from the
         // LDS, its gradient from the sample's gvec row: a dozen registers live instead of 64)
-        auto gv_apply = [&](bf16x8 (&d)[DVP], int b) {
+        auto gv_apply = [&](hx8 (&d)[DVP], int b) {
             if (DYF != 2) return;
             const float* gv = a.gvec + (size_t)b * a.ldgv + cdl;
 #pragma unroll
@@ -195,15 +207,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
 #pragma unroll
                 for (int k = 0; k < DVP; ++k) {
                     u32x4 w = __builtin_bit_cast(u32x4, d[k]);
-                    const float da = wm_bn_fold_dy(__builtin_bit_cast(float, w[pq] << 16), ka[0], ka[1], ka[2], ka[3], k3ga);
-                    const float db = wm_bn_fold_dy(__builtin_bit_cast(float, w[pq] & 0xffff0000u), kb[0], kb[1], kb[2], kb[3], k3gb);
-                    const bf16x2 pk = {(bf16_t)da, (bf16_t)db};
+                    const float da = wm_bn_fold_dy(HX::lo(w[pq]), ka[0], ka[1], ka[2], ka[3], k3ga);
+                    const float db = wm_bn_fold_dy(HX::hi(w[pq]), kb[0], kb[1], kb[2], kb[3], k3gb);
+                    const hx2 pk = {(hx_t)da, (hx_t)db};
                     w[pq] = __builtin_bit_cast(unsigned, pk);
-                    d[k] = __builtin_bit_cast(bf16x8, w);
+                    d[k] = __builtin_bit_cast(hx8, w);
                 }
             }
         };
-        bf16x8 x0[XV], x1[XV], d0[DVP], d1[DVP], y0[DVP], y1[DVP];
+        hx8 x0[XV], x1[XV], d0[DVP], d1[DVP], y0[DVP], y1[DVP];
         unsigned okx0 = 0, okx1 = 0, okd0 = 0, okd1 = 0;
         if (t_begin < t_end) {
             const TileGeo g0 = geo(t_begin);
@@ -296,14 +308,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
         const char* sDc = sXc + XB;
 #pragma unroll
         for (int ks = 0; ks < TH / 2; ++ks) {
-            bf16x8 bfrag[FJ];
+            hx8 bfrag[FJ];
 #pragma unroll
             for (int fj = 0; fj < FJ; ++fj)
                 bfrag[fj] = tr_frag(sDc + 2 * ks * TW * 128 + dof[0][fj], sDc + 2 * ks * TW * 128 + dof[1][fj]);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int kh = tap / 3, kw = tap % 3;
-                bf16x8 afrag[FI];
+                hx8 afrag[FI];
 #pragma unroll
                 for (int fi = 0; fi < FI; ++fi)
                     afrag[fi] = tr_frag(sXc + (2 * ks + kh) * XROW + xo[kw][0][fi], sXc + (2 * ks + kh) * XROW + xo[kw][1][fi]);
@@ -311,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
                 for (int fi = 0; fi < FI; ++fi)
 #pragma unroll
                     for (int fj = 0; fj < FJ; ++fj)
-                        acc[tap][fi][fj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[fi], bfrag[fj], acc[tap][fi][fj], 0, 0, 0);
+                        acc[tap][fi][fj] = HX::mfma16(afrag[fi], bfrag[fj], acc[tap][fi][fj]);
             }
         }
         __syncthreads();
@@ -335,14 +347,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
 
 }  // namespace
 
-void wm_launch_wgrad_ws(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy,
+void WM_HSYM(wm_launch_wgrad_ws)(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift, const void* dy,
                         int lddy, int CoutY, float* ws, int B, int H, int W, int nslabs, hipStream_t s, int reverse, const void* yb = nullptr,
                         int ldyb = 0, const float* bstats4 = nullptr, int bstats_ld = 0, const float* bcoef = nullptr,
                         const float* gvec = nullptr) {
     WsWgArgs a;
-    a.x = (const bf16_t*)x; a.ldx = ldx; a.CinX = CinX; a.in_scale = in_scale; a.in_shift = in_shift;
-    a.dy = (const bf16_t*)dy; a.lddy = lddy; a.CoutY = CoutY; a.ws = ws; a.B = B; a.H = H; a.W = W;
-    a.yb = (const bf16_t*)yb; a.ldyb = ldyb;
+    a.x = (const hx_t*)x; a.ldx = ldx; a.CinX = CinX; a.in_scale = in_scale; a.in_shift = in_shift;
+    a.dy = (const hx_t*)dy; a.lddy = lddy; a.CoutY = CoutY; a.ws = ws; a.B = B; a.H = H; a.W = W;
+    a.yb = (const hx_t*)yb; a.ldyb = ldyb;
     a.bscale = bstats4; a.bshift = bstats4 ? bstats4 + bstats_ld : nullptr; a.bmean = bstats4 ? bstats4 + 2 * bstats_ld : nullptr;
     a.binvstd = bstats4 ? bstats4 + 3 * bstats_ld : nullptr; a.bcoef = bcoef; a.gvec = gvec; a.ldgv = bstats_ld;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;

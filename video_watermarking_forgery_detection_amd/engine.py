@@ -311,9 +311,10 @@ class FlatModule:
 
 
 def set_compute_dtype(module, dtype):
-    """torch.bfloat16 (production) or torch.float32 (parity path) for every HIP-backed submodule."""
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise TypeError("compute dtype must be torch.float32 or torch.bfloat16")
+    """torch.bfloat16 (production), torch.float16 (the reference's autocast dtype; needs loss scaling, see models/IRNrhi_model.py)
+    or torch.float32 (parity path) for every HIP-backed submodule."""
+    if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise TypeError("compute dtype must be torch.float32, torch.bfloat16 or torch.float16")
     for m in module.modules():
         if hasattr(m, "compute_dtype"):
             m.compute_dtype = dtype

@@ -95,10 +95,22 @@ class _FlatAdam:
         for m in self.modules:
             m.flat_grads.zero_()
 
+    def attach_amp(self, amp):
+        """run under a device-side GradScaler (ops.AmpState): the gradients arrive multiplied by its scale, the step divides it
+        out, is skipped when they hold an inf / nan, and takes its bias corrections from the scaler's per-optimiser step count"""
+        self.amp, self.amp_slot = amp, amp.slot()
+
     def step(self, grad_scale=1.0):
         self._ensure()
         self.step_count += 1
         g = self.param_groups[0]
+        amp = getattr(self, "amp", None)
+        if amp is not None:   # scaler.step(optimizer), IRNcrop_model.py:413-414
+            amp.found_inf(self.amp_slot, [ops.sumsq(mod.flat_grads) for mod in self.modules])
+            for mod, m, v in zip(self.modules, self._m, self._v):
+                ops.adam_step_amp(mod.flat_params, mod.flat_grads, m, v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
+                                  amp, self.amp_slot, decoupled=self.decoupled, grad_scale=grad_scale)
+            return
         for mod, m, v in zip(self.modules, self._m, self._v):
             ops.adam_step(mod.flat_params, mod.flat_grads, m, v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                           g["weight_decay"], self.step_count, decoupled=self.decoupled, grad_scale=grad_scale)
@@ -111,11 +123,12 @@ class _FlatAdam:
         {step, exp_avg, exp_avg_sq} sliced out of the flat moment buffers in parameters() order, one param group."""
         self._ensure()
         state, i = {}, 0
+        steps = self.amp.step_count(self.amp_slot) if getattr(self, "amp", None) is not None else self.step_count
         for mod, m, v in zip(self.modules, self._m, self._v):
             off = 0
             for p in mod.parameters():
                 n = p.numel()
-                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m[off:off + n].view_as(p).detach().cpu().clone(),
+                state[i] = {"step": torch.tensor(float(steps)), "exp_avg": m[off:off + n].view_as(p).detach().cpu().clone(),
                             "exp_avg_sq": v[off:off + n].view_as(p).detach().cpu().clone()}
                 off += n
                 i += 1
@@ -123,7 +136,7 @@ class _FlatAdam:
         group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": g["weight_decay"], "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "decoupled_weight_decay": bool(self.decoupled), "initial_lr": g.get("initial_lr", g["lr"]), "params": list(range(i))}
-        return {"state": state if self.step_count else {}, "param_groups": [group]}
+        return {"state": state if steps else {}, "param_groups": [group]}
 
     def load_state_dict(self, sd):
         """accepts torch.optim.Adam / AdamW state_dicts (the reference's files) and this class's round-1 flat layout"""
@@ -218,7 +231,7 @@ _ACCEPTS_ID = {}
 
 class Hidden:
     def __init__(self, configuration: HiDDenConfiguration, device: torch.device, noiser, tb_logger=None,
-                 compute_dtype=torch.bfloat16, grad_sync=None):
+                 compute_dtype=torch.bfloat16, grad_sync=None, amp=None):
         """
         :param configuration: sizes / loss weights (options.HiDDenConfiguration)
         :param device: must be a cuda (ROCm) device -- the step has no CPU path
@@ -228,6 +241,9 @@ class Hidden:
         :param compute_dtype: torch.bfloat16 (production) or torch.float32 (parity path)
         :param grad_sync: optional callable(flat_grad_tensor) run before each optimiser step
                           (data-parallel all-reduce, see parallel.py)
+        :param amp: optional ops.AmpState -- torch.cuda.amp.GradScaler semantics on the device (models/IRNcrop_model.py:143,
+                    407-416): every loss gradient is multiplied by its scale, both optimisers step through it.  Required in
+                    practice with compute_dtype=torch.float16 (the gradients of a 3M-element mean loss underflow f16 otherwise)
         """
         device = torch.device(device)
         if device.type != "cuda":
@@ -250,15 +266,23 @@ class Hidden:
         self.encoded_label = 0
         self.tb_logger = tb_logger
         self.grad_sync = grad_sync
+        self.amp = amp
+        self.amp_owner = True   # this object calls amp.update() at the end of a step (a wrapping model may take that over)
+        if amp is not None:
+            self.optimizer_enc_dec.attach_amp(amp)
+            self.optimizer_discrim.attach_amp(amp)
         self.noise_id = None  # optional deterministic choice for Combined/Noiser layers
         self.lazy_losses = True  # train_on_batch returns StepLosses (host sync on first read) instead of a plain dict
 
     # ------------------------------------------------------------------ helpers
-    @staticmethod
-    def _bce_logits(logits, target, gscale=1.0):
+    def _bce_logits(self, logits, target, gscale=1.0):
         """nn.BCEWithLogitsLoss (mean) value ([1] tensor) and gscale * gradient wrt logits, on a [B,1] tensor: one launch."""
-        loss, grad = ops.bce_logits(logits, target, gscale)
+        loss, grad = ops.bce_logits(logits, target, gscale, gscale_dev=self._gsd())
         return loss[0], grad.view_as(logits)
+
+    def _gsd(self):
+        """the AMP loss scale as a device scalar (None without a scaler): scaler.scale(loss).backward()"""
+        return self.amp.scale if self.amp is not None else None
 
     def _run_noiser(self, enc, cover):
         n = self.encoder_decoder.noiser
@@ -341,11 +365,11 @@ class Hidden:
         n_img = encoded.numel()
         gate = enc_gate(encoded, images) if enc_gate is not None else None
         if gate is None:
-            enc_part, g_mse = ops.mse_fwd_bwd(encoded, images, 2.0 * cfg.encoder_loss / n_img)
+            enc_part, g_mse = ops.mse_fwd_bwd(encoded, images, 2.0 * cfg.encoder_loss / n_img, gscale_dev=self._gsd())
         else:
-            enc_part, g_mse = ops.mse_fwd_bwd_gated(encoded, images, 2.0 * cfg.encoder_loss / n_img, gate[1:2])
+            enc_part, g_mse = ops.mse_fwd_bwd_gated(encoded, images, 2.0 * cfg.encoder_loss / n_img, gate[1:2], gscale_dev=self._gsd())
         ops.axpy_(g_enc, g_mse)
-        msg_out, g_dec = ops.message_loss(decoded, messages, 2.0 * cfg.decoder_loss / decoded.numel())   # mse, bit error, grad
+        msg_out, g_dec = ops.message_loss(decoded, messages, 2.0 * cfg.decoder_loss / decoded.numel(), gscale_dev=self._gsd())   # mse, bit error, grad
         g_dec = g_dec.view_as(decoded)
         g_noised = dec_net.bwd(cDec, g_dec, gDec, accumulate=False, need_input_grad=True)
         # data parallel: the decoder's bucket goes out now and travels while the attack and the encoder run their backward
@@ -375,6 +399,8 @@ class Hidden:
         if clip is not None:
             clip([enc_net.flat_grads, dec_net.flat_grads])   # one norm over encoder_decoder.parameters()
         self.optimizer_enc_dec.step(grad_scale=gscale)
+        if self.amp is not None and self.amp_owner:
+            self.amp.update()   # scaler.update(), IRNcrop_model.py:416
 
         # ---------------- metrics: one host sync for all seven scalars (hidden.py:105-117)
         vals = ops.hidden_metrics(enc_part, n_img, msg_out, g_loss_adv, d_loss_on_cover, d_loss_on_encoded, cfg.adversarial_loss,

@@ -95,7 +95,13 @@ class IRNrhiModel(BaseModel):
         self.previous_images = self.previous_previous_images = None
         self.save_interval = _get(train_opt, 'save_interval', default=3000)
         self.gradient_clipping = _get(train_opt, 'gradient_clipping', default=None)
-        dtype = {"bf16": torch.bfloat16, "f32": torch.float32, None: torch.bfloat16}[_get(train_opt, 'compute_dtype')]
+        dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16, "f32": torch.float32,
+                 None: torch.bfloat16}[_get(train_opt, 'compute_dtype')]
+        # torch.cuda.amp.autocast() + GradScaler() of the reference (IRNcrop_model.py:143,340,407-416): with f16 activations the
+        # loss gradients are scaled by a device-side GradScaler (train.amp: true by default for f16, optional for the other dtypes)
+        use_amp = _get(train_opt, 'amp', default=(dtype == torch.float16))
+        self.amp = ops.AmpState(self.device, init_scale=_get(train_opt, 'amp_init_scale', default=65536.0),
+                                growth_interval=_get(train_opt, 'amp_growth_interval', default=2000)) if use_amp else None
 
         # ---- attacks (IRNrhi_model.py:103-150 / IRNcrop_model.py:85-104) cycled per step
         attacks = _get(train_opt, 'attacks', default=None)
@@ -120,7 +126,7 @@ class IRNrhiModel(BaseModel):
         if opt['dist'] and torch.distributed.get_world_size() > 1:
             from ..distributed import GradSync
             grad_sync = GradSync()
-        self.hidden = Hidden(cfg, self.device, self.attack, None, compute_dtype=dtype, grad_sync=grad_sync)
+        self.hidden = Hidden(cfg, self.device, self.attack, None, compute_dtype=dtype, grad_sync=grad_sync, amp=self.amp)
         self.netG = self.hidden.encoder_decoder
         self.discriminator = self.hidden.discriminator
         lr = _get(train_opt, 'lr_G', default=1e-3)
@@ -137,6 +143,8 @@ class IRNrhiModel(BaseModel):
             engine.set_compute_dtype(self.localizer, dtype)
             self.localizer.flatten_parameters_()
             self.optimizer_localizer = _FlatAdam([self.localizer], lr=lr, betas=betas, weight_decay=wd)
+            if self.amp is not None:
+                self.optimizer_localizer.attach_amp(self.amp)
             self.optimizers.append(self.optimizer_localizer)
             self.localizer_weight = _get(train_opt, 'localizer_weight', default=1.0)
         self.psnr_gate = bool(_get(train_opt, 'psnr_gate', default=True))   # IRNcrop_model.py:379-388
@@ -208,7 +216,8 @@ class IRNrhiModel(BaseModel):
             if self.keep_outputs:
                 self.last_outputs["pred"] = pred
             # the reference applies BCEWithLogits to the sigmoid output (:378,391-393); the kernel chains sigmoid'
-            loss, g_logit = ops.bce_logits_target(pred, mask, self.localizer_weight, chain_sigmoid=True)
+            loss, g_logit = ops.bce_logits_target(pred, mask, self.localizer_weight, chain_sigmoid=True,
+                                                  gscale_dev=self.amp.scale if self.amp is not None else None)
             grads = engine.grad_dict(net)
             # data parallel: the localiser's 31 MB of gradients leave in four reverse-order buckets from inside its backward
             gs, pending = self.grad_sync, []

@@ -14,16 +14,21 @@ c_float = ctypes.c_float
 c_size_t = ctypes.c_size_t
 c_double = ctypes.c_double
 
-WM_F32, WM_BF16 = 0, 1
+WM_F32, WM_BF16, WM_F16 = 0, 1, 2
+_DT = {torch.float32: WM_F32, torch.bfloat16: WM_BF16, torch.float16: WM_F16}
+
+
+def dt_id(dtype):
+    """torch dtype -> WM_F32 / WM_BF16 / WM_F16"""
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"unsupported activation dtype {dtype} (float32, bfloat16 or float16)") from None
 JPEG_ROUND, JPEG_SS, JPEG_MASK = 0, 1, 2
 
 
 def dtype_id(t):
-    if t.dtype == torch.float32:
-        return WM_F32
-    if t.dtype == torch.bfloat16:
-        return WM_BF16
-    raise TypeError(f"unsupported activation dtype {t.dtype} (float32 or bfloat16)")
+    return dt_id(t.dtype)
 
 
 def _need_cuda(*ts):
@@ -216,14 +221,14 @@ class PackPlan:
         if self.jobs is None:
             self._build()
         rc = _lib.lib().wm_pack_w3x3_batch(_p(self.jobs), c_int(self.njobs), c_size_t(self.max_elems),
-                                           c_int(WM_BF16 if self.dtype == torch.bfloat16 else WM_F32), _stream())
+                                           c_int(dt_id(self.dtype)), _stream())
         _lib.check(rc, "wm_pack_w3x3_batch")
         self.valid = True
 
 
 # ----------------------------------------------------------------------------- conv / bn
 def conv3x3_nparts(B, H, W, Cin, CoutP, dtype):
-    return _lib.lib().wm_conv3x3_nparts(c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(CoutP), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32))
+    return _lib.lib().wm_conv3x3_nparts(c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(CoutP), c_int(dt_id(dtype)))
 
 
 class _WmBnBwdFin(ctypes.Structure):   # include/wm_hip.h: WmBnBwdFin
@@ -339,7 +344,7 @@ def bn_bwd(g, gvec, y, stats, C, gamma, dgamma, dbeta, accumulate, dbias, coef=N
 
 
 def conv3x3_wgrad_bnfused_supported(CinX, CoutY, dtype):
-    return bool(_lib.lib().wm_conv3x3_wgrad_bnfused_supported(c_int(CinX), c_int(CoutY), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32)))
+    return bool(_lib.lib().wm_conv3x3_wgrad_bnfused_supported(c_int(CinX), c_int(CoutY), c_int(dt_id(dtype))))
 
 
 def conv3x3_wgrad_bnfused(x, g, y, stats, coef, dw, accumulate):
@@ -360,7 +365,7 @@ def conv3x3_wgrad_bnfused(x, g, y, stats, coef, dw, accumulate):
 
 
 def conv3x3_gvfused_supported(CinX, CoutY, dtype):
-    return bool(_lib.lib().wm_conv3x3_gvfused_supported(c_int(CinX), c_int(CoutY), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32)))
+    return bool(_lib.lib().wm_conv3x3_gvfused_supported(c_int(CinX), c_int(CoutY), c_int(dt_id(dtype))))
 
 
 def conv3x3_wgrad_gvfused(x, in_scale, in_shift, gvec, y, stats, coef, dw, accumulate, fin=None):
@@ -395,7 +400,7 @@ def conv3x3_dgrad_gvfused(y, wpt, gvec, stats, coef):
 
 
 def conv3x3_dgrad_bwdstats_supported(CoutY, CinP, dtype):
-    return bool(_lib.lib().wm_conv3x3_dgrad_bwdstats_supported(c_int(CoutY), c_int(CinP), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32)))
+    return bool(_lib.lib().wm_conv3x3_dgrad_bwdstats_supported(c_int(CoutY), c_int(CinP), c_int(dt_id(dtype))))
 
 
 def conv3x3_dgrad_bwdstats(src, wpt, ry, r_scale, r_shift, gvec=None, stats=None, coef=None, reverse=False):
@@ -416,7 +421,7 @@ def conv3x3_dgrad_bwdstats(src, wpt, ry, r_scale, r_shift, gvec=None, stats=None
 
 
 def conv3x3_dgrad_applyfused_supported(CoutY, CinP, dtype):
-    return bool(_lib.lib().wm_conv3x3_dgrad_applyfused_supported(c_int(CoutY), c_int(CinP), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32)))
+    return bool(_lib.lib().wm_conv3x3_dgrad_applyfused_supported(c_int(CoutY), c_int(CinP), c_int(dt_id(dtype))))
 
 
 def conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry=None, r_scale=None, r_shift=None, reverse=False):
@@ -462,24 +467,26 @@ def linear_head_bwd(pooled, w, g_out, dw, db, accumulate, CP, inv_hw):
     return gvec
 
 
-def bce_logits(logits, target, gscale=1.0, want_grad=True):
-    """BCEWithLogitsLoss(mean) against a constant label: (loss [1] tensor, gscale * d loss / d logits or None)."""
+def bce_logits(logits, target, gscale=1.0, want_grad=True, gscale_dev=None):
+    """BCEWithLogitsLoss(mean) against a constant label: (loss [1] tensor, gscale * d loss / d logits or None).
+    gscale_dev (here and in the other loss ops): optional device scalar multiplied into gscale (the AMP loss scale)."""
     _need_cuda(logits)
     x = logits.contiguous().float()
     loss = torch.empty(1, device=x.device, dtype=torch.float32)
     grad = torch.empty_like(x) if want_grad else None
-    rc = _lib.lib().wm_bce_logits(_p(x), c_float(float(target)), c_int(x.numel()), c_float(float(gscale)), _p(loss), _p(grad), _stream())
+    rc = _lib.lib().wm_bce_logits(_p(x), c_float(float(target)), c_int(x.numel()), c_float(float(gscale)), _p(gscale_dev), _p(loss), _p(grad),
+                                  _stream())
     _lib.check(rc, "wm_bce_logits")
     return loss, grad
 
 
-def message_loss(decoded, messages, gscale, want_grad=True):
+def message_loss(decoded, messages, gscale, want_grad=True, gscale_dev=None):
     """(out [2] = [mean squared error, bitwise error], gscale * (decoded - messages) or None)."""
     _need_cuda(decoded, messages)
     d = decoded.contiguous().float(); m = messages.contiguous().float()
     out = torch.empty(2, device=d.device, dtype=torch.float32)
     grad = torch.empty_like(d) if want_grad else None
-    rc = _lib.lib().wm_message_loss(_p(d), _p(m), c_int(d.numel()), c_float(float(gscale)), _p(out), _p(grad), _stream())
+    rc = _lib.lib().wm_message_loss(_p(d), _p(m), c_int(d.numel()), c_float(float(gscale)), _p(gscale_dev), _p(out), _p(grad), _stream())
     _lib.check(rc, "wm_message_loss")
     return out, grad
 
@@ -603,14 +610,14 @@ def conv1x1_head_bwd(y, scale, shift, w, gout, dw, dbias, accumulate):
 
 
 # ----------------------------------------------------------------------------- losses / optimiser
-def mse_fwd_bwd(a, b, gscale, want_grad=True):
+def mse_fwd_bwd(a, b, gscale, want_grad=True, gscale_dev=None):
     """returns (sum of squared differences partials [nparts], grad = gscale*(a-b))"""
     a = a.contiguous(); b = b.contiguous()
     n = a.numel()
     nparts = max(1, min(1024, (n + 4095) // 4096))
     part = torch.empty(nparts, device=a.device, dtype=torch.float32)
     grad = torch.empty_like(a) if want_grad else None
-    rc = _lib.lib().wm_mse_fwd_bwd(_p(a), _p(b), _p(grad), c_float(gscale), _p(part), c_int(nparts), c_size_t(n), _stream())
+    rc = _lib.lib().wm_mse_fwd_bwd(_p(a), _p(b), _p(grad), c_float(gscale), _p(gscale_dev), _p(part), c_int(nparts), c_size_t(n), _stream())
     _lib.check(rc, "wm_mse_fwd_bwd")
     return part, grad
 
@@ -627,6 +634,50 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, decoupled=F
                                  c_float(eps), c_float(weight_decay), c_int(1 if decoupled else 0), c_int(step),
                                  c_float(grad_scale), _stream())
     _lib.check(rc, "wm_adam_step")
+
+
+class AmpState:
+    """torch.cuda.amp.GradScaler (IRNcrop_model.py:143,407-416) with its state on the device: see include/wm_hip.h (wm_amp_*).
+    `scale` is the device scalar the loss kernels multiply their gradient seeds by."""
+    N = 16
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        st = torch.zeros(self.N, dtype=torch.float32)
+        st[0], st[2], st[3], st[4] = init_scale, growth_factor, backoff_factor, growth_interval
+        self.state = st.to(device)
+        self.scale = self.state[0:1]
+        self.nopt = 0
+
+    def slot(self):
+        """index of a new optimiser under this scaler (<= 4)"""
+        k = self.nopt
+        if k >= 4:
+            raise ValueError("at most four optimisers per scaler")
+        self.nopt += 1
+        return k
+
+    def found_inf(self, k, parts):
+        """found_inf[k] from the wm_sumsq rows of optimiser k's gradient buffers"""
+        arr = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+        ns = (ctypes.c_int * len(parts))(*[p.numel() for p in parts])
+        rc = _lib.lib().wm_amp_found_inf(arr, ns, c_int(len(parts)), _p(self.state), c_int(k), _stream())
+        _lib.check(rc, "wm_amp_found_inf")
+
+    def update(self):
+        rc = _lib.lib().wm_amp_update(_p(self.state), c_int(max(1, self.nopt)), _stream())
+        _lib.check(rc, "wm_amp_update")
+
+    def get_scale(self):
+        return float(self.state[0].item())
+
+    def step_count(self, k):
+        return int(self.state[12 + k].item())
+
+
+def adam_step_amp(p, g, m, v, lr, beta1, beta2, eps, weight_decay, amp, k, decoupled=False, grad_scale=1.0):
+    rc = _lib.lib().wm_adam_step_amp(_p(p), _p(g), _p(m), _p(v), c_size_t(p.numel()), c_float(lr), c_float(beta1), c_float(beta2), c_float(eps),
+                                     c_float(weight_decay), c_int(1 if decoupled else 0), c_float(grad_scale), _p(amp.state), c_int(k), _stream())
+    _lib.check(rc, "wm_adam_step_amp")
 
 
 def sumsq(x):
@@ -679,19 +730,20 @@ def psnr_gate(partials, n, threshold=33.0, w_below=1.0, w_above=0.8):
     return out
 
 
-def mse_fwd_bwd_gated(a, b, gscale, gate):
+def mse_fwd_bwd_gated(a, b, gscale, gate, gscale_dev=None):
     """mse_fwd_bwd with the gradient scale multiplied by the device scalar gate[0]"""
     a = a.contiguous(); b = b.contiguous()
     n = a.numel()
     nparts = max(1, min(1024, (n + 4095) // 4096))
     part = torch.empty(nparts, device=a.device, dtype=torch.float32)
     grad = torch.empty_like(a)
-    rc = _lib.lib().wm_mse_fwd_bwd_gated(_p(a), _p(b), _p(grad), c_float(gscale), _p(gate), _p(part), c_int(nparts), c_size_t(n), _stream())
+    rc = _lib.lib().wm_mse_fwd_bwd_gated(_p(a), _p(b), _p(grad), c_float(gscale), _p(gate), _p(gscale_dev), _p(part), c_int(nparts), c_size_t(n),
+                                         _stream())
     _lib.check(rc, "wm_mse_fwd_bwd_gated")
     return part, grad
 
 
-def bce_logits_target(p, target, gscale=1.0, want_grad=True, chain_sigmoid=False):
+def bce_logits_target(p, target, gscale=1.0, want_grad=True, chain_sigmoid=False, gscale_dev=None):
     """BCEWithLogitsLoss(mean)(p, target) for tensors: (loss [1] device tensor, gscale * d loss / d p or None).
     chain_sigmoid: p is a sigmoid output s(z) and the gradient returned is wrt z."""
     _need_cuda(p, target)
@@ -702,7 +754,7 @@ def bce_logits_target(p, target, gscale=1.0, want_grad=True, chain_sigmoid=False
     part = torch.empty(nparts, device=p.device, dtype=torch.float32)
     loss = torch.empty(1, device=p.device, dtype=torch.float32)
     grad = torch.empty_like(p) if want_grad else None
-    rc = _lib.lib().wm_bce_logits_target(_p(p), _p(target), c_size_t(n), c_float(gscale), _p(part), c_int(nparts), _p(loss), _p(grad),
+    rc = _lib.lib().wm_bce_logits_target(_p(p), _p(target), c_size_t(n), c_float(gscale), _p(gscale_dev), _p(part), c_int(nparts), _p(loss), _p(grad),
                                          c_int(1 if chain_sigmoid else 0), _stream())
     _lib.check(rc, "wm_bce_logits_target")
     return loss, grad
@@ -727,11 +779,11 @@ def mask_threshold(p, threshold=0.5):
     return out
 
 
-def clip_grad_norm_(flats, max_norm):
+def clip_grad_norm_(flats, max_norm, parts=None):
     """nn.utils.clip_grad_norm_ over the parameters of SEVERAL flat gradient buffers taken together (IRNcrop_model.py:410-412:
     netG.parameters() is one group), without a host sync.  Returns the [2] device tensor (clip coefficient, total norm)."""
     assert 1 <= len(flats) <= 4
-    parts = [sumsq(f) for f in flats]
+    parts = parts if parts is not None else [sumsq(f) for f in flats]
     arr = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
     ns = (ctypes.c_int * len(parts))(*[p.numel() for p in parts])
     out = torch.empty(2, device=flats[0].device, dtype=torch.float32)
@@ -878,15 +930,15 @@ def maxpool2_bwd(y, scale, shift, gpooled, g_skip, g_skip_c0, C):
 
 
 def upconv2x2_mfma_supported(Cin, Cout, dtype):
-    return bool(_lib.lib().wm_upconv2x2_mfma_supported(c_int(Cin), c_int(Cout), c_int(WM_BF16 if dtype == torch.bfloat16 else WM_F32)))
+    return bool(_lib.lib().wm_upconv2x2_mfma_supported(c_int(Cin), c_int(Cout), c_int(dt_id(dtype))))
 
 
-def upconv2x2_pack(w):
-    """w [Cin,Cout,2,2] f32 -> (wf bf16 [4*Cout, Cin] rows (ij, co), wb bf16 [Cin, 4*Cout] columns (ij, co)): the MFMA operands"""
+def upconv2x2_pack(w, dtype=torch.bfloat16):
+    """w [Cin,Cout,2,2] f32 -> (wf [4*Cout, Cin] rows (ij, co), wb [Cin, 4*Cout] columns (ij, co)) in the 16-bit activation dtype: the MFMA operands"""
     Cin, Cout = w.shape[0], w.shape[1]
-    wf = torch.empty(4 * Cout, Cin, device=w.device, dtype=torch.bfloat16)
-    wb = torch.empty(Cin, 4 * Cout, device=w.device, dtype=torch.bfloat16)
-    rc = _lib.lib().wm_upconv2x2_pack(_p(w), _p(wf), _p(wb), c_int(Cin), c_int(Cout), _stream())
+    wf = torch.empty(4 * Cout, Cin, device=w.device, dtype=dtype)
+    wb = torch.empty(Cin, 4 * Cout, device=w.device, dtype=dtype)
+    rc = _lib.lib().wm_upconv2x2_pack(_p(w), _p(wf), _p(wb), c_int(Cin), c_int(Cout), c_int(dt_id(dtype)), _stream())
     _lib.check(rc, "wm_upconv2x2_pack")
     return wf, wb
 
@@ -896,9 +948,9 @@ def upconv2x2_fwd(x, scale, shift, w, bias, out, c0):
     B, H, W, ldx = x.shape
     Cin, Cout = w.shape[0], w.shape[1]
     if upconv2x2_mfma_supported(Cin, Cout, x.dtype):
-        wf, _ = upconv2x2_pack(w)
+        wf, _ = upconv2x2_pack(w, x.dtype)
         rc = _lib.lib().wm_upconv2x2_fwd_mfma(_p(x), c_int(ldx), _p(scale), _p(shift), _p(wf), _p(bias), _p(out), c_int(out.shape[-1]),
-                                              c_int(c0), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(Cout), _stream())
+                                              c_int(c0), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(Cout), c_int(dtype_id(x)), _stream())
         _lib.check(rc, "wm_upconv2x2_fwd_mfma")
         return out
     rc = _lib.lib().wm_upconv2x2_fwd(_p(x), c_int(ldx), _p(scale), _p(shift), _p(w), _p(bias), _p(out), c_int(out.shape[-1]),
@@ -913,17 +965,17 @@ def upconv2x2_bwd(x, scale, shift, w, gy, c0, dw, dbias, accumulate):
     Cin, Cout = w.shape[0], w.shape[1]
     L = _lib.lib()
     if upconv2x2_mfma_supported(Cin, Cout, x.dtype):
-        _, wb = upconv2x2_pack(w)
+        _, wb = upconv2x2_pack(w, x.dtype)
         gx = torch.empty(B, H, W, Cin, device=x.device, dtype=x.dtype)
         rc = L.wm_upconv2x2_dgrad_mfma(_p(gy), c_int(gy.shape[-1]), c_int(c0), _p(wb), _p(gx), c_int(Cin), c_int(B), c_int(H), c_int(W),
-                                       c_int(Cin), c_int(Cout), _stream())
+                                       c_int(Cin), c_int(Cout), c_int(dtype_id(x)), _stream())
         _lib.check(rc, "wm_upconv2x2_dgrad_mfma")
         ns = L.wm_upconv2x2_wgrad_nsplit(c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(Cout))
         part = torch.empty(ns, Cin, 4 * Cout, device=x.device, dtype=torch.float32)
         bpart = torch.empty(ns, 4 * Cout, device=x.device, dtype=torch.float32)
         rc = L.wm_upconv2x2_wgrad_mfma(_p(x), c_int(ldx), _p(scale), _p(shift), _p(gy), c_int(gy.shape[-1]), c_int(c0), _p(part), _p(bpart),
                                        _p(dw), _p(dbias), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W), c_int(Cin),
-                                       c_int(Cout), _stream())
+                                       c_int(Cout), c_int(dtype_id(x)), _stream())
         _lib.check(rc, "wm_upconv2x2_wgrad_mfma")
         return gx
     chunks = L.wm_upconv2x2_dw_chunks(c_int(B), c_int(H), c_int(W))
