@@ -853,3 +853,57 @@ def test_fused_backward_entry_points_fail_loudly():
     rc = L.wm_conv3x3_wgrad_fin(P(g), 64, 64, P(f[0]), P(f[1]), P(g), 64, 64, P(ws), P(dw), 0, 1, 16, 16, 64, 64, P(None), 1, ctypes.byref(st), None)
     assert rc < 0 and "rider" in err()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 40, 36), (1, 16, 16), (3, 33, 18)])
+def test_after_concat_layer_without_the_concat(case, dtype):
+    """hidden_models/encoder.py:25,34-41 in its split form -- conv64(features) + [conv3(image) + bias + message term] -- against
+    torch's CPU conv over the materialised 97-channel concat (operands rounded to the 16-bit dtype the kernels store): forward
+    (side tensor P, the summed output, its statistics) and the three slices of the weight gradient (message / feature / image channels)"""
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W = case
+    L, C = 30, 64
+    img = detgen.uniform((B, 3, H, W), 301)
+    msg = detgen.bits((B, L), 302)
+    feat = detgen.normal((B, C, H, W), 303).to(dtype).float()
+    sc = detgen.normal((C,), 304, mean=1.0, std=0.2); sh = detgen.normal((C,), 305, std=0.3)
+    w = detgen.normal((C, L + C + 3, 3, 3), 306, std=(2.0 / (9 * 97)) ** 0.5)
+    bias = detgen.normal((C,), 307, std=0.1)
+    wq = w.clone()
+    wq[:, L:] = w[:, L:].to(dtype).float()         # feature and image filters are stored in the 16-bit dtype; the message term stays f32
+    a = torch.relu(feat * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).to(dtype).float()
+    imq = img.to(dtype).float()
+    cat = torch.cat([msg.view(B, L, 1, 1).expand(-1, -1, H, W), a, imq], dim=1)
+    wr = wq.clone().requires_grad_(True)
+    ref = F.conv2d(cat, wr, bias, padding=1)
+    dy = detgen.normal((B, C, H, W), 308).to(dtype).float()
+    ref.backward(dy)
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    # ---- forward
+    P = ops.concat_side_fwd(img.cuda(), w.cuda(), bias.cuda(), msg.cuda(), dtype, 0, L, L + C)
+    ref_side = F.conv2d(cat[:, :L], wq[:, :L], bias, padding=1) + F.conv2d(imq, wq[:, L + C:], None, padding=1)
+    torch.testing.assert_close(nchw(P, C), ref_side, rtol=tol, atol=tol)
+    DROP = 1 << 20
+    fperm = [DROP] * L + list(range(C)) + [DROP] * 3
+    wp = ops.pack_w3x3(w.cuda(), C, C, dtype, perm=fperm)
+    y, st = ops.conv3x3_fwd_addin(nhwc(feat, dtype), wp, sc.cuda(), sh.cuda(), P)
+    torch.testing.assert_close(nchw(y, C), ref.detach(), rtol=tol, atol=2 * tol)
+    s = st.sum(0).cpu()
+    torch.testing.assert_close(s[0], ref.detach().sum((0, 2, 3)), rtol=2e-2, atol=0.5)
+    # ---- weight gradient: three writers, three disjoint channel ranges of dW
+    dw = torch.full((C, L + C + 3, 3, 3), 7.0, device="cuda")
+    dyh = nhwc(dy, dtype)
+    ops.conv3x3_wgrad(nhwc(feat, dtype), C, sc.cuda(), sh.cuda(), dyh, dw, False, perm_dev=torch.tensor(fperm, dtype=torch.int32, device="cuda"))
+    img16 = torch.zeros(B, H, W, 16, device="cuda", dtype=dtype)
+    ops.nchw_to_nhwc(img.cuda(), img16, 0, 13)
+    iperm = [DROP] * (L + C) + [0, 1, 2]
+    ops.conv3x3_wgrad(img16, 16, None, None, dyh, dw, False, perm_dev=torch.tensor(iperm, dtype=torch.int32, device="cuda"))
+    ops.concat_side_msg_wgrad(dyh, msg.cuda(), dw, False, 0, L)
+    g = wr.grad
+    torch.testing.assert_close(dw.cpu(), g, rtol=tol, atol=tol * g.abs().max().item())
+    # accumulate adds onto what is there
+    dw2 = dw.clone()
+    ops.concat_side_msg_wgrad(dyh, msg.cuda(), dw2, True, 0, L)
+    torch.testing.assert_close(dw2[:, :L].cpu(), 2 * dw[:, :L].cpu(), rtol=1e-5, atol=1e-5 * g.abs().max().item())
+    assert torch.equal(dw2[:, L:], dw[:, L:])

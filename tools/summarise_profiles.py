@@ -1,41 +1,122 @@
-"""gpurun_out/prof_final (tools/collect_profiles.sh) -> profiles/r01_* (committed summaries).
-FETCH_SIZE is doubled (gfx950 reports half of wide coalesced reads: MI355X_MICROARCH.md, HBM section); both counters
-are in KB per dispatch."""
+"""gpurun_out/prof_final (tools/collect_profiles.sh) -> profiles/<tag>_* (committed summaries).
+
+FETCH_SIZE is doubled (gfx950 reports half of wide coalesced reads: MI355X_MICROARCH.md, HBM section); both traffic counters are in
+KB per dispatch.  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs): busy cycles of the
+matrix pipes over the SIMD-cycles the dispatch held the chip (the gfx94x MfmaUtil formula; GRBM_GUI_ACTIVE is summed over the XCDs).
+usage: python tools/summarise_profiles.py <tag>"""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_final")
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
-shutil.copy(stats, os.path.join(dst, f"{tag}_bench_c2_kernel_stats.csv"))
-rows = list(csv.DictReader(open(stats)))
-steps = 13.0
-tot = sum(float(r["TotalDurationNs"]) for r in rows)
-with open(os.path.join(dst, f"{tag}_bench_c2_kernel_stats_summary.txt"), "w") as f:
-    f.write(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 3\n")
-    f.write(f"total kernel ms: {tot/1e6:.2f}  (/{steps:g} steps = {tot/1e6/steps:.2f} ms/step)\n")
-    for r in rows[:40]:
-        f.write(f"{r['Name'][:110]:110s} n={int(r['Calls']):5d} ms/step={float(r['TotalDurationNs'])/1e6/steps:7.3f} avg_us={float(r['AverageNs'])/1e3:8.1f} {float(r['Percentage']):5.1f}%\n")
-out = {}
-for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    f = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)[0]
-    agg = collections.defaultdict(list)
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+os.makedirs(dst, exist_ok=True)
+NXCD, NCU, NSIMD = 8, 256, 4
+
+
+def find(sub, pat):
+    return glob.glob(os.path.join(src, sub, "**", pat), recursive=True)[0]
+
+
+def stats_summary(sub, out_base, steps, cmd):
+    stats = find(sub, "*kernel_stats.csv")
+    shutil.copy(stats, os.path.join(dst, out_base + ".csv"))
+    rows = list(csv.DictReader(open(stats)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    with open(os.path.join(dst, out_base + "_summary.txt"), "w") as f:
+        f.write(f"rocprofv3 --kernel-trace --stats -- {cmd}\n")
+        f.write(f"total kernel ms: {tot/1e6:.2f}" + (f"  (/{steps:g} steps = {tot/1e6/steps:.2f} ms/step)\n" if steps else "\n"))
+        for r in rows[:48]:
+            per = f"ms/step={float(r['TotalDurationNs'])/1e6/steps:7.3f} " if steps else ""
+            f.write(f"{r['Name'][:110]:110s} n={int(r['Calls']):5d} {per}avg_us={float(r['AverageNs'])/1e3:8.1f} {float(r['Percentage']):5.1f}%\n")
+    return {r["Name"]: float(r["AverageNs"]) for r in rows}
+
+
+def counters(sub):
+    f = find(sub, "*counter_collection.csv")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == name:
-            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    with open(os.path.join(dst, f"{tag}_bench_c2_pmc_{name}.csv"), "w") as g:
-        g.write("kernel,dispatches,mean_KB_per_dispatch\n")
-        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-            g.write(f"\"{k[:120]}\",{len(v)},{sum(v)/len(v):.2f}\n")
-    out[name] = {k: sum(v) / len(v) for k, v in agg.items()}
-def traffic(pattern):
-    k = [k for k in out["FETCH_SIZE"] if pattern in k][0]
-    return k, out["FETCH_SIZE"][k], out["WRITE_SIZE"][k], (2.0 * out["FETCH_SIZE"][k] + out["WRITE_SIZE"][k]) * 1024.0
-# dominant kernel: the fused 64->64 input-gradient conv (BNBWD = 2, BWDST); runner-up: the forward 64->64 conv (XFORM, STATS)
-k, f, w, b = traffic("conv3x3_ws_kernel<64, 64, false, false, true, false, 2, true")
-k2, f2, w2, b2 = traffic("conv3x3_ws_kernel<64, 64, true, true")
-res = {"kernel": k, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": b,
-       "fwd_kernel": k2, "fwd_FETCH_SIZE_KB": f2, "fwd_WRITE_SIZE_KB": w2, "fwd_hbm_bytes_per_launch": b2,
-       "note": "FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads); KB = 1024 B"}
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def traffic_tables(fetch_sub, write_sub, base):
+    out = {}
+    for name, sub in (("FETCH_SIZE", fetch_sub), ("WRITE_SIZE", write_sub)):
+        agg = counters(sub)
+        with open(os.path.join(dst, f"{base}_pmc_{name}.csv"), "w") as g:
+            g.write("kernel,dispatches,mean_KB_per_dispatch\n")
+            for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1][name])):
+                g.write(f"\"{k[:120]}\",{len(v[name])},{sum(v[name])/len(v[name]):.2f}\n")
+        out[name] = {k: sum(v[name]) / len(v[name]) for k, v in agg.items()}
+    return out
+
+
+avg_ns = stats_summary("stats", f"{tag}_bench_c2_kernel_stats", 13.0, "python3 bench.py --no-cpu-baseline --steps 10 --warmup 3")
+tr = traffic_tables("pmc_fetch", "pmc_write", f"{tag}_bench_c2")
+
+# ---- MFMA utilisation per kernel and for the whole step
+m = counters("pmc_mfma")
+rows, tot_busy, tot_act = [], 0.0, 0.0
+for k, v in m.items():
+    if "GRBM_GUI_ACTIVE" not in v:
+        continue
+    busy = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", [0.0]))
+    act = sum(v["GRBM_GUI_ACTIVE"])
+    tot_busy += busy
+    tot_act += act
+    n = len(v["GRBM_GUI_ACTIVE"])
+    rows.append((busy, k, n, busy / n, act / n, busy / (act / NXCD * NCU * NSIMD) if act else 0.0))
+rows.sort(reverse=True)
+step_util = tot_busy / (tot_act / NXCD * NCU * NSIMD)
+with open(os.path.join(dst, f"{tag}_bench_c2_pmc_mfma.csv"), "w") as g:
+    g.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1\n")
+    g.write(f"# whole run (every kernel of 4 training steps): MFMA utilisation {step_util:.4f}\n")
+    g.write("kernel,dispatches,mean_SQ_VALU_MFMA_BUSY_CYCLES,mean_GRBM_GUI_ACTIVE,mfma_util\n")
+    for busy, k, n, mb, ma, u in rows:
+        g.write(f"\"{k[:120]}\",{n},{mb:.0f},{ma:.0f},{u:.4f}\n")
+
+
+def pick(d, pattern):
+    ks = [k for k in d if pattern in k]
+    return ks[0] if ks else None
+
+
+def kern(pattern):
+    k = pick(tr["FETCH_SIZE"], pattern)
+    if k is None:
+        return None
+    f, w = tr["FETCH_SIZE"][k], tr["WRITE_SIZE"].get(k, 0.0)
+    mu = next((u for _, kk, _, _, _, u in rows if kk == k), None)
+    return {"kernel": k, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0, "mfma_util": mu,
+            "avg_us_rocprof": avg_ns.get(k, 0.0) / 1e3}
+
+
+res = {"note": "FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads); KB = 1024 B; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 * 4)",
+       "step_mfma_util": step_util,
+       "dgrad_fused": kern("conv3x3_ws_kernel<64, 64, false, false, true, false, 2, true"),
+       "fwd": kern("conv3x3_ws_kernel<64, 64, true, true"),
+       "wgrad": kern("wgrad_ws16_kernel<64, true, 0>")}
+# round-1 keys bench.py reads
+if res["dgrad_fused"]:
+    res["hbm_bytes_per_launch"] = res["dgrad_fused"]["hbm_bytes_per_launch"]
+if res["fwd"]:
+    res["fwd_hbm_bytes_per_launch"] = res["fwd"]["hbm_bytes_per_launch"]
 json.dump(res, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-print(json.dumps(res, indent=1))
+
+# ---- attack kernels
+try:
+    aavg = stats_summary("att_stats", f"{tag}_attack_kernel_stats", 0, "python3 tools/attack_bench.py 20   (B=16, 3x256x256 f32)")
+    atr = traffic_tables("att_fetch", "att_write", f"{tag}_attack")
+    px = 16 * 256 * 256
+    with open(os.path.join(dst, f"{tag}_attack_roofline.csv"), "w") as g:
+        g.write("# per launch at B=16, 3x256x256 f32: rocprofv3 average duration, HBM bytes from the PMC passes (2*FETCH_SIZE + WRITE_SIZE), GB/s of those bytes, fraction of 8 TB/s\n")
+        g.write("kernel,avg_us,hbm_MB_pmc,GBps_pmc,frac_of_8TBps\n")
+        for k, ns in sorted(aavg.items(), key=lambda kv: -kv[1]):
+            if k not in atr["FETCH_SIZE"] or "at::native" in k or "rocclr" in k:
+                continue
+            b = (2.0 * atr["FETCH_SIZE"][k] + atr["WRITE_SIZE"].get(k, 0.0)) * 1024.0
+            g.write(f"\"{k[:100]}\",{ns/1e3:.1f},{b/1e6:.1f},{b/ns:.0f},{b/ns/8000.0:.3f}\n")
+    shutil.copy(os.path.join(src, "attack_bench.json"), os.path.join(dst, f"{tag}_attack_bench.json"))
+except (IndexError, OSError) as e:
+    print("attack profiles missing:", e)
+print(json.dumps(res, indent=1)[:1500])

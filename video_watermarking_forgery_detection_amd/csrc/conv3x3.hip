@@ -35,7 +35,8 @@ WM_DECL_STREAM(_f16);
                                   const float* in_scale, const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs,          \
                                   int tiles_per_wg, hipStream_t s, int reverse, const float* bw_stats4 = nullptr, int bw_ld = 0,            \
                                   const float* bw_coef = nullptr, const float* bw_gvec = nullptr, const void* ry = nullptr,                 \
-                                  const float* r_scale = nullptr, const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr)
+                                  const float* r_scale = nullptr, const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr, \
+                                  const void* addend = nullptr)
 WM_DECL_WS(_bf16);
 WM_DECL_WS(_f16);
 // the two compilations of conv3x3_ws.hip, by activation dtype (WM_BF16 / WM_F16)
@@ -395,6 +396,22 @@ extern "C" int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const floa
     else if (dtype == WM_F16) launch_conv<f16_t>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s, sweep_reverse ? 1 : 0);
     else launch_conv<float>(x, ldx, wp, bias, nbias, in_scale, in_shift, y, ldy, stat_partials, B, H, W, Cin, CoutP, s, 0);
     WM_LAUNCH_CHECK("wm_conv3x3_fwd");
+    return WM_OK;
+}
+
+// forward 64 -> 64 conv (16-bit dtypes, dense tensors) whose epilogue adds a second tensor before the BatchNorm statistics:
+// y = conv3x3(relu(in_scale*x + in_shift), wp) + addend
+extern "C" int wm_conv3x3_fwd_addin(const void* x, const void* wp, const float* in_scale, const float* in_shift, const void* addend, void* y,
+                                    float* stat_partials, int B, int H, int W, int dtype, int sweep_reverse, void* stream) {
+    WM_REQUIRE(x && wp && in_scale && in_shift && addend && y && stat_partials, WM_E_BADARG, "wm_conv3x3_fwd_addin: null pointer");
+    WM_REQUIRE(B > 0 && H > 0 && W > 0 && is16(dtype), WM_E_BADARG, "wm_conv3x3_fwd_addin: bad shape / dtype (WM_BF16 or WM_F16)");
+    WM_REQUIRE((((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y | (uintptr_t)addend) & 15) == 0, WM_E_SHAPE, "wm_conv3x3_fwd_addin: pointers must be 16-byte aligned");
+    const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
+    const int rc = wm_launch_conv3x3_ws(dtype, x, 64, 64, 64, wp, nullptr, 0, in_scale, in_shift, y, stat_partials, B, H, W, ws_wgs(ntiles),
+                                        ws_tiles_per_wg(ntiles), (hipStream_t)stream, sweep_reverse ? 1 : 0, nullptr, 0, nullptr, nullptr, nullptr,
+                                        nullptr, nullptr, nullptr, nullptr, addend);
+    WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_fwd_addin: no kernel for this shape");
+    WM_LAUNCH_CHECK("wm_conv3x3_fwd_addin");
     return WM_OK;
 }
 

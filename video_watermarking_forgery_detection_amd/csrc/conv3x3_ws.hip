@@ -81,8 +81,13 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 // BatchNorm-backward sums from the tile they hold -- per channel sum(gz) and sum(gz*y), gz = g*[scale*y+shift > 0], g rounded
 // to bf16 as stored, y = that layer's raw conv output read at the tile's pixels -- into the partial rows `stat`: the separate
 // reduce pass over (g, y) disappears (its y read moves here, its g read is gone)
-template <int CIN, int COUT, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false, int BNBWD = 0, bool BWDST = false, bool PIN = true>
+// ADDIN (forward, M16): the consumers add a second tensor `a.ry` [B,H,W,COUT] (same 16-bit dtype) to the accumulators before the
+// statistics and the pack -- y = conv(x) + addend.  The encoder's after-concat layer (hidden_models/encoder.py:25,40) runs as
+// conv64(features) + [conv(image) + message bias] this way: the 97-channel concat tensor is never built (csrc/concat_side.hip)
+template <int CIN, int COUT, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false, int BNBWD = 0, bool BWDST = false, bool PIN = true,
+          bool ADDIN = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned long long* __restrict__ stamps = nullptr) {
+    static_assert(!ADDIN || (M16 && !BWDST && BNBWD == 0), "ADDIN: forward form of the 16x16x32 consumers");
     static_assert(CIN == 64 || CIN == 32 || CIN == 16, "input channels");
     static_assert(!M16 || CIN % 32 == 0, "the 16x16x32 MFMA consumes 32 input channels per step");
     static_assert(COUT == 64 || (COUT == 32 && M16), "32 output channels (image dgrads, the 30-channel layer) only with the 16x16x32 consumers");
@@ -488,9 +493,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
 #pragma unroll
             for (int c = 0; c < CPL; ++c) { rsc[c] = a.r_scale[CPL * q + c]; rsh[c] = a.r_shift[CPL * q + c]; }
         }
-        unsigned ryv[2][NPAIR];   // BWDST: the layer's y at the two pixels of the half being drained, this lane's channels
+        unsigned ryv[2][NPAIR];   // BWDST: the layer's y at the two pixels of the half being drained, this lane's channels (ADDIN: the addend)
         auto load_ry = [&](const Drain (&d)[2]) {
-            if (BWDST) {
+            if (BWDST || ADDIN) {
 #pragma unroll
                 for (int ml = 0; ml < 2; ++ml) {
                     const hx_t* src = a.ry + (d[ml].inb ? (d[ml].yp - a.y) : (ptrdiff_t)(CPL * q));
@@ -516,7 +521,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             const int ml = m / (NPAIR + 1), j = m - ml * (NPAIR + 1), mf = 2 * dh + ml;
             if (j < NPAIR) {
                 const int nf = j >> 1, i0 = 2 * (j & 1);
-                const float v0 = acc[mf][nf][i0], v1 = acc[mf][nf][i0 + 1];
+                float v0 = acc[mf][nf][i0], v1 = acc[mf][nf][i0 + 1];
+                if (ADDIN) { v0 += HX::lo(ryv[ml][j]); v1 += HX::hi(ryv[ml][j]); }
                 if (STATS) {   // scalar f32 on purpose (packed f32 VALU is slow beside MFMAs)
                     const float t0 = v0 * d[ml].mk, t1 = v1 * d[ml].mk;
                     s1[2 * j] += t0; s1[2 * j + 1] += t1;
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 return;
             }
             // BWDST: the y values of the half being drained are requested here and first used DS0 K-steps later
-            constexpr int DS0 = BWDST ? 6 : 0;
+            constexpr int DS0 = (BWDST || ADDIN) ? 6 : 0;
             if (drain) load_ry(d);
             constexpr int PF = 2;   // a deeper ring measured the same
             hx8 pix[PF][2], fil[PF][NFR];
@@ -835,7 +841,7 @@ int WM_HSYM(wm_launch_conv3x3_ws)(const void* x, int ldx, int Cin, int CoutP, co
                            const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
                            hipStream_t s, int reverse, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
                            const float* bw_gvec = nullptr, const void* ry = nullptr, const float* r_scale = nullptr,
-                           const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr) {
+                           const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr, const void* addend = nullptr) {
     WsArgs a;
     a.dbg = g_ws_variant == 3 ? 8 : (g_ws_variant == 8 ? 64 : (g_ws_variant == 10 ? 128 : 0)); a.xcd_map = g_ws_variant != 2;
     a.x = (const hx_t*)x; a.ldx = ldx; a.wp = (const hx_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
@@ -846,6 +852,12 @@ int WM_HSYM(wm_launch_conv3x3_ws)(const void* x, int ldx, int Cin, int CoutP, co
     a.ry = (const hx_t*)ry; a.r_scale = r_scale; a.r_shift = r_shift;
     a.ay = (const hx_t*)ay; a.dy_out = (hx_t*)dy_out;
     const dim3 grid((unsigned)wgs), block(512);
+    if (addend) {   // forward 64 -> 64 with a second tensor added before the statistics (the encoder's after-concat layer)
+        if (Cin != 64 || CoutP != 64 || !in_scale || !stat || ay || ry || bw_stats4) return WM_E_SHAPE;
+        a.ry = (const hx_t*)addend;
+        hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, true, true, true, false, 0, false, true, true>), grid, block, 0, s, a, nullptr);
+        return WM_OK;
+    }
     if (ay) {   // dgrad with the BatchNorm-backward apply (tensor gradient) fused; x = g, dy written out for the weight gradient
         if (Cin != 64 || (CoutP != 64 && CoutP != 32) || ldx != 64 || in_scale || !bw_stats4 || !bw_coef || bw_gvec || !dy_out ||
             (ry != nullptr) != (stat != nullptr) || (ry && CoutP != 64))

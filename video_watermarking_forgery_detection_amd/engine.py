@@ -99,9 +99,16 @@ def cbr_forward(conv, bn, x, dtype, perm=None, training=True, momentum=0.1):
     CinX = x.t.shape[-1]
     wp = _packed(conv, CoutP, CinX, dtype, perm, False)
     bias = conv.bias.data if conv.bias is not None else None
-    B, H, W, _ = x.t.shape
     d = _opposite(x.rev)
     y, st = ops.conv3x3_fwd(x.t, wp, bias, x.scale, x.shift, want_stats=training, reverse=d)
+    return cbr_finish(conv, bn, x, y, st, d, perm, training, momentum)
+
+
+def cbr_finish(conv, bn, x, y, st, d, perm=None, training=True, momentum=0.1):
+    """second half of a ConvBNRelu forward: the raw conv output y (+ its statistics partials st) -> (Act(y, scale, shift), ctx)"""
+    Cout = conv.weight.shape[0]
+    CoutP = y.shape[-1]
+    B, H, W, _ = y.shape
     if training:
         stats = ops.bn_finalize(st, Cout, CoutP, B * H * W, bn.weight.data, bn.bias.data, bn.running_mean,
                                 bn.running_var, momentum if bn.momentum is None else bn.momentum, bn.eps)
@@ -117,6 +124,15 @@ def cbr_forward(conv, bn, x, dtype, perm=None, training=True, momentum=0.1):
     ctx.x, ctx.y, ctx.stats, ctx.perm, ctx.training = x, y, stats, perm, training
     ctx.out = Act(y, Cout, stats[0], stats[1], rev=d, src=(bn, ctx))
     return ctx.out, ctx
+
+
+def fin_rider(x, part, grads, accumulate):
+    """the BatchNorm-backward finalisation of the layer that produced Act `x`, to ride on a weight-gradient slab reduction"""
+    if x.src is None or not ops.fin_rider_enabled():
+        return None
+    pbn, pctx = x.src
+    return dict(partials=part, y_shape=tuple(x.t.shape), stats=pctx.stats, C=x.C, gamma=pbn.weight.data, dgamma=grads[pbn.weight],
+                dbeta=grads[pbn.bias], accumulate=accumulate)
 
 
 def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, accumulate=False,

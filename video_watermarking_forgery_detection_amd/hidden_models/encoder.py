@@ -15,7 +15,7 @@ from .conv_bn_relu import ConvBNRelu
 
 
 class EncCtx:
-    __slots__ = ("layers", "cat_ctx", "final_in", "B", "H", "W")
+    __slots__ = ("layers", "cat_ctx", "final_in", "B", "H", "W", "split", "message", "image")
 
 
 class Encoder(nn.Module, engine.FlatModule):
@@ -41,6 +41,13 @@ class Encoder(nn.Module, engine.FlatModule):
         self._cat_ld = engine.round_up(c + L + 3, 16)
         self._perm = [c + i for i in range(L)] + list(range(c)) + [c + L + i for i in range(3)]
         self._perm_dev = None
+        # the same layer WITHOUT the concat (16-bit dtypes, 64 feature channels): conv64(features) + [conv3(image) + message bias];
+        # reference channel -> position in the 64-channel feature operand / the 16-channel image operand (>= the width: not there)
+        DROP = 1 << 20
+        self._fperm = [DROP] * L + list(range(c)) + [DROP] * 3
+        self._iperm = [DROP] * (L + c) + [0, 1, 2]
+        self._fperm_dev = self._iperm_dev = None
+        self.split_concat = True   # A/B switch: False builds the 97(112)-channel tensor like round 1
 
     # -- explicit engine path ------------------------------------------------------------------
     def fwd(self, image, message, training=True):
@@ -56,11 +63,24 @@ class Encoder(nn.Module, engine.FlatModule):
         for blk in self.conv_layers:
             a, cx = engine.cbr_forward(blk.layers[0], blk.layers[1], a, dt, training=training)
             ctx.layers.append(cx)
-        cat = torch.empty(B, self.H, self.W, self._cat_ld, device=image.device, dtype=dt)
-        ops.concat_full(a.t, a.scale, a.shift, message, image, cat, c)   # [features | message | image | 0-pad], one pass
         blk = self.after_concat_layer
-        a5, ctx.cat_ctx = engine.cbr_forward(blk.layers[0], blk.layers[1], engine.Act(cat, c + L + 3), dt,
-                                             perm=self._perm, training=training)
+        ctx.split = (self.split_concat and dt in (torch.bfloat16, torch.float16) and c == 64 and a.t.shape[-1] == 64 and a.scale is not None
+                     and self.H >= 2 and self.W >= 2)
+        if ctx.split:
+            # encoder.py:34-41 without materialising the concat: P = conv3(image) + bias + message term (one store-bound pass),
+            # added to conv64(features) in the epilogue of the ordinary 64 -> 64 kernel, before the BatchNorm statistics
+            conv, bn = blk.layers[0], blk.layers[1]
+            P = ops.concat_side_fwd(image, conv.weight.data, conv.bias.data, message, dt, 0, L, L + c)
+            wp = engine._packed(conv, 64, 64, dt, self._fperm, False)
+            d = engine._opposite(a.rev)
+            y, st = ops.conv3x3_fwd_addin(a.t, wp, a.scale, a.shift, P, reverse=d)
+            a5, ctx.cat_ctx = engine.cbr_finish(conv, bn, a, y, st, d, None, training)
+            ctx.message, ctx.image = message, image
+        else:
+            cat = torch.empty(B, self.H, self.W, self._cat_ld, device=image.device, dtype=dt)
+            ops.concat_full(a.t, a.scale, a.shift, message, image, cat, c)   # [features | message | image | 0-pad], one pass
+            a5, ctx.cat_ctx = engine.cbr_forward(blk.layers[0], blk.layers[1], engine.Act(cat, c + L + 3), dt,
+                                                 perm=self._perm, training=training)
         ctx.final_in = a5
         fl = self.final_layer
         enc = ops.conv1x1_head_fwd(a5.t, a5.scale, a5.shift, fl.weight.data.view(3, c), fl.bias.data, act=0)
@@ -85,8 +105,11 @@ class Encoder(nn.Module, engine.FlatModule):
         g = ops.conv1x1_head_bwd(a5.t, a5.scale, a5.shift, fl.weight.data.view(3, c), g_enc,
                                  grads[fl.weight].view(3, c), grads[fl.bias], accumulate)
         blk = self.after_concat_layer
-        g = engine.cbr_backward(blk.layers[0], blk.layers[1], ctx.cat_ctx, grads, g=g, accumulate=accumulate,
-                                dgrad_channels=c, perm_dev=self._perm_dev)
+        if ctx.split:
+            g = self._after_concat_bwd_split(ctx, g, grads, accumulate)
+        else:
+            g = engine.cbr_backward(blk.layers[0], blk.layers[1], ctx.cat_ctx, grads, g=g, accumulate=accumulate,
+                                    dgrad_channels=c, perm_dev=self._perm_dev)
         if after_head is not None:
             after_head()
         n = len(self.conv_layers)
@@ -95,6 +118,37 @@ class Encoder(nn.Module, engine.FlatModule):
             g = engine.cbr_backward(blk.layers[0], blk.layers[1], ctx.layers[i], grads, g=g, accumulate=accumulate,
                                     need_input_grad=(i > 0))
         return None
+
+    def _after_concat_bwd_split(self, ctx, g, grads, accumulate):
+        """backward of the after-concat ConvBNRelu in its split form.  The feature part is an ordinary 64 -> 64 layer (fused input
+        gradient: BatchNorm-backward apply + the sums of the last body layer; weight gradient with that layer's finalisation riding
+        on its slab reduction) writing the feature channels of dW; the image channels of dW come from the image-fed weight-gradient
+        kernel, the message channels from per-sample border-class sums of dy."""
+        conv, bn = self.after_concat_layer.layers[0], self.after_concat_layer.layers[1]
+        cx = ctx.cat_ctx
+        y, x, dt = cx.y, cx.x, cx.y.dtype
+        dev = y.device
+        if self._fperm_dev is None or self._fperm_dev.device != dev:
+            self._fperm_dev = torch.tensor(self._fperm, dtype=torch.int32, device=dev)
+            self._iperm_dev = torch.tensor(self._iperm, dtype=torch.int32, device=dev)
+        dw = grads[conv.weight]
+        coef = ops.bn_bwd_coef(g, None, y, cx.stats, 64, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate)
+        wpt = engine._packed(conv, 64, 64, dt, self._fperm, True)
+        d = engine._opposite(getattr(g, "_wm_rev", None))
+        feed = ops.conv3x3_dgrad_bwdstats_supported(64, 64, dt) and ops.conv3x3_dgrad_applyfused_supported(64, 64, dt) and x.src is not None
+        if feed:
+            dy, gx, part = ops.conv3x3_dgrad_applyfused(g, y, cx.stats, coef, wpt, x.t, x.scale, x.shift, reverse=d)
+            pcoef = ops.conv3x3_wgrad(x.t, 64, x.scale, x.shift, dy, dw, accumulate, perm_dev=self._fperm_dev, reverse=not d,
+                                      fin=engine.fin_rider(x, part, grads, accumulate))
+            x.bwd = (gx, part, pcoef, gx._version)
+        else:
+            dy, gx, _ = ops.conv3x3_dgrad_applyfused(g, y, cx.stats, coef, wpt, reverse=d)
+            ops.conv3x3_wgrad(x.t, 64, x.scale, x.shift, dy, dw, accumulate, perm_dev=self._fperm_dev, reverse=not d)
+        gx._wm_rev = d
+        img16 = engine.image_to_act(ctx.image, dt)
+        ops.conv3x3_wgrad(img16.t, 16, None, None, dy, dw, accumulate, perm_dev=self._iperm_dev)
+        ops.concat_side_msg_wgrad(dy, ctx.message, dw, accumulate, 0, self.message_length)
+        return gx
 
     def _bump_bn_counters(self):
         for m in self.modules():

@@ -279,6 +279,50 @@ def conv3x3_fwd(x, wp, bias, in_scale, in_shift, want_stats, Cin=None, reverse=F
     return y, st
 
 
+def conv3x3_fwd_addin(x, wp, in_scale, in_shift, addend, reverse=False):
+    """dense 64 -> 64 forward conv (16-bit dtypes) whose epilogue adds `addend` [B,H,W,64] before the BatchNorm statistics:
+    y = conv3x3(relu(in_scale*x + in_shift), wp) + addend.  Returns (y, stat partials)."""
+    _need_cuda(x, wp, addend)
+    B, H, W, C = x.shape
+    assert C == 64 and tuple(wp.shape) == (9, 64, 64) and addend.shape == x.shape and addend.dtype == x.dtype and x.is_contiguous() and addend.is_contiguous()
+    y = torch.empty_like(x)
+    st = torch.empty(conv3x3_nparts(B, H, W, 64, 64, x.dtype), 2, 64, device=x.device, dtype=torch.float32)
+    info = {"B": B, "H": H, "W": W, "Cin": 64, "CoutP": 64, "xform": True, "dtype": x.dtype, "addin": True}
+    rc = _timed("conv3x3_fwd", info, lambda: _lib.lib().wm_conv3x3_fwd_addin(_p(x), _p(wp), _p(in_scale), _p(in_shift), _p(addend), _p(y), _p(st), c_int(B),
+                                                                             c_int(H), c_int(W), c_int(dtype_id(x)), _sweep(reverse), _stream()))
+    _lib.check(rc, "wm_conv3x3_fwd_addin")
+    return y, st
+
+
+def concat_side_fwd(img, w, bias, msg, dtype, c_msg, L, c_img):
+    """P [B,H,W,64] = conv3(image channels of w) + bias + the message term (hidden_models/encoder.py:34-41 without the concat):
+    img [B,3,H,W] f32, w [64,Cin,3,3] f32, msg [B,L] f32."""
+    _need_cuda(img, w, msg)
+    B, _, H, W = img.shape
+    Cin = w.shape[1]
+    assert w.shape[0] == 64 and img.shape[1] == 3 and img.dtype == torch.float32 and img.is_contiguous() and w.is_contiguous()
+    msg = msg.contiguous().float()
+    P = torch.empty(B, H, W, 64, device=img.device, dtype=dtype)
+    wside = torch.empty(64 * 32, device=img.device, dtype=dtype)
+    mbias = torch.empty(B, 9, 64, device=img.device, dtype=torch.float32)
+    rc = _lib.lib().wm_concat_side_fwd(_p(img), _p(w), _p(bias), _p(msg), _p(wside), _p(mbias), _p(P), c_int(B), c_int(H), c_int(W), c_int(Cin),
+                                       c_int(c_msg), c_int(L), c_int(c_img), c_int(dt_id(dtype)), _stream())
+    _lib.check(rc, "wm_concat_side_fwd")
+    return P
+
+
+def concat_side_msg_wgrad(dy, msg, dw, accumulate, c_msg, L):
+    """dw[:, c_msg + l, tap] (+)= sum_b msg[b,l] * (sum of dy[b] over the pixels for which the tap lies inside the image)"""
+    B, H, W, C = dy.shape
+    assert C == 64 and dy.is_contiguous() and dw.is_contiguous() and dw.shape[0] == 64
+    msg = msg.contiguous().float()
+    partial = torch.empty(B, 16, 64, device=dy.device, dtype=torch.float32)
+    S = torch.empty(B, 9, 64, device=dy.device, dtype=torch.float32)
+    rc = _lib.lib().wm_concat_side_msg_wgrad(_p(dy), _p(msg), _p(partial), _p(S), _p(dw), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W),
+                                             c_int(dw.shape[1]), c_int(c_msg), c_int(L), c_int(dtype_id(dy)), _stream())
+    _lib.check(rc, "wm_concat_side_msg_wgrad")
+
+
 def bn_finalize(partials, C, CP, count, gamma, beta, running_mean, running_var, momentum, eps):
     dev = partials.device
     out = torch.empty(4, CP, device=dev, dtype=torch.float32)  # scale, shift, mean, invstd
