@@ -289,10 +289,12 @@ int wm_conv1x1_head_fwd(const void* y, int ldy, const float* scale, const float*
                         int dtype, void* stream);
 /* backward: gout f32 NCHW [B,Cout,H,W] (for act=1 the caller passes the gradient wrt the
  * pre-sigmoid logits) -> g NHWC dtype [B,H,W,Cin] (gradient wrt the ReLU output), and
- * partial sums for dw[Cout,Cin], dbias[Cout]: partials f32[nparts][Cout*(Cin+1)]. */
+ * partial sums for dw[Cout,Cin], dbias[Cout]: partials f32[nparts][Cout*(Cin+1)].
+ * bn_partials (may be NULL): f32[nparts][2][Cin] = per-workgroup sum(gz), sum(gz*y) of the ConvBNRelu that produced y (gz = g as
+ * stored * [scale*y+shift > 0]) -- the rows wm_bn_bwd_finalize_raw takes, so that layer needs no wm_bn_bwd_reduce pass. */
 int wm_conv1x1_head_nparts(size_t npix);
 int wm_conv1x1_head_bwd(const void* y, int ldy, const float* scale, const float* shift, const float* w,
-                        const float* gout, void* g, int ldg, float* partials, int B, size_t hw, int Cin,
+                        const float* gout, void* g, int ldg, float* partials, float* bn_partials, int B, size_t hw, int Cin,
                         int Cout, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ UNet pieces

@@ -161,3 +161,23 @@ def test_flat_adam_state_interchanges_with_torch_optim_adam():
     f2 = _FlatAdam(nets)
     f2.load_state_dict(legacy)
     assert f2.step_count == 5 and f2.param_groups[0]["lr"] == 1e-4 and torch.equal(f2._m[1], flat._m[1])
+
+
+def test_median_selection_networks_of_the_attack_kernel():
+    """csrc/attacks.hip selects the median of 9 / 25 taps with min/max exchange networks (Devillard's opt_med9 / opt_med25 orders):
+    replay the exchange lists parsed from the kernel source on random vectors (with ties) against numpy's median"""
+    import numpy as np
+    src = open(os.path.join(ROOT, "video_watermarking_forgery_detection_amd", "csrc", "attacks.hip")).read()
+    rng = np.random.RandomState(0)
+    for n, out in ((9, 4), (25, 12)):
+        body = src[src.index(f"median_select<{n}>(float (&v)[{n}])"):]
+        body = body[:body.index("return")]
+        ces = [(int(a), int(b)) for a, b in re.findall(r"WM_CE\((\d+), (\d+)\)", body)]
+        assert len(ces) == (19 if n == 9 else 99)
+        for trial in range(4000):
+            v = rng.randint(0, 6 if trial % 2 else 1000, size=n).astype(np.float64)   # every other trial is full of ties
+            w = v.copy()
+            for a, b in ces:
+                lo, hi = min(w[a], w[b]), max(w[a], w[b])
+                w[a], w[b] = lo, hi
+            assert w[out] == np.sort(v)[n // 2], (n, trial)

@@ -14,56 +14,88 @@ namespace {
 
 struct W9 { float w[9]; };
 
+// grid = (column blocks of 256, rows, planes): no 64-bit div/mod per pixel, a wave reads 3 x 256 B of contiguous row data
 __global__ __launch_bounds__(256) void stencil3_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H,
                                                        int W, W9 k) {
-    const size_t total = (size_t)N * H * W;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int w = (int)(i % W);
-        const int h = (int)((i / W) % H);
-        const float* p = x + (i - (size_t)h * W - w);  // plane base
-        float acc = 0.f;
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= W) return;
+    for (int n = blockIdx.z; n < N; n += gridDim.z) {
+        const float* p = x + (size_t)n * H * W;
+        for (int h = blockIdx.y; h < H; h += gridDim.y) {
+            float acc = 0.f;
 #pragma unroll
-        for (int dh = -1; dh <= 1; ++dh) {
-            const int hh = h + dh;
-            if (hh < 0 || hh >= H) continue;
-#pragma unroll
-            for (int dw = -1; dw <= 1; ++dw) {
-                const int ww = w + dw;
-                if (ww < 0 || ww >= W) continue;
-                acc += k.w[(dh + 1) * 3 + (dw + 1)] * p[(size_t)hh * W + ww];
+            for (int dh = -1; dh <= 1; ++dh) {
+                const int hh = h + dh;
+                if (hh < 0 || hh >= H) continue;
+                const float* r = p + (size_t)hh * W;
+                const float l = w > 0 ? r[w - 1] : 0.f, c = r[w], rt = w + 1 < W ? r[w + 1] : 0.f;
+                acc += k.w[(dh + 1) * 3] * l + k.w[(dh + 1) * 3 + 1] * c + k.w[(dh + 1) * 3 + 2] * rt;
             }
+            y[(size_t)n * H * W + (size_t)h * W + w] = acc;
         }
-        y[i] = acc;
     }
 }
 
-// ---- median: rank by counting (stable tie-break by tap index), K2 = k*k taps
+// ---- median of K2 = k*k taps (zero padded).  The VALUE comes from a min/max selection network (19 exchanges for 9 taps, 99 for 25:
+// Devillard's opt_med9 / opt_med25 orders) instead of K2^2 rank comparisons; the tap INDEX the backward needs keeps the stable
+// tie-break of the rank form (among equal values the one with the lowest tap index ranks first): with lt = #{v < med}, the
+// selected tap is the (K2/2 - lt)-th tap equal to med.
+#define WM_CE(a, b) { const float lo_ = fminf(v[a], v[b]); v[b] = fmaxf(v[a], v[b]); v[a] = lo_; }
+template <int K2> __device__ __forceinline__ float median_select(float (&v)[K2]);
+template <> __device__ __forceinline__ float median_select<9>(float (&v)[9]) {
+    WM_CE(1, 2) WM_CE(4, 5) WM_CE(7, 8) WM_CE(0, 1) WM_CE(3, 4) WM_CE(6, 7) WM_CE(1, 2) WM_CE(4, 5) WM_CE(7, 8) WM_CE(0, 3)
+    WM_CE(5, 8) WM_CE(4, 7) WM_CE(3, 6) WM_CE(1, 4) WM_CE(2, 5) WM_CE(4, 7) WM_CE(4, 2) WM_CE(6, 4) WM_CE(4, 2)
+    return v[4];
+}
+template <> __device__ __forceinline__ float median_select<25>(float (&v)[25]) {
+    WM_CE(0, 1) WM_CE(3, 4) WM_CE(2, 4) WM_CE(2, 3) WM_CE(6, 7) WM_CE(5, 7) WM_CE(5, 6) WM_CE(9, 10) WM_CE(8, 10) WM_CE(8, 9)
+    WM_CE(12, 13) WM_CE(11, 13) WM_CE(11, 12) WM_CE(15, 16) WM_CE(14, 16) WM_CE(14, 15) WM_CE(18, 19) WM_CE(17, 19) WM_CE(17, 18)
+    WM_CE(21, 22) WM_CE(20, 22) WM_CE(20, 21) WM_CE(23, 24) WM_CE(2, 5) WM_CE(3, 6) WM_CE(0, 6) WM_CE(0, 3) WM_CE(4, 7) WM_CE(1, 7)
+    WM_CE(1, 4) WM_CE(11, 14) WM_CE(8, 14) WM_CE(8, 11) WM_CE(12, 15) WM_CE(9, 15) WM_CE(9, 12) WM_CE(13, 16) WM_CE(10, 16)
+    WM_CE(10, 13) WM_CE(20, 23) WM_CE(17, 23) WM_CE(17, 20) WM_CE(21, 24) WM_CE(18, 24) WM_CE(18, 21) WM_CE(19, 22) WM_CE(8, 17)
+    WM_CE(9, 18) WM_CE(0, 18) WM_CE(0, 9) WM_CE(10, 19) WM_CE(1, 19) WM_CE(1, 10) WM_CE(11, 20) WM_CE(2, 20) WM_CE(2, 11)
+    WM_CE(12, 21) WM_CE(3, 21) WM_CE(3, 12) WM_CE(13, 22) WM_CE(4, 22) WM_CE(4, 13) WM_CE(14, 23) WM_CE(5, 23) WM_CE(5, 14)
+    WM_CE(15, 24) WM_CE(6, 24) WM_CE(6, 15) WM_CE(7, 16) WM_CE(7, 19) WM_CE(13, 21) WM_CE(15, 23) WM_CE(7, 13) WM_CE(7, 15)
+    WM_CE(1, 9) WM_CE(3, 11) WM_CE(5, 17) WM_CE(11, 17) WM_CE(9, 17) WM_CE(4, 10) WM_CE(6, 12) WM_CE(7, 14) WM_CE(4, 6) WM_CE(4, 7)
+    WM_CE(12, 14) WM_CE(10, 14) WM_CE(6, 7) WM_CE(10, 12) WM_CE(6, 10) WM_CE(6, 17) WM_CE(12, 17) WM_CE(7, 17) WM_CE(7, 10)
+    WM_CE(12, 18) WM_CE(7, 12) WM_CE(10, 18) WM_CE(12, 20) WM_CE(10, 20) WM_CE(10, 12)
+    return v[12];
+}
+#undef WM_CE
+
 template <int K>
 __global__ __launch_bounds__(256) void median_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          int8_t* __restrict__ idx, int N, int H, int W) {
     constexpr int K2 = K * K, R = K / 2;
-    const size_t total = (size_t)N * H * W;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int w = (int)(i % W);
-        const int h = (int)((i / W) % H);
-        const float* p = x + (i - (size_t)h * W - w);
-        float v[K2];
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= W) return;
+    for (int n = blockIdx.z; n < N; n += gridDim.z) {
+        const float* p = x + (size_t)n * H * W;
+        for (int h = blockIdx.y; h < H; h += gridDim.y) {
+            float v[K2], s[K2];
 #pragma unroll
-        for (int t = 0; t < K2; ++t) {
-            const int hh = h + t / K - R, ww = w + t % K - R;
-            v[t] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? p[(size_t)hh * W + ww] : 0.f;
+            for (int t = 0; t < K2; ++t) {
+                const int hh = h + t / K - R, ww = w + t % K - R;
+                v[t] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? p[(size_t)hh * W + ww] : 0.f;
+                s[t] = v[t];
+            }
+            const float med = median_select<K2>(s);
+            const size_t o = (size_t)n * H * W + (size_t)h * W + w;
+            y[o] = med;
+            if (idx) {
+                int lt = 0;
+#pragma unroll
+                for (int t = 0; t < K2; ++t) lt += v[t] < med ? 1 : 0;
+                int want = K2 / 2 - lt, sel = 0, seen = 0;
+#pragma unroll
+                for (int t = 0; t < K2; ++t) {
+                    const bool eq = v[t] == med;
+                    if (eq && seen == want) sel = t;
+                    seen += eq ? 1 : 0;
+                }
+                idx[o] = (int8_t)sel;
+            }
         }
-        float med = 0.f;
-        int sel = 0;
-#pragma unroll
-        for (int a = 0; a < K2; ++a) {
-            int rank = 0;
-#pragma unroll
-            for (int b = 0; b < K2; ++b) rank += (v[b] < v[a] || (v[b] == v[a] && b < a)) ? 1 : 0;
-            if (rank == K2 / 2) { med = v[a]; sel = a; }
-        }
-        y[i] = med;
-        if (idx) idx[i] = (int8_t)sel;
     }
 }
 
@@ -71,22 +103,23 @@ template <int K>
 __global__ __launch_bounds__(256) void median_bwd_kernel(const float* __restrict__ gy, const int8_t* __restrict__ idx,
                                                          float* __restrict__ gx, int N, int H, int W) {
     constexpr int R = K / 2;
-    const size_t total = (size_t)N * H * W;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int w = (int)(i % W);
-        const int h = (int)((i / W) % H);
-        const size_t base = i - (size_t)h * W - w;
-        float acc = 0.f;
-        // output pixel (oh,ow) selected tap t  <=>  it points at input (oh + t/K - R, ow + t%K - R)
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= W) return;
+    for (int n = blockIdx.z; n < N; n += gridDim.z) {
+        const size_t base = (size_t)n * H * W;
+        for (int h = blockIdx.y; h < H; h += gridDim.y) {
+            float acc = 0.f;
+            // output pixel (oh,ow) selected tap t  <=>  it points at input (oh + t/K - R, ow + t%K - R)
 #pragma unroll
-        for (int t = 0; t < K * K; ++t) {
-            const int oh = h - (t / K - R), ow = w - (t % K - R);
-            if (oh >= 0 && oh < H && ow >= 0 && ow < W) {
-                const size_t o = base + (size_t)oh * W + ow;
-                if (idx[o] == t) acc += gy[o];
+            for (int t = 0; t < K * K; ++t) {
+                const int oh = h - (t / K - R), ow = w - (t % K - R);
+                if (oh >= 0 && oh < H && ow >= 0 && ow < W) {
+                    const size_t o = base + (size_t)oh * W + ow;
+                    if (idx[o] == t) acc += gy[o];
+                }
             }
+            gx[base + (size_t)h * W + w] = acc;
         }
-        gx[i] = acc;
     }
 }
 
@@ -175,42 +208,69 @@ __device__ __forceinline__ void axis_range(int i, int in, int out, float scale, 
     if (hi > out - 1) hi = out - 1;
 }
 
+// gather-form backward (deterministic): input pixel (ih, iw) collects from the outputs that used it.  The interpolation is
+// separable, so the weights along x of the candidate output columns are evaluated ONCE per input pixel (not once per candidate
+// output row as before: 10x fewer cubic evaluations at the 0.7x resize).  2-D launch: no 64-bit div/mod per pixel.
 template <int KIND>
 __global__ __launch_bounds__(256) void resample_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ yc,
                                                            float* __restrict__ gx, int N, int H, int W, int h0, int hs,
                                                            int w0, int ws, int OH, int OW) {
+    constexpr int MAXC = 24;   // candidate output columns kept in registers; wider footprints (scale < 0.2) evaluate on the fly
     const float sh = (float)hs / (float)OH, sw = (float)ws / (float)OW;
-    const size_t total = (size_t)N * H * W;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int w = (int)(i % W);
-        const int h = (int)((i / W) % H);
-        const size_t n = i / ((size_t)W * H);
-        const int ih = h - h0, iw = w - w0;
-        float acc = 0.f;
-        if (ih >= 0 && ih < hs && iw >= 0 && iw < ws) {
-            int ylo, yhi, xlo, xhi;
-            axis_range<KIND>(ih, hs, OH, sh, ylo, yhi);
-            axis_range<KIND>(iw, ws, OW, sw, xlo, xhi);
-            const float* g = gy + n * (size_t)OH * OW;
-            const float* yy = yc ? yc + n * (size_t)OH * OW : nullptr;
-            for (int oy = ylo; oy <= yhi; ++oy) {
-                const float wy = axis_weight<KIND>(oy, ih, hs, sh);
-                if (wy == 0.f) continue;
-                float row = 0.f;
-                for (int ox = xlo; ox <= xhi; ++ox) {
-                    const float wx = axis_weight<KIND>(ox, iw, ws, sw);
-                    if (wx == 0.f) continue;
-                    float gg = g[(size_t)oy * OW + ox];
-                    if (yy) {  // clamp(0,1) passed the gradient only strictly inside the interval
-                        const float v = yy[(size_t)oy * OW + ox];
-                        if (!(v > 0.f && v < 1.f)) gg = 0.f;
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= W) return;
+    const int iw = w - w0;
+    int xlo = 0, xhi = -1;
+    float wxs[MAXC];
+    const bool in_x = iw >= 0 && iw < ws;
+    if (in_x) {
+        axis_range<KIND>(iw, ws, OW, sw, xlo, xhi);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) wxs[c] = (xlo + c <= xhi) ? axis_weight<KIND>(xlo + c, iw, ws, sw) : 0.f;
+    }
+    const bool wide = xhi - xlo + 1 > MAXC;
+    for (int n = blockIdx.z; n < N; n += gridDim.z) {
+        const float* g = gy + (size_t)n * OH * OW;
+        const float* yy = yc ? yc + (size_t)n * OH * OW : nullptr;
+        for (int h = blockIdx.y; h < H; h += gridDim.y) {
+            const int ih = h - h0;
+            float acc = 0.f;
+            if (in_x && ih >= 0 && ih < hs) {
+                int ylo, yhi;
+                axis_range<KIND>(ih, hs, OH, sh, ylo, yhi);
+                for (int oy = ylo; oy <= yhi; ++oy) {
+                    const float wy = axis_weight<KIND>(oy, ih, hs, sh);
+                    if (wy == 0.f) continue;
+                    float row = 0.f;
+                    const float* gr = g + (size_t)oy * OW;
+                    const float* yr = yy ? yy + (size_t)oy * OW : nullptr;
+#pragma unroll
+                    for (int c = 0; c < MAXC; ++c) {
+                        const int ox = xlo + c;
+                        if (ox > xhi || wxs[c] == 0.f) continue;
+                        float gg = gr[ox];
+                        if (yr) {  // clamp(0,1) passed the gradient only strictly inside the interval
+                            const float v = yr[ox];
+                            if (!(v > 0.f && v < 1.f)) gg = 0.f;
+                        }
+                        row += wxs[c] * gg;
                     }
-                    row += wx * gg;
+                    if (wide)
+                        for (int ox = xlo + MAXC; ox <= xhi; ++ox) {
+                            const float wx = axis_weight<KIND>(ox, iw, ws, sw);
+                            if (wx == 0.f) continue;
+                            float gg = gr[ox];
+                            if (yr) {
+                                const float v = yr[ox];
+                                if (!(v > 0.f && v < 1.f)) gg = 0.f;
+                            }
+                            row += wx * gg;
+                        }
+                    acc += wy * row;
                 }
-                acc += wy * row;
             }
+            gx[(size_t)n * H * W + (size_t)h * W + w] = acc;
         }
-        gx[i] = acc;
     }
 }
 
@@ -230,7 +290,8 @@ extern "C" int wm_stencil3_fwd(const float* x, float* y, int N, int H, int W, co
     WM_REQUIRE(x && y && w9 && N > 0 && H > 0 && W > 0, WM_E_BADARG, "wm_stencil3_fwd: bad arguments");
     W9 k;
     for (int i = 0; i < 9; ++i) k.w[i] = w9[i];
-    hipLaunchKernelGGL(stencil3_kernel, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, k);
+    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)(H < 65535 ? H : 65535), (unsigned)(N < 65535 ? N : 65535));
+    hipLaunchKernelGGL(stencil3_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, k);
     WM_LAUNCH_CHECK("wm_stencil3_fwd");
     return WM_OK;
 }
@@ -238,7 +299,7 @@ extern "C" int wm_stencil3_fwd(const float* x, float* y, int N, int H, int W, co
 extern "C" int wm_median_fwd(const float* x, float* y, int8_t* idx, int N, int H, int W, int k, void* stream) {
     WM_REQUIRE(x && y && N > 0 && H > 0 && W > 0, WM_E_BADARG, "wm_median_fwd: bad arguments");
     WM_REQUIRE(k == 3 || k == 5, WM_E_SHAPE, "wm_median_fwd: kernel size must be 3 or 5 (got %d)", k);
-    const dim3 grid(grid_for((size_t)N * H * W)), block(256);
+    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)(H < 65535 ? H : 65535), (unsigned)(N < 65535 ? N : 65535)), block(256);
     if (k == 3) hipLaunchKernelGGL(median_fwd_kernel<3>, grid, block, 0, (hipStream_t)stream, x, y, idx, N, H, W);
     else hipLaunchKernelGGL(median_fwd_kernel<5>, grid, block, 0, (hipStream_t)stream, x, y, idx, N, H, W);
     WM_LAUNCH_CHECK("wm_median_fwd");
@@ -248,7 +309,7 @@ extern "C" int wm_median_fwd(const float* x, float* y, int8_t* idx, int N, int H
 extern "C" int wm_median_bwd(const float* gy, const int8_t* idx, float* gx, int N, int H, int W, int k, void* stream) {
     WM_REQUIRE(gy && idx && gx && N > 0 && H > 0 && W > 0, WM_E_BADARG, "wm_median_bwd: bad arguments");
     WM_REQUIRE(k == 3 || k == 5, WM_E_SHAPE, "wm_median_bwd: kernel size must be 3 or 5 (got %d)", k);
-    const dim3 grid(grid_for((size_t)N * H * W)), block(256);
+    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)(H < 65535 ? H : 65535), (unsigned)(N < 65535 ? N : 65535)), block(256);
     if (k == 3) hipLaunchKernelGGL(median_bwd_kernel<3>, grid, block, 0, (hipStream_t)stream, gy, idx, gx, N, H, W);
     else hipLaunchKernelGGL(median_bwd_kernel<5>, grid, block, 0, (hipStream_t)stream, gy, idx, gx, N, H, W);
     WM_LAUNCH_CHECK("wm_median_bwd");
@@ -280,7 +341,7 @@ extern "C" int wm_resample_bwd(const float* gy, const float* y_clamped, float* g
     WM_REQUIRE(gy && gx, WM_E_BADARG, "wm_resample_bwd: null pointer");
     int rc = resample_check("wm_resample_bwd", N, H, W, h0, hs, w0, ws, OH, OW, kind);
     if (rc) return rc;
-    const dim3 grid(grid_for((size_t)N * H * W)), block(256);
+    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)(H < 65535 ? H : 65535), (unsigned)(N < 65535 ? N : 65535)), block(256);
     if (kind == WM_BILINEAR) hipLaunchKernelGGL(resample_bwd_kernel<WM_BILINEAR>, grid, block, 0, (hipStream_t)stream, gy, y_clamped, gx, N, H, W, h0, hs, w0, ws, OH, OW);
     else hipLaunchKernelGGL(resample_bwd_kernel<WM_BICUBIC>, grid, block, 0, (hipStream_t)stream, gy, y_clamped, gx, N, H, W, h0, hs, w0, ws, OH, OW);
     WM_LAUNCH_CHECK("wm_resample_bwd");

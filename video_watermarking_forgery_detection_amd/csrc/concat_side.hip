@@ -36,22 +36,32 @@ __device__ __forceinline__ int cls_of(int h, int w, int H, int W) {
 }
 
 #ifndef WM_H16_F16
-// mbias[b][cls][co] = bias[co] + sum over the taps valid in cls of sum_l w[co][c0 + l][tap] * m[b][l]   (w: [Cout][Cin][3][3] f32)
+// mbias[b][cls][co] = bias[co] + sum_l m[b][l] * (sum over the taps valid in cls of w[co][c0 + l][tap])   (w: [Cout][Cin][3][3] f32)
+// one workgroup per border class: a thread folds its channel's L x 9 weights ONCE, then walks the samples
+constexpr int MAXL = 64;
 __global__ __launch_bounds__(64) void msg_bias_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ msg,
-                                                      float* __restrict__ mbias, int Cin, int c0, int L) {
-    const int b = blockIdx.x / 9, cls = blockIdx.x % 9, co = threadIdx.x;
+                                                      float* __restrict__ mbias, int B, int Cin, int c0, int L) {
+    const int cls = blockIdx.x, co = threadIdx.x;
     const int rc = cls / 3, cc = cls % 3;
-    float acc = bias ? bias[co] : 0.f;
-    for (int l = 0; l < L; ++l) {
-        const float m = msg[(size_t)b * L + l];
-        const float* wl = w + ((size_t)co * Cin + c0 + l) * 9;
-        float t = 0.f;
+    float t[MAXL];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-            if (tap_valid(tap / 3, rc) && tap_valid(tap % 3, cc)) t += wl[tap];
-        acc = __builtin_fmaf(t, m, acc);
+    for (int l = 0; l < MAXL; ++l) {
+        t[l] = 0.f;
+        if (l < L) {
+            const float* wl = w + ((size_t)co * Cin + c0 + l) * 9;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                if (tap_valid(tap / 3, rc) && tap_valid(tap % 3, cc)) t[l] += wl[tap];
+        }
     }
-    mbias[((size_t)b * 9 + cls) * 64 + co] = acc;
+    const float b0 = bias ? bias[co] : 0.f;
+    for (int b = 0; b < B; ++b) {
+        float acc = b0;
+#pragma unroll
+        for (int l = 0; l < MAXL; ++l)
+            if (l < L) acc = __builtin_fmaf(t[l], msg[(size_t)b * L + l], acc);
+        mbias[((size_t)b * 9 + cls) * 64 + co] = acc;
+    }
 }
 
 // dW of the message channels: dw[co][c0 + l][tap] (+)= sum_b m[b][l] * S[b][tap][co]
@@ -70,8 +80,9 @@ struct SideArgs {
     const hx_t* wside;     // [64][32]: row = output channel, k = tap*3 + c (27 used), packed by side_pack_kernel
     const float* mbias;    // [B][9][64]
     hx_t* P;               // [B][H][W][64]
-    int B, H, W, tilesX, tilesY;
+    int B, H, W, tilesX, tilesY, stripsX;
 };
+constexpr int XT = 4;   // 16x16 tiles per workgroup (a 16 x 64 strip): the filter fragments and the launch cost are shared
 
 // wside[co][k] <- w[co][c0 + c][tap], k = 3*tap + c
 __global__ void side_pack_kernel(const float* __restrict__ w, hx_t* __restrict__ wside, int Cin, int c0) {
@@ -87,16 +98,17 @@ __global__ void side_pack_kernel(const float* __restrict__ w, hx_t* __restrict__
 // operand (accumulator rows = channels): A row 4q'+i of fragment nf holds channel 16q' + 4nf + i, so lane (p, q) ends up with the 16
 // adjacent channels [16q, 16q+16) of pixel p -- two 16-byte stores, no transpose (the layout trick of conv3x3_ws.hip)
 __global__ __launch_bounds__(256) void concat_side_kernel(SideArgs a) {
-    __shared__ float sImg[3][HS][HS + 1];
+    __shared__ float sImg[3][HS][XT * TS + 3];
+    constexpr int SW = XT * TS + 2;   // halo columns of the strip
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int t = blockIdx.x;
-    const int tx = t % a.tilesX; t /= a.tilesX;
+    const int sx = t % a.stripsX; t /= a.stripsX;
     const int ty = t % a.tilesY; t /= a.tilesY;
-    const int b = t, y0 = ty * TS, x0 = tx * TS;
+    const int b = t, y0 = ty * TS, xs = sx * XT * TS;
     const size_t plane = (size_t)a.H * a.W;
-    for (int i = tid; i < 3 * HS * HS; i += 256) {
-        const int c = i / (HS * HS), r = (i / HS) % HS, col = i % HS;
-        const int gy = y0 - 1 + r, gx = x0 - 1 + col;
+    for (int i = tid; i < 3 * HS * SW; i += 256) {
+        const int c = i / (HS * SW), r = (i / SW) % HS, col = i % SW;
+        const int gy = y0 - 1 + r, gx = xs - 1 + col;
         float v = 0.f;
         if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = a.img[((size_t)b * 3 + c) * plane + (size_t)gy * a.W + gx];
         sImg[c][r][col] = v;
@@ -109,58 +121,72 @@ __global__ __launch_bounds__(256) void concat_side_kernel(SideArgs a) {
         afr[nf] = *reinterpret_cast<const hx8*>(a.wside + co * 32 + 8 * q);
     }
     __syncthreads();
+    for (int xt = 0; xt < XT; ++xt) {
+        const int x0 = xs + xt * TS;
+        if (x0 >= a.W) break;   // (workgroup-uniform)
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int row = wave * 4 + rr;
-        const int gy = y0 + row, gx = x0 + p;
-        // B operand: lane (p, q) = pixel p, k = 8q .. 8q+7
-        unsigned bw[4];
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = wave * 4 + rr;
+            const int gy = y0 + row, gx = x0 + p;
+            // B operand: lane (p, q) = pixel p, k = 8q .. 8q+7
+            unsigned bw[4];
 #pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) {
-            float v[2];
+            for (int e2 = 0; e2 < 4; ++e2) {
+                float v[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int k = 8 * q + 2 * e2 + u;
-                const int tap = k / 3, c = k - 3 * tap;
-                v[u] = k < 27 ? sImg[c][row + tap / 3][p + tap % 3] : 0.f;
+                for (int u = 0; u < 2; ++u) {
+                    const int k = 8 * q + 2 * e2 + u;
+                    const int tap = k / 3, c = k - 3 * tap;
+                    v[u] = k < 27 ? sImg[c][row + tap / 3][xt * TS + p + tap % 3] : 0.f;
+                }
+                bw[e2] = h16_pack<hx_t>(v[0], v[1]);
             }
-            bw[e2] = h16_pack<hx_t>(v[0], v[1]);
-        }
-        const hx8 bfr = __builtin_bit_cast(hx8, u32x4{bw[0], bw[1], bw[2], bw[3]});
-        // every lane takes part in the MFMAs of its wave; only the stores are predicated
-        const bool inb = gy < a.H && gx < a.W;
-        const int cy = gy < a.H ? gy : a.H - 1, cx = gx < a.W ? gx : a.W - 1;
-        const float* mb = a.mbias + ((size_t)b * 9 + cls_of(cy, cx, a.H, a.W)) * 64 + 16 * q;
-        unsigned pk[8];
+            const hx8 bfr = __builtin_bit_cast(hx8, u32x4{bw[0], bw[1], bw[2], bw[3]});
+            // every lane takes part in the MFMAs of its wave; only the stores are predicated
+            const bool inb = gy < a.H && gx < a.W;
+            const int cy = gy < a.H ? gy : a.H - 1, cx = gx < a.W ? gx : a.W - 1;
+            const float* mb = a.mbias + ((size_t)b * 9 + cls_of(cy, cx, a.H, a.W)) * 64 + 16 * q;
+            unsigned pk[8];
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const f32x4 init = *reinterpret_cast<const f32x4*>(mb + 4 * nf);
-            const f32x4 acc = HX::mfma16(afr[nf], bfr, init);
-            pk[2 * nf] = h16_pack<hx_t>(acc[0], acc[1]);
-            pk[2 * nf + 1] = h16_pack<hx_t>(acc[2], acc[3]);
-        }
-        if (inb) {
-            hx_t* o = a.P + (((size_t)b * a.H + gy) * a.W + gx) * 64 + 16 * q;
-            *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-            *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+            for (int nf = 0; nf < 4; ++nf) {
+                const f32x4 init = *reinterpret_cast<const f32x4*>(mb + 4 * nf);
+                const f32x4 acc = HX::mfma16(afr[nf], bfr, init);
+                pk[2 * nf] = h16_pack<hx_t>(acc[0], acc[1]);
+                pk[2 * nf + 1] = h16_pack<hx_t>(acc[2], acc[3]);
+            }
+            if (inb) {
+                hx_t* o = a.P + (((size_t)b * a.H + gy) * a.W + gx) * 64 + 16 * q;
+                *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+            }
         }
     }
 }
 
 // per-sample column sums of dy [B][HW][64]: partial[b][slice][64] (f32), deterministic two-stage
-constexpr int DSL = 16;   // slices per sample
+constexpr int DSL = 64;   // slices per sample
 __global__ __launch_bounds__(256) void dy_total_kernel(const hx_t* __restrict__ dy, float* __restrict__ partial, size_t HW) {
     const int b = blockIdx.x / DSL, sl = blockIdx.x % DSL;
     const int vec = threadIdx.x & 7, pl = threadIdx.x >> 3;   // 8 vectors of 8 channels per pixel, 32 pixel lanes
     const size_t per = (HW + DSL - 1) / DSL, p0 = (size_t)sl * per, p1 = p0 + per < HW ? p0 + per : HW;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const hx_t* base = dy + (size_t)b * HW * 64 + vec * 8;
-    for (size_t px = p0 + pl; px < p1; px += 32) {
+    size_t px = p0 + pl;
+    for (; px + 96 < p1; px += 128) {   // four independent 16-byte loads in flight per thread
+        u32x4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const u32x4*>(base + (px + 32 * u) * 64);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[2 * e] += HX::lo(w[u][e]); acc[2 * e + 1] += HX::hi(w[u][e]); }
+    }
+    for (; px < p1; px += 32) {
         const u32x4 w = *reinterpret_cast<const u32x4*>(base + px * 64);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { acc[2 * e] += HX::lo(w[e]); acc[2 * e + 1] += HX::hi(w[e]); }
     }
-    __shared__ float s[32][64];
+    __shared__ float s[32][65];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[pl][vec * 8 + e] = acc[e];
     __syncthreads();
@@ -171,47 +197,66 @@ __global__ __launch_bounds__(256) void dy_total_kernel(const hx_t* __restrict__ 
     }
 }
 
-// S[b][tap][co] = sum of dy over the pixels of sample b for which tap is inside the image
-//             = sum over classes in which the tap is valid of R[b][cls][co];  R[interior] = total - the 8 border classes
-__global__ __launch_bounds__(256) void dy_border_kernel(const hx_t* __restrict__ dy, const float* __restrict__ partial, float* __restrict__ S,
-                                                        int H, int W) {
-    const int b = blockIdx.x, co = threadIdx.x & 63, part = threadIdx.x >> 6;   // 4 pixel lanes x 64 channels
-    __shared__ float R[4][9][64];
-    float r[9];
+// sums of dy over the border pixels of sample b by class: R[b][cls][64] for the 8 border classes (R[b][4] is not written here).
+// grid = (4 edges, B): edge 0 / 1 = first / last row (corners included, split by column class), 2 / 3 = first / last column of the
+// rows between.  16-byte loads, 32 pixel lanes.
+__global__ __launch_bounds__(256) void dy_border_kernel(const hx_t* __restrict__ dy, float* __restrict__ R, int H, int W) {
+    const int edge = blockIdx.x, b = blockIdx.y;
+    const int vec = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const hx_t* base = dy + (size_t)b * H * W * 64 + vec * 8;
+    float acc[3][8];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) r[c] = 0.f;
-    const hx_t* base = dy + (size_t)b * H * W * 64 + co;
-    auto at = [&](int h, int w) { return (float)base[((size_t)h * W + w) * 64]; };
-    for (int w = part; w < W; w += 4) {   // first and last row
-        const int cc = w == 0 ? 0 : (w == W - 1 ? 2 : 1);
-        r[0 * 3 + cc] += at(0, w);
-        r[2 * 3 + cc] += at(H - 1, w);
-    }
-    for (int h = 1 + part; h < H - 1; h += 4) {   // first and last column of the rows between
-        r[1 * 3 + 0] += at(h, 0);
-        r[1 * 3 + 2] += at(h, W - 1);
-    }
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int c = 0; c < 9; ++c) R[part][c][co] = r[c];
+        for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
+    auto add = [&](int h, int w, int slot) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(base + ((size_t)h * W + w) * 64);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[slot][2 * e] += HX::lo(v[e]); acc[slot][2 * e + 1] += HX::hi(v[e]); }
+    };
+    if (edge < 2) {
+        const int h = edge == 0 ? 0 : H - 1;
+        for (int w = pl; w < W; w += 32) add(h, w, w == 0 ? 0 : (w == W - 1 ? 2 : 1));
+    } else {
+        const int w = edge == 2 ? 0 : W - 1;
+        for (int h = 1 + pl; h < H - 1; h += 32) add(h, w, 1);
+    }
+    __shared__ float s[3][32][65];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[c][pl][vec * 8 + e] = acc[c][e];
     __syncthreads();
-    if (part == 0) {
-        float tot = 0.f;
-        for (int sl = 0; sl < DSL; ++sl) tot += partial[((size_t)b * DSL + sl) * 64 + co];
-        float rc[9], border = 0.f;
+    if (threadIdx.x < 192) {
+        const int c = threadIdx.x / 64, co = threadIdx.x % 64;
+        float t = 0.f;
+        for (int k = 0; k < 32; ++k) t += s[c][k][co];
+        // rows: classes (rc, 0..2) with rc = 0 / 2; columns: class (1, 0) / (1, 2) from slot 1 only
+        if (edge < 2) R[((size_t)b * 9 + (edge == 0 ? 0 : 6) + c) * 64 + co] = t;
+        else if (c == 1) R[((size_t)b * 9 + (edge == 2 ? 3 : 5)) * 64 + co] = t;
+    }
+}
+
+// S[b][tap][co] = sum of dy over the pixels of sample b for which tap is inside the image
+//             = sum over the classes in which the tap is valid of R[b][cls][co];  R[interior] = total - the 8 border classes
+__global__ __launch_bounds__(64) void dy_S_kernel(const float* __restrict__ partial, const float* __restrict__ R, float* __restrict__ S) {
+    const int b = blockIdx.x, co = threadIdx.x;
+    float tot = 0.f;
+    for (int sl = 0; sl < DSL; ++sl) tot += partial[((size_t)b * DSL + sl) * 64 + co];
+    float rc[9], border = 0.f;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            rc[c] = (R[0][c][co] + R[1][c][co]) + (R[2][c][co] + R[3][c][co]);
-            if (c != 4) border += rc[c];
-        }
-        rc[4] = tot - border;
+    for (int c = 0; c < 9; ++c) {
+        rc[c] = c == 4 ? 0.f : R[((size_t)b * 9 + c) * 64 + co];
+        border += rc[c];
+    }
+    rc[4] = tot - border;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            float sacc = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        float sacc = 0.f;
 #pragma unroll
-            for (int c = 0; c < 9; ++c)
-                if (tap_valid(tap / 3, c / 3) && tap_valid(tap % 3, c % 3)) sacc += rc[c];
-            S[((size_t)b * 9 + tap) * 64 + co] = sacc;
-        }
+        for (int c = 0; c < 9; ++c)
+            if (tap_valid(tap / 3, c / 3) && tap_valid(tap % 3, c % 3)) sacc += rc[c];
+        S[((size_t)b * 9 + tap) * 64 + co] = sacc;
     }
 }
 
@@ -224,7 +269,7 @@ int WM_HSYM(wm_concat_side_bwd_impl)(const void* dy, const float* msg, float* pa
 
 #ifndef WM_H16_F16
 void wm_launch_msg_bias(const float* w, const float* bias, const float* msg, float* mbias, int B, int Cin, int c0, int L, hipStream_t s) {
-    hipLaunchKernelGGL(msg_bias_kernel, dim3(B * 9), dim3(64), 0, s, w, bias, msg, mbias, Cin, c0, L);
+    hipLaunchKernelGGL(msg_bias_kernel, dim3(9), dim3(64), 0, s, w, bias, msg, mbias, B, Cin, c0, L);
 }
 void wm_launch_msg_wgrad(const float* S, const float* msg, float* dw, int B, int Cin, int c0, int L, int accumulate, hipStream_t s) {
     hipLaunchKernelGGL(msg_wgrad_kernel, dim3(L * 9), dim3(64), 0, s, S, msg, dw, B, Cin, c0, L, accumulate);
@@ -240,15 +285,17 @@ int WM_HSYM(wm_concat_side_fwd_impl)(const float* img, const float* w, const flo
     hipLaunchKernelGGL(side_pack_kernel, dim3(8), dim3(256), 0, s, w, (hx_t*)wside, Cin, c_img);
     SideArgs a;
     a.img = img; a.wside = (const hx_t*)wside; a.mbias = mbias; a.P = (hx_t*)P; a.B = B; a.H = H; a.W = W;
-    a.tilesX = wm_cdiv(W, TS); a.tilesY = wm_cdiv(H, TS);
-    hipLaunchKernelGGL(concat_side_kernel, dim3((unsigned)(B * a.tilesX * a.tilesY)), dim3(256), 0, s, a);
+    a.tilesX = wm_cdiv(W, TS); a.tilesY = wm_cdiv(H, TS); a.stripsX = wm_cdiv(a.tilesX, XT);
+    hipLaunchKernelGGL(concat_side_kernel, dim3((unsigned)(B * a.stripsX * a.tilesY)), dim3(256), 0, s, a);
     return WM_OK;
 }
 
 int WM_HSYM(wm_concat_side_bwd_impl)(const void* dy, const float* msg, float* partial, float* S, float* dw, int accumulate, int B, int H, int W,
                                      int Cin, int c_msg, int L, hipStream_t s) {
+    float* R = partial + (size_t)B * DSL * 64;   // [B][9][64] behind the slice rows
     hipLaunchKernelGGL(dy_total_kernel, dim3(B * DSL), dim3(256), 0, s, (const hx_t*)dy, partial, (size_t)H * W);
-    hipLaunchKernelGGL(dy_border_kernel, dim3(B), dim3(256), 0, s, (const hx_t*)dy, partial, S, H, W);
+    hipLaunchKernelGGL(dy_border_kernel, dim3(4, B), dim3(256), 0, s, (const hx_t*)dy, R, H, W);
+    hipLaunchKernelGGL(dy_S_kernel, dim3(B), dim3(64), 0, s, partial, R, S);
     wm_launch_msg_wgrad(S, msg, dw, B, Cin, c_msg, L, accumulate, s);
     return WM_OK;
 }
@@ -259,7 +306,7 @@ int wm_concat_side_fwd_impl_f16(const float* img, const float* w, const float* b
 int wm_concat_side_bwd_impl_f16(const void* dy, const float* msg, float* partial, float* S, float* dw, int accumulate, int B, int H, int W,
                                 int Cin, int c_msg, int L, hipStream_t s);
 
-extern "C" size_t wm_concat_side_ws_bytes(int B) { return ((size_t)B * 9 * 64 * 2 + (size_t)B * DSL * 64) * sizeof(float) + 64 * 32 * 2; }
+extern "C" int wm_concat_side_partial_rows(void) { return DSL + 9; }   // rows of 64 floats per sample in `partial`
 
 // P[B,H,W,64] = conv3x3 of the image channels [c_img, c_img+3) of w [64][Cin][3][3] over img [B,3,H,W] (f32 NCHW planes, zero padded)
 //               + bias + the message term of channels [c_msg, c_msg+L) for messages msg [B][L]
@@ -267,8 +314,8 @@ extern "C" size_t wm_concat_side_ws_bytes(int B) { return ((size_t)B * 9 * 64 * 
 extern "C" int wm_concat_side_fwd(const float* img, const float* w, const float* bias, const float* msg, void* wside, float* mbias, void* P,
                                   int B, int H, int W, int Cin, int c_msg, int L, int c_img, int dtype, void* stream) {
     WM_REQUIRE(img && w && msg && wside && mbias && P, WM_E_BADARG, "wm_concat_side_fwd: null pointer");
-    WM_REQUIRE(B > 0 && H >= 2 && W >= 2 && L > 0 && c_msg >= 0 && c_img >= 0 && c_msg + L <= Cin && c_img + 3 <= Cin, WM_E_BADARG,
-               "wm_concat_side_fwd: bad shape (H, W >= 2; the channel ranges must lie inside Cin=%d)", Cin);
+    WM_REQUIRE(B > 0 && H >= 2 && W >= 2 && L > 0 && L <= 64 && c_msg >= 0 && c_img >= 0 && c_msg + L <= Cin && c_img + 3 <= Cin, WM_E_BADARG,
+               "wm_concat_side_fwd: bad shape (H, W >= 2; message length <= 64; the channel ranges must lie inside Cin=%d)", Cin);
     WM_REQUIRE(((uintptr_t)P & 15) == 0 && ((uintptr_t)wside & 15) == 0, WM_E_SHAPE, "wm_concat_side_fwd: P / wside must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -280,7 +327,7 @@ extern "C" int wm_concat_side_fwd(const float* img, const float* w, const float*
 }
 
 // dw[co][c_msg + l][tap] (+)= sum_b msg[b][l] * (sum of dy[b] over the pixels for which the tap lies inside the image)
-// dy: [B,H,W,64] dense, 16-bit; partial: f32 [B][16][64] scratch; S: f32 [B][9][64] scratch
+// dy: [B,H,W,64] dense, 16-bit; partial: f32 [B][64 + 9][64] scratch; S: f32 [B][9][64] scratch
 extern "C" int wm_concat_side_msg_wgrad(const void* dy, const float* msg, float* partial, float* S, float* dw, int accumulate, int B, int H,
                                         int W, int Cin, int c_msg, int L, int dtype, void* stream) {
     WM_REQUIRE(dy && msg && partial && S && dw, WM_E_BADARG, "wm_concat_side_msg_wgrad: null pointer");

@@ -69,7 +69,8 @@ template <typename T, int COUT>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ w,
                                                        const float* __restrict__ gout, T* __restrict__ g, int ldg,
-                                                       float* __restrict__ partials, size_t npix, size_t hw, int Cin) {
+                                                       float* __restrict__ partials, size_t npix, size_t hw, int Cin,
+                                                       float* __restrict__ bn_partials) {
     constexpr int VE = vec16<T>::N;
     const int VPP = Cin / VE, PPB = 256 / VPP;
     const int vv = threadIdx.x % VPP, ps = threadIdx.x / VPP;
@@ -84,6 +85,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ y, 
     }
 #pragma unroll
     for (int co = 0; co < COUT; ++co) db[co] = 0.f;
+    // bn_partials: the BatchNorm-backward sums of the ConvBNRelu that produced y -- sum(gz), sum(gz*y), gz = g (as stored) * [z > 0] --
+    // gathered while y and g are in registers anyway: the separate reduce pass over (g, y) disappears (rows for wm_bn_bwd_finalize_raw)
+    float b1[VE], b2[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { b1[e] = 0.f; b2[e] = 0.f; }
     for (size_t p = (size_t)blockIdx.x * PPB + ps; p < npix; p += (size_t)gridDim.x * PPB) {
         const size_t b = p / hw, q = p - b * hw;
         float go[COUT];
@@ -99,6 +105,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ y, 
 #pragma unroll
             for (int co = 0; co < COUT; ++co) { gg += go[co] * wr[co][e]; dw[co][e] += go[co] * a; }
             gv.set(e, gg);
+            if (bn_partials) {
+                const float gz = a > 0.f ? gv.get(e) : 0.f;
+                b1[e] += gz;
+                b2[e] = __builtin_fmaf(gz, yv.get(e), b2[e]);
+            }
         }
         if (vv == 0) {
 #pragma unroll
@@ -126,6 +137,19 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ y, 
         float s = 0.f;
         for (int qq = 0; qq < PPB; ++qq) s += red[qq * VPP][COUT * VE + threadIdx.x];
         prow[COUT * Cin + threadIdx.x] = s;
+    }
+    if (bn_partials) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { red[threadIdx.x][e] = b1[e]; red[threadIdx.x][VE + e] = b2[e]; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * Cin; i += 256) {
+            const int which = i / Cin, c = i - which * Cin;
+            const int v2 = c / VE, e = c - v2 * VE;
+            float s = 0.f;
+            for (int qq = 0; qq < PPB; ++qq) s += red[qq * VPP + v2][which * VE + e];
+            bn_partials[((size_t)blockIdx.x * 2 + which) * Cin + c] = s;
+        }
     }
 }
 
@@ -163,9 +187,10 @@ extern "C" int wm_conv1x1_head_fwd(const void* y, int ldy, const float* scale, c
 extern "C" int wm_conv1x1_head_nparts(size_t npix) { return head_parts(npix); }
 
 extern "C" int wm_conv1x1_head_bwd(const void* y, int ldy, const float* scale, const float* shift, const float* w,
-                                   const float* gout, void* g, int ldg, float* partials, int B, size_t hw, int Cin,
+                                   const float* gout, void* g, int ldg, float* partials, float* bn_partials, int B, size_t hw, int Cin,
                                    int Cout, int dtype, void* stream) {
     WM_REQUIRE(y && w && gout && g && partials, WM_E_BADARG, "wm_conv1x1_head_bwd: null pointer");
+    WM_REQUIRE(!bn_partials || scale, WM_E_BADARG, "wm_conv1x1_head_bwd: bn_partials need the producing layer's scale / shift");
     WM_REQUIRE((scale == nullptr) == (shift == nullptr), WM_E_BADARG, "wm_conv1x1_head_bwd: scale/shift must come together");
     WM_REQUIRE(cin_ok(Cin, dtype), WM_E_SHAPE, "wm_conv1x1_head_bwd: unsupported Cin=%d", Cin);
     WM_REQUIRE(Cout == 1 || Cout == 3, WM_E_SHAPE, "wm_conv1x1_head_bwd: Cout must be 1 or 3 (got %d)", Cout);
@@ -173,8 +198,8 @@ extern "C" int wm_conv1x1_head_bwd(const void* y, int ldy, const float* scale, c
     const int grid = head_parts(npix);
     hipStream_t s = (hipStream_t)stream;
     WM_DISPATCH_DTYPE(dtype, "wm_conv1x1_head_bwd",
-        if (Cout == 3) hipLaunchKernelGGL((head_bwd_kernel<T, 3>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, scale, shift, w, gout, (T*)g, ldg, partials, npix, hw, Cin);
-        else hipLaunchKernelGGL((head_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, scale, shift, w, gout, (T*)g, ldg, partials, npix, hw, Cin));
+        if (Cout == 3) hipLaunchKernelGGL((head_bwd_kernel<T, 3>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, scale, shift, w, gout, (T*)g, ldg, partials, npix, hw, Cin, bn_partials);
+        else hipLaunchKernelGGL((head_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, scale, shift, w, gout, (T*)g, ldg, partials, npix, hw, Cin, bn_partials));
     WM_LAUNCH_CHECK("wm_conv1x1_head_bwd");
     return WM_OK;
 }

@@ -102,8 +102,11 @@ class Encoder(nn.Module, engine.FlatModule):
             self._perm_dev = torch.tensor(self._perm, dtype=torch.int32, device=g_enc.device)
         fl = self.final_layer
         a5 = ctx.final_in
-        g = ops.conv1x1_head_bwd(a5.t, a5.scale, a5.shift, fl.weight.data.view(3, c), g_enc,
-                                 grads[fl.weight].view(3, c), grads[fl.bias], accumulate)
+        # the head's backward also reduces the after-concat layer's BatchNorm-backward sums (y and g are in its registers anyway)
+        g, bnp = ops.conv1x1_head_bwd(a5.t, a5.scale, a5.shift, fl.weight.data.view(3, c), g_enc,
+                                      grads[fl.weight].view(3, c), grads[fl.bias], accumulate, want_bn_partials=True)
+        if bnp is not None:
+            a5.bwd = (g, bnp, None, g._version)
         blk = self.after_concat_layer
         if ctx.split:
             g = self._after_concat_bwd_split(ctx, g, grads, accumulate)
@@ -132,17 +135,26 @@ class Encoder(nn.Module, engine.FlatModule):
             self._fperm_dev = torch.tensor(self._fperm, dtype=torch.int32, device=dev)
             self._iperm_dev = torch.tensor(self._iperm, dtype=torch.int32, device=dev)
         dw = grads[conv.weight]
-        coef = ops.bn_bwd_coef(g, None, y, cx.stats, 64, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate)
+        pre, cx.out.bwd = cx.out.bwd, None
+        if pre is not None and pre[0] is g and g._version == pre[3]:    # sums already reduced by the head's backward
+            coef = ops.bn_bwd_coef_raw(pre[1], y, cx.stats, 64, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate)
+        else:
+            coef = ops.bn_bwd_coef(g, None, y, cx.stats, 64, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate)
         wpt = engine._packed(conv, 64, 64, dt, self._fperm, True)
         d = engine._opposite(getattr(g, "_wm_rev", None))
-        feed = ops.conv3x3_dgrad_bwdstats_supported(64, 64, dt) and ops.conv3x3_dgrad_applyfused_supported(64, 64, dt) and x.src is not None
+        fused = ops.conv3x3_dgrad_applyfused_supported(64, 64, dt)
+        feed = fused and ops.conv3x3_dgrad_bwdstats_supported(64, 64, dt) and x.src is not None
         if feed:
             dy, gx, part = ops.conv3x3_dgrad_applyfused(g, y, cx.stats, coef, wpt, x.t, x.scale, x.shift, reverse=d)
             pcoef = ops.conv3x3_wgrad(x.t, 64, x.scale, x.shift, dy, dw, accumulate, perm_dev=self._fperm_dev, reverse=not d,
                                       fin=engine.fin_rider(x, part, grads, accumulate))
             x.bwd = (gx, part, pcoef, gx._version)
         else:
-            dy, gx, _ = ops.conv3x3_dgrad_applyfused(g, y, cx.stats, coef, wpt, reverse=d)
+            if fused:
+                dy, gx, _ = ops.conv3x3_dgrad_applyfused(g, y, cx.stats, coef, wpt, reverse=d)
+            else:   # (debug build with the fusion switched off: the stand-alone apply pass + a plain conv with the transposed filter)
+                dy = ops.bn_bwd(g, None, y, cx.stats, 64, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate, None, coef=coef)
+                gx, _ = ops.conv3x3_fwd(dy, wpt, None, None, None, want_stats=False)
             ops.conv3x3_wgrad(x.t, 64, x.scale, x.shift, dy, dw, accumulate, perm_dev=self._fperm_dev, reverse=not d)
         gx._wm_rev = d
         img16 = engine.image_to_act(ctx.image, dt)

@@ -140,8 +140,10 @@ class UNet(nn.Module, engine.FlatModule):
         y = ctx.out
         g_logit = g_out if g_is_logit else g_out * y * (1.0 - y)  # sigmoid' on the small mask tensor
         a = ctx.last
-        g = ops.conv1x1_head_bwd(a.t, a.scale, a.shift, self.conv.weight.data.view(oc, f), g_logit,
-                                 grads[self.conv.weight].view(oc, f), grads[self.conv.bias], accumulate)
+        g, bnp = ops.conv1x1_head_bwd(a.t, a.scale, a.shift, self.conv.weight.data.view(oc, f), g_logit,
+                                      grads[self.conv.weight].view(oc, f), grads[self.conv.bias], accumulate, want_bn_partials=True)
+        if bnp is not None:   # the last decoder layer's BatchNorm-backward sums come out of the head's backward: no reduce pass
+            a.bwd = (g, bnp, None, g._version)
         gcats = {}
         for k, lvl in enumerate((1, 2, 3, 4)):  # decoder blocks were run 4,3,2,1 -> undo 1,2,3,4
             C = f * (1 << (lvl - 1))

@@ -316,7 +316,7 @@ def concat_side_msg_wgrad(dy, msg, dw, accumulate, c_msg, L):
     B, H, W, C = dy.shape
     assert C == 64 and dy.is_contiguous() and dw.is_contiguous() and dw.shape[0] == 64
     msg = msg.contiguous().float()
-    partial = torch.empty(B, 16, 64, device=dy.device, dtype=torch.float32)
+    partial = torch.empty(B, _lib.lib().wm_concat_side_partial_rows(), 64, device=dy.device, dtype=torch.float32)
     S = torch.empty(B, 9, 64, device=dy.device, dtype=torch.float32)
     rc = _lib.lib().wm_concat_side_msg_wgrad(_p(dy), _p(msg), _p(partial), _p(S), _p(dw), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W),
                                              c_int(dw.shape[1]), c_int(c_msg), c_int(L), c_int(dtype_id(dy)), _stream())
@@ -635,21 +635,26 @@ def conv1x1_head_fwd(y, scale, shift, w, bias, act=0):
     return out
 
 
-def conv1x1_head_bwd(y, scale, shift, w, gout, dw, dbias, accumulate):
+def conv1x1_head_bwd(y, scale, shift, w, gout, dw, dbias, accumulate, want_bn_partials=False):
+    """-> g (gradient wrt the ReLU output feeding the head); with want_bn_partials: (g, rows [n,2,Cin] of sum(gz), sum(gz*y) of the
+    ConvBNRelu that produced y, for bn_bwd_coef_raw: that layer then needs no reduce pass over (g, y))"""
     B, H, W, Cin = y.shape
     Cout = w.shape[0]
     L = _lib.lib()
     nparts = L.wm_conv1x1_head_nparts(c_size_t(B * H * W))
     part = torch.empty(nparts, Cout * (Cin + 1), device=y.device, dtype=torch.float32)
+    bnp = torch.empty(nparts, 2, Cin, device=y.device, dtype=torch.float32) if want_bn_partials and scale is not None else None
     g = torch.empty_like(y)
     gout = gout.contiguous()
-    rc = L.wm_conv1x1_head_bwd(_p(y), c_int(Cin), _p(scale), _p(shift), _p(w), _p(gout), _p(g), c_int(Cin), _p(part), c_int(B),
+    rc = L.wm_conv1x1_head_bwd(_p(y), c_int(Cin), _p(scale), _p(shift), _p(w), _p(gout), _p(g), c_int(Cin), _p(part), _p(bnp), c_int(B),
                                c_size_t(H * W), c_int(Cin), c_int(Cout), c_int(dtype_id(y)), _stream())
     _lib.check(rc, "wm_conv1x1_head_bwd")
     ldp = Cout * (Cin + 1)
     colsum(part, Cout * Cin, ldp, dw, accumulate)
     # the first call folded the rows in place to <= 64 (wm_colsum_finalize treats partials as scratch)
     colsum(part[:(nparts if nparts <= 256 else 64), Cout * Cin:], Cout, ldp, dbias, accumulate)
+    if want_bn_partials:
+        return g, bnp
     return g
 
 
