@@ -219,10 +219,14 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step events on the launch stream (§8d: median)
     barrier()
     t0 = time.perf_counter()
+    host_ms = []
     for i in range(args.steps):
         marks[i].record()
+        th = time.perf_counter()
         losses, _ = h.train_on_batch([images, messages])
+        host_ms.append(1e3 * (time.perf_counter() - th))
     marks[args.steps].record()
+    host_ms.sort()
     barrier()
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
@@ -264,7 +268,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"C2: HiDDeN GAN step enc(4x64)->{args.noise}->dec(7x64)+disc(3x64), L=30, {S}x{S}, batch {B}/GPU",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
-            "ms_per_step_median_events": step_ms[len(step_ms) // 2], "ms_per_step_min_events": step_ms[0],
+            "ms_per_step_median_events": step_ms[len(step_ms) // 2], "ms_per_step_min_events": step_ms[0], "ms_per_step_max_events": step_ms[-1],
+            "host_enqueue_ms_median": host_ms[len(host_ms) // 2], "host_enqueue_ms_max": host_ms[-1],
             "roofline": roof,
             "roofline_mfma": mfma,
             "roofline_attack": attack_roofline(timer, B, S, args.noise),

@@ -37,29 +37,30 @@ __device__ __forceinline__ int cls_of(int h, int w, int H, int W) {
 
 #ifndef WM_H16_F16
 // mbias[b][cls][co] = bias[co] + sum_l m[b][l] * (sum over the taps valid in cls of w[co][c0 + l][tap])   (w: [Cout][Cin][3][3] f32)
-// one workgroup per border class: a thread folds its channel's L x 9 weights ONCE, then walks the samples
+// one wave per output channel: its L x 9 message weights are ONE contiguous run in w (coalesced), folded per class in LDS
 constexpr int MAXL = 64;
 __global__ __launch_bounds__(64) void msg_bias_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ msg,
                                                       float* __restrict__ mbias, int B, int Cin, int c0, int L) {
-    const int cls = blockIdx.x, co = threadIdx.x;
-    const int rc = cls / 3, cc = cls % 3;
-    float t[MAXL];
+    __shared__ float sw[MAXL * 9];
+    __shared__ float sT[9][MAXL];
+    const int co = blockIdx.x, lane = threadIdx.x;
+    const float* wl = w + ((size_t)co * Cin + c0) * 9;
+    for (int i = lane; i < L * 9; i += 64) sw[i] = wl[i];
+    __syncthreads();
+    for (int i = lane; i < 9 * L; i += 64) {
+        const int cls = i / L, l = i - cls * L, rc = cls / 3, cc = cls % 3;
+        float t = 0.f;
 #pragma unroll
-    for (int l = 0; l < MAXL; ++l) {
-        t[l] = 0.f;
-        if (l < L) {
-            const float* wl = w + ((size_t)co * Cin + c0 + l) * 9;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-                if (tap_valid(tap / 3, rc) && tap_valid(tap % 3, cc)) t[l] += wl[tap];
-        }
+        for (int tap = 0; tap < 9; ++tap)
+            if (tap_valid(tap / 3, rc) && tap_valid(tap % 3, cc)) t += sw[l * 9 + tap];
+        sT[cls][l] = t;
     }
+    __syncthreads();
     const float b0 = bias ? bias[co] : 0.f;
-    for (int b = 0; b < B; ++b) {
+    for (int i = lane; i < B * 9; i += 64) {
+        const int b = i / 9, cls = i - b * 9;
         float acc = b0;
-#pragma unroll
-        for (int l = 0; l < MAXL; ++l)
-            if (l < L) acc = __builtin_fmaf(t[l], msg[(size_t)b * L + l], acc);
+        for (int l = 0; l < L; ++l) acc = __builtin_fmaf(sT[cls][l], msg[(size_t)b * L + l], acc);
         mbias[((size_t)b * 9 + cls) * 64 + co] = acc;
     }
 }
@@ -269,7 +270,7 @@ int WM_HSYM(wm_concat_side_bwd_impl)(const void* dy, const float* msg, float* pa
 
 #ifndef WM_H16_F16
 void wm_launch_msg_bias(const float* w, const float* bias, const float* msg, float* mbias, int B, int Cin, int c0, int L, hipStream_t s) {
-    hipLaunchKernelGGL(msg_bias_kernel, dim3(9), dim3(64), 0, s, w, bias, msg, mbias, B, Cin, c0, L);
+    hipLaunchKernelGGL(msg_bias_kernel, dim3(64), dim3(64), 0, s, w, bias, msg, mbias, B, Cin, c0, L);
 }
 void wm_launch_msg_wgrad(const float* S, const float* msg, float* dw, int B, int Cin, int c0, int L, int accumulate, hipStream_t s) {
     hipLaunchKernelGGL(msg_wgrad_kernel, dim3(L * 9), dim3(64), 0, s, S, msg, dw, B, Cin, c0, L, accumulate);

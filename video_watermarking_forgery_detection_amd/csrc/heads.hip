@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ y, 
         }
         *reinterpret_cast<vec16<T>*>(g + p * ldg + c0) = gv;
     }
-    __shared__ float red[256][COUT * vec16<T>::N + COUT + 1];
+    constexpr int RW = (COUT * vec16<T>::N + COUT + 1) > (2 * vec16<T>::N + 1) ? (COUT * vec16<T>::N + COUT + 1) : (2 * vec16<T>::N + 1);
+    __shared__ float red[256][RW];   // (wide enough for the 2 x VE BatchNorm sums of the second reduction too)
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
 #pragma unroll

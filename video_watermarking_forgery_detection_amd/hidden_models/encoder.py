@@ -152,10 +152,16 @@ class Encoder(nn.Module, engine.FlatModule):
         else:
             if fused:
                 dy, gx, _ = ops.conv3x3_dgrad_applyfused(g, y, cx.stats, coef, wpt, reverse=d)
-            else:   # (debug build with the fusion switched off: the stand-alone apply pass + a plain conv with the transposed filter)
+                ops.conv3x3_wgrad(x.t, 64, x.scale, x.shift, dy, dw, accumulate, perm_dev=self._fperm_dev, reverse=not d)
+            else:   # (debug build with the fusion switched off: the stand-alone apply pass, as engine.cbr_backward's generic branch)
                 dy = ops.bn_bwd(g, None, y, cx.stats, 64, bn.weight.data, grads[bn.weight], grads[bn.bias], accumulate, None, coef=coef)
-                gx, _ = ops.conv3x3_fwd(dy, wpt, None, None, None, want_stats=False)
-            ops.conv3x3_wgrad(x.t, 64, x.scale, x.shift, dy, dw, accumulate, perm_dev=self._fperm_dev, reverse=not d)
+                ops.conv3x3_wgrad(x.t, 64, x.scale, x.shift, dy, dw, accumulate, perm_dev=self._fperm_dev, reverse=True)
+                if x.src is not None and ops.conv3x3_dgrad_bwdstats_supported(64, 64, dt):
+                    gx, part = ops.conv3x3_dgrad_bwdstats(dy, wpt, x.t, x.scale, x.shift)
+                    x.bwd = (gx, part, None, gx._version)
+                else:
+                    gx, _ = ops.conv3x3_fwd(dy, wpt, None, None, None, want_stats=False)
+                d = False
         gx._wm_rev = d
         img16 = engine.image_to_act(ctx.image, dt)
         ops.conv3x3_wgrad(img16.t, 16, None, None, dy, dw, accumulate, perm_dev=self._iperm_dev)
