@@ -19,7 +19,9 @@ The JSON line carries, besides the driver contract:
                   671 MB algorithmic per launch at B=16 256x256: 115 FLOP/B, below the 312 FLOP/B ridge), so the bound
                   is HBM: achieved = algorithmic bytes / launch duration measured live with events on the launch stream
                   inside the timed region; peak = 8 TB/s; `traffic` = HBM bytes / launch from the committed rocprofv3
-                  PMC passes of this round (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled as the gfx950 guide says)
+                  PMC passes of this round (profiles/r02_pmc_traffic.json; FETCH_SIZE doubled as the gfx950 guide says);
+                  `mfma_util_pmc` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) from the committed counter pass
+                  (profiles/r02_bench_c2_pmc_mfma.csv); `step_mfma_util_pmc` = the same ratio over every kernel of the step
   roofline_mfma -- the runner-up, conv3x3_ws_kernel<64,64,XFORM,STATS,M16> (forward 64->64 conv, fused BN+ReLU input and
                   BatchNorm statistics, 15 launches / step): 77.3 GFLOP per launch against 2.5 PFLOP/s dense bf16
   cpu_baseline -- the oracle (oracle/hidden_ref.py, torch CPU fp32, all host cores) on a bounded
@@ -138,8 +140,11 @@ def pmc_traffic(args, S, B, key="hbm_bytes_per_launch"):
     if args.dtype != "bf16" or S != 256 or B != 16:
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)[key]
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            d = json.load(f)
+        for part in key.split("."):
+            d = d[part]
+        return d
     except (OSError, KeyError, ValueError):
         return None
 
@@ -248,7 +253,8 @@ def main():
         mfma = {"bound": "mfma",
                 "kernel": ("conv3x3_ws_kernel<64,64,XFORM,STATS,M16>" if dtype == torch.bfloat16 else "conv3x3_kernel<float,64,true>") + " (forward 64->64 implicit GEMM, fused BN+ReLU input, BN statistics)",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": pmc_traffic(args, S, B, "fwd_hbm_bytes_per_launch"), "launches_timed": len(kms), "avg_launch_ms": avg_ms,
+                "traffic": pmc_traffic(args, S, B, "fwd_hbm_bytes_per_launch"), "mfma_util_pmc": pmc_traffic(args, S, B, "fwd.mfma_util"),
+                "launches_timed": len(kms), "avg_launch_ms": avg_ms,
                 "flops_per_launch": flops_per_launch, "hbm_algorithmic_bytes_per_launch": 2.0 * tensor_bytes}
         if dms:   # bf16: the fused input-gradient kernel is the dominant one, and it is HBM-bound
             davg = sum(dms) / len(dms)
@@ -256,7 +262,8 @@ def main():
             roof = {"bound": "hbm",
                     "kernel": "conv3x3_ws_kernel<64,64,M16,BNBWD=2,BWDST> (64->64 input-gradient implicit GEMM + BatchNorm-backward apply + the feeding layer's BatchNorm sums)",
                     "achieved": dbytes / (davg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": dbytes / (davg * 1e-3) / 1e9 / 8000.0,
-                    "traffic": pmc_traffic(args, S, B), "launches_timed": len(dms), "avg_launch_ms": davg,
+                    "traffic": pmc_traffic(args, S, B), "mfma_util_pmc": pmc_traffic(args, S, B, "dgrad_fused.mfma_util"),
+                    "launches_timed": len(dms), "avg_launch_ms": davg,
                     "algorithmic_bytes_per_launch": dbytes, "flops_per_launch": flops_per_launch,
                     "flops_frac_of_mfma_peak": flops_per_launch / (davg * 1e-3) / 1e12 / peak}
         else:
@@ -273,6 +280,7 @@ def main():
             "roofline": roof,
             "roofline_mfma": mfma,
             "roofline_attack": attack_roofline(timer, B, S, args.noise),
+            "step_mfma_util_pmc": pmc_traffic(args, S, B, "step_mfma_util"),
             "step_flops_frac_of_peak": (249.0e9 * (S / 256.0) ** 2 * world * B * args.steps / dt) / (peak * 1e12 * world),
             "last_losses": {k.strip(): v for k, v in losses.items()},
         }
