@@ -587,7 +587,27 @@ def gen_localise(out, Cfg):
                 out[f"{key}/{tag}/{n}"] = npy(detgen.subsample(p.float(), st))
 
 
+# --------------------------------------------------------------------------- TensorBoard scalar log written by the reference's own run
+def gen_tfevents():
+    """the first records of one of the reference's TensorBoard event files (runs/RHI3: `PSNR Forward` ... scalars written through
+    torch.utils.tensorboard at models/IRNcrop_model.py:399-400) -- DATA, kept as a known-answer file for utils/tb_writer.read_events and
+    for the framing / crc / protobuf layout utils/tb_writer.SummaryWriter has to produce"""
+    import struct
+    src = os.path.join(REF, "runs", "RHI3", "events.out.tfevents.1653714410.group2.1832315.1")
+    data = open(src, "rb").read()
+    i, n = 0, 0
+    while n < 10 and i + 12 <= len(data):
+        (ln,) = struct.unpack("<Q", data[i:i + 8])
+        i += 16 + ln
+        n += 1
+    out = os.path.join(HERE, "tfevents_head.bin")
+    open(out, "wb").write(data[:i])
+    print(f"tfevents: {n} records, {i} bytes -> {out}")
+
+
 def main():
+    if sys.argv[1:] == ["tfevents"]:
+        return gen_tfevents()
     Cfg = install_shims()
     jobs = {
         "jpeg": lambda o: gen_jpeg(o),

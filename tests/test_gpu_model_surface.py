@@ -84,3 +84,29 @@ def test_clip_and_localizer_branch(tmp_path):
     for p in m.localizer.parameters():
         assert torch.isfinite(p).all()
     assert [os.path.basename(p) for p in m.save(12)][-1] == '12_localizer.pth'
+
+
+def test_log_side_tensorboard_and_image_sheets(tmp_path):
+    """IRNcrop_model.py:399-400,421-437: scalars of the step's logs into a tfevents file, an image sheet at step % interval == 10 % interval"""
+    from video_watermarking_forgery_detection_amd.models.IRNrhi_model import IRNrhiModel
+    from video_watermarking_forgery_detection_amd.utils import read_events
+    from PIL import Image
+    opt = make_opt(tmp_path, localizer=True, tensorboard_dir=str(tmp_path / "runs" / "RHI3"), image_dump_interval=4, attacks=["JpegSS50", "GaussianBlur"])
+    opt["path"]["images"] = str(tmp_path / "images")
+    torch.manual_seed(0)
+    m = IRNrhiModel(opt)
+    for step in range(1, 8):
+        x = detgen.uniform((4, 3, 32, 32), 40 + step)
+        mask = torch.zeros(4, 1, 32, 32); mask[:, :, 4:12, 6:20] = 1
+        m.feed_data((x, mask))
+        logs, _ = m.optimize_parameters(step, None)
+    m.writer.close()
+    ev = read_events(m.writer.path)
+    tags = {t for e in ev for t, _ in e["scalars"]}
+    assert {"loss", "encoder_mse", "dec_mse", "lB", "PF", "lr"} <= tags
+    assert max(e["step"] for e in ev) == 7 and sum(1 for e in ev if e["scalars"] and e["scalars"][0][0] == "loss") == 5   # steps 3..7
+    sheets = sorted(os.listdir(str(tmp_path / "images")))
+    assert sheets == ["00006.png"]                                      # 6 % 4 == 10 % 4 (and step 2 had no work yet)
+    im = Image.open(str(tmp_path / "images" / sheets[0]))
+    assert im.size == (32 * 6, 32 * 4)                                  # input | watermarked | 10x diff | attacked | predicted mask | mask, 4 rows
+    assert m.keep_outputs is False

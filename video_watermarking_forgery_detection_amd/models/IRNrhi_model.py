@@ -148,6 +148,14 @@ class IRNrhiModel(BaseModel):
             self.optimizers.append(self.optimizer_localizer)
             self.localizer_weight = _get(train_opt, 'localizer_weight', default=1.0)
         self.psnr_gate = bool(_get(train_opt, 'psnr_gate', default=True))   # IRNcrop_model.py:379-388
+        # log side (IRNcrop_model.py:78,399-400: SummaryWriter scalars; :421-437: an image sheet every 500 steps at step % 500 == 10)
+        tb_dir = _get(train_opt, 'tensorboard_dir', default=None)
+        self.writer = None
+        if tb_dir and self.rank <= 0:
+            from ..utils import SummaryWriter
+            self.writer = SummaryWriter(tb_dir)
+        self.image_dump_interval = _get(train_opt, 'image_dump_interval', default=None)
+        self.image_dump_dir = _get(self.opt, 'path', 'images', default=None)
         self._loc = None
         self.messages = None
         self.keep_outputs = False    # tests / image dumps: keep the step's tensors in self.last_outputs
@@ -271,17 +279,21 @@ class IRNrhiModel(BaseModel):
             extra = self._localise if self.use_localizer else None
             gate = self._gate if (self.use_localizer and self.psnr_gate) else None
             self._loc = None
+            dump = bool(self.image_dump_interval and self.image_dump_dir and step % self.image_dump_interval == 10 % self.image_dump_interval)
+            keep, self.keep_outputs = self.keep_outputs, self.keep_outputs or dump
             if self.keep_outputs:
                 self.last_outputs = {}
             losses, outs = self.hidden.train_on_batch([self.real_H, messages], extra_encoded_grad=extra,
                                                       clip=self._clip if self.gradient_clipping else None, enc_gate=gate)
             if self.keep_outputs:
                 self.last_outputs.update(encoded=outs[0], noised=outs[1], decoded=outs[2])
+            self.keep_outputs = keep
             extra_logs = losses.pop('_extra', [])
             logs = [(k.strip(), v) for k, v in losses.items()]
             for name, v in extra_logs:
                 logs.append((name, v.item() if torch.is_tensor(v) else v))
             logs.append(('lr', self.get_current_learning_rate()))
+            self._log_side(step, logs)
         elif ready:
             L = self.hidden.config.message_length
             messages = torch.randint(0, 2, (self.real_H.shape[0], L), device=self.device).float()
@@ -295,6 +307,29 @@ class IRNrhiModel(BaseModel):
                 self.previous_previous_images = self.previous_images
             self.previous_images = self.real_H.clone().detach()
         return logs, debug_logs
+
+    def _log_side(self, step, logs):
+        """TensorBoard scalars of every float in `logs` and, every image_dump_interval steps, the stitched sheet
+        input | watermarked | 10 x |difference| | attacked | predicted mask | mask (IRNcrop_model.py:399-400,421-437)"""
+        if self.writer is not None:
+            for name, v in logs:
+                if isinstance(v, float):
+                    self.writer.add_scalar(name, v, global_step=self.global_step)
+            self.writer.flush()
+        n = self.image_dump_interval
+        if n and self.image_dump_dir and self.rank <= 0 and step % n == 10 % n and self.last_outputs.get("encoded") is not None:
+            from ..utils import postprocess, stitch_images
+            o = self.last_outputs
+            x, enc = self.real_H[:4], o["encoded"][:4].clamp(0, 1)
+            cols = [postprocess(enc), postprocess((10 * (x - enc).abs()).clamp(0, 1))]
+            if o.get("attacked") is not None:
+                cols += [postprocess(o["attacked"][:4].clamp(0, 1)), postprocess(o["pred"][:4].expand(-1, 3, -1, -1)),
+                         postprocess(self.mask[:4].expand(-1, 3, -1, -1))]
+            else:
+                cols.append(postprocess(o["noised"][:4].clamp(0, 1)))
+            sheet = stitch_images(postprocess(x), *cols, img_per_row=1)
+            os.makedirs(self.image_dump_dir, exist_ok=True)
+            sheet.save(os.path.join(self.image_dump_dir, str(step).zfill(5) + ".png"))
 
     def evaluate(self, *args, **kwargs):
         return self.optimize_parameters(self.global_step, train=False)

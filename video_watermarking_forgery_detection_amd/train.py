@@ -3,10 +3,10 @@
     python -m torch.distributed.run --nproc_per_node=N -m video_watermarking_forgery_detection_amd.train \
         -opt options/train/train_hidden_c2.yml --launcher pytorch
 
-`-opt <yml>`, `--launcher {none,pytorch}`, `--local_rank`, `-val {0,1}`.  The DAVIS loader of the
-reference (data/) is outside the hot path: batches here are synthetic tensors of the loader's shape
-contract ([B,3,H,W] frames or [B,3,T,H,W] clips + [B,1,T,H,W] masks), sharded as
-data/__init__.py:16-17 does (per-rank batch = batch_size // world_size)."""
+`-opt <yml>`, `--launcher {none,pytorch}`, `--local_rank`, `-val {0,1}`.  With `datasets.train.dataroot` set, batches come from
+the DAVIS clip loader (data/: `DVDataset` + `DistIterSampler` + `create_dataloader`, per-rank batch = batch_size // world_size as
+data/__init__.py:16-17); without it they are synthetic tensors of the same shape contract ([B,3,H,W] frames or [B,3,T,H,W] clips +
+[B,1,T,H,W] masks).  Rank 0 feeds the step's `logs` to the Progbar (train.py:93-96,109)."""
 import argparse
 import logging
 import os
@@ -15,9 +15,28 @@ import random
 import numpy as np
 import torch
 
+from .data import DistIterSampler, DVDataset, create_dataloader
 from .distributed import init_dist, shard_batch_size
 from .models.IRNrhi_model import IRNrhiModel
 from .options import options as option
+from .utils import Progbar
+
+
+def davis_batches(opt, rank, world, n):
+    """train.py:50-60,91-99 of the reference: dataset -> sampler -> loader, epochs until n iterations"""
+    dopt = opt['datasets']['train']
+    ds = DVDataset(root_path=dopt['dataroot'], image_size=dopt['GT_size'], clip_length=dopt['clip_length'])
+    sampler = DistIterSampler(ds, world, rank, ratio=dopt['dist_ratio'] or 100) if opt['dist'] else None
+    opt['phase'] = 'train'
+    dopt['n_workers'] = dopt['n_workers'] or 0
+    loader = create_dataloader(ds, dopt, opt, sampler)
+    done = 0
+    while done < n:
+        for batch in loader:
+            yield batch
+            done += 1
+            if done >= n:
+                return
 
 
 def synthetic_batches(opt, per_rank_batch, rank, n):
@@ -60,7 +79,10 @@ def main():
     current_step = opt['train']['current_step'] or 0
     total_iters = int(opt['train']['niter'])
     latest_values = None
-    for train_data in synthetic_batches(opt, per_rank, rank, total_iters):
+    progbar = Progbar(total_iters * per_rank, stateful_metrics=['lr', 'Kind', 'LocKind', 'PF']) if rank <= 0 and opt['train']['progbar'] else None
+    batches = (davis_batches(opt, max(rank, 0), world, total_iters) if opt['datasets']['train']['dataroot']
+               else synthetic_batches(opt, per_rank, rank, total_iters))
+    for train_data in batches:
         current_step += 1
         if current_step > total_iters:
             break
@@ -69,7 +91,9 @@ def main():
             logs, debug_logs = model.optimize_parameters(current_step, latest_values)
         else:
             logs, debug_logs = model.evaluate()
-        if rank <= 0 and logs and current_step % 10 == 0:
+        if progbar is not None:
+            progbar.add(len(model.real_H), values=logs)      # train.py:109
+        elif rank <= 0 and logs and current_step % 10 == 0:
             log.info("step %d  frames %d  %s", current_step, len(model.real_H),
                      "  ".join(f"{k}={v:.4f}" if isinstance(v, float) else f"{k}={v}" for k, v in logs))
 
