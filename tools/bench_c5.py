@@ -1,30 +1,43 @@
-"""step time of the widened path (SURVEY §8 'next' rows): IRNrhiModel.feed_data / optimize_parameters with the attack cycle
-(DiffJPEG, blur, resize, crop, ...), quantisation and the UNet localisation head -- options/train/train_hidden_c5.yml."""
-import os, sys, time
+"""step time of the widened configurations through the model surface (IRNrhiModel.feed_data / optimize_parameters):
+  C5 (default yml): 16-frame 256x256 clip folded into the batch, rotating attack set, gradient clipping, UNet localisation head
+  C3 (train_hidden_c3.yml): 16 frames, the 7-attack cycle + discriminator, no localiser
+usage: python tools/bench_c5.py [yml] [dtype override: bf16|f16|f32] [steps]   -> one JSON line (per-attack medians, events on the stream)"""
+import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from video_watermarking_forgery_detection_amd.models.IRNrhi_model import IRNrhiModel
 from video_watermarking_forgery_detection_amd.options import options as option
 from video_watermarking_forgery_detection_amd.train import synthetic_batches
-yml = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "video_watermarking_forgery_detection_amd", "options", "train", "train_hidden_c5.yml")
+D = os.path.join(ROOT, "video_watermarking_forgery_detection_amd", "options", "train")
+yml = sys.argv[1] if len(sys.argv) > 1 else os.path.join(D, "train_hidden_c5.yml")
+if not os.path.exists(yml):
+    yml = os.path.join(D, yml)
 opt = option.parse(yml, is_train=True)
 opt['dist'] = False
+if len(sys.argv) > 2:
+    opt['train']['compute_dtype'] = sys.argv[2]
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 72
 torch.manual_seed(10)
 model = IRNrhiModel(opt)
 B = opt['datasets']['train']['batch_size']
-N = 40
-batches = list(synthetic_batches(opt, B, 0, N))
-step = 0
-times = []
-for i, data in enumerate(batches):
-    step += 1
+per = {}
+for i, data in enumerate(synthetic_batches(opt, B, 0, N)):
+    step = i + 1
     model.feed_data(data)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
     logs, _ = model.optimize_parameters(step, None)
-    torch.cuda.synchronize(); times.append((time.perf_counter() - t0) * 1e3)
-    if i % 8 == 0:
-        print(step, [(k, round(v, 4) if isinstance(v, float) else v) for k, v in (logs or [])][:8])
+    b.record()
+    torch.cuda.synchronize()
+    if logs and step > 16:     # every attack has run twice by then: first-use allocations are out of the way
+        d = dict(logs)
+        per.setdefault(d.get('Kind', model.attack.name), []).append(a.elapsed_time(b))
 frames = len(model.real_H)
-ts = sorted(times[8:])
-print(f"frames/step {frames}; step ms median {ts[len(ts)//2]:.2f} min {ts[0]:.2f} max {ts[-1]:.2f} -> {frames/ts[len(ts)//2]*1e3:.0f} frames/s (attack varies per step)")
+med = {k: sorted(v)[len(v) // 2] for k, v in per.items()}
+allt = sorted(t for v in per.values() for t in v)
+out = {"yml": os.path.basename(yml), "dtype": opt['train']['compute_dtype'], "frames_per_step": frames, "steps_timed": len(allt),
+       "ms_per_step_median": allt[len(allt) // 2], "ms_per_step_mean": sum(allt) / len(allt), "ms_per_step_max": allt[-1],
+       "frames_per_s": frames / (sum(allt) / len(allt)) * 1e3, "ms_per_step_by_attack": {k: round(v, 3) for k, v in med.items()},
+       "amp_scale": model.amp.get_scale() if model.amp is not None else None}
+print(json.dumps(out))
