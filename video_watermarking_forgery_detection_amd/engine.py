@@ -28,7 +28,10 @@ class Act:
     def __init__(self, t, C, scale=None, shift=None, rev=None, src=None):
         self.t, self.C, self.scale, self.shift = t, C, scale, shift
         self.bwd = None   # backward: (g, partials, coef or None, g._version) left by the consumer's dgrad when it reduced this layer's BatchNorm sums
-        self.src = src    # (bn module, ctx) of the ConvBNRelu that produced t (lets the consumer's backward finish this layer's statistics)
+        self.src = src    # (bn module, stats [4,CP]) of the ConvBNRelu that produced t (lets the consumer's backward finish this layer's statistics).
+                          # NOT the layer's ctx: ctx.out -> Act -> src -> ctx would be a reference cycle, and a cycle keeps a step's 134 MB
+                          # tensors alive until Python's cyclic collector runs -- the caching allocator then falls back to hipMalloc mid-step
+                          # (measured: 40-60 ms host stalls)
         self.rev = rev    # sweep direction of the conv that just wrote t (False forward, True backward, None: not fresh)
 
 
@@ -122,7 +125,7 @@ def cbr_finish(conv, bn, x, y, st, d, perm=None, training=True, momentum=0.1):
         stats[3, :Cout] = invstd
     ctx = CBRCtx()
     ctx.x, ctx.y, ctx.stats, ctx.perm, ctx.training = x, y, stats, perm, training
-    ctx.out = Act(y, Cout, stats[0], stats[1], rev=d, src=(bn, ctx))
+    ctx.out = Act(y, Cout, stats[0], stats[1], rev=d, src=(bn, stats))
     return ctx.out, ctx
 
 
@@ -130,8 +133,8 @@ def fin_rider(x, part, grads, accumulate):
     """the BatchNorm-backward finalisation of the layer that produced Act `x`, to ride on a weight-gradient slab reduction"""
     if x.src is None or not ops.fin_rider_enabled():
         return None
-    pbn, pctx = x.src
-    return dict(partials=part, y_shape=tuple(x.t.shape), stats=pctx.stats, C=x.C, gamma=pbn.weight.data, dgamma=grads[pbn.weight],
+    pbn, pstats = x.src
+    return dict(partials=part, y_shape=tuple(x.t.shape), stats=pstats, C=x.C, gamma=pbn.weight.data, dgamma=grads[pbn.weight],
                 dbeta=grads[pbn.bias], accumulate=accumulate)
 
 
@@ -188,8 +191,8 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
         """the feeding layer's BatchNorm-backward finalisation, to ride on this layer's weight-gradient slab reduction"""
         if x.src is None or not ops.fin_rider_enabled():
             return None
-        pbn, pctx = x.src
-        return dict(partials=part, y_shape=tuple(x.t.shape), stats=pctx.stats, C=x.C, gamma=pbn.weight.data, dgamma=grads[pbn.weight],
+        pbn, pstats = x.src
+        return dict(partials=part, y_shape=tuple(x.t.shape), stats=pstats, C=x.C, gamma=pbn.weight.data, dgamma=grads[pbn.weight],
                     dbeta=grads[pbn.bias], accumulate=accumulate)
 
     # A globally pooled layer (the gradient wrt its ReLU output is one row per sample): both consumers of dy -- the weight
