@@ -22,7 +22,11 @@ torch.manual_seed(10)
 model = IRNrhiModel(opt)
 B = opt['datasets']['train']['batch_size']
 per = {}
-for i, data in enumerate(synthetic_batches(opt, B, 0, N)):
+# the synthetic batches are drawn BEFORE the timed loop: torch.rand on the host runs on every core it sees, and on a box whose CPU
+# share is a cgroup quota (16 CPUs of 256 here) that burst exhausts the 100 ms quota period -- the whole process, the thread that
+# feeds the GPU included, is then throttled for 40-60 ms every few steps (measured: tools/stall_probe*.py; a real loader's workers
+# are separate processes)
+for i, data in enumerate(list(synthetic_batches(opt, B, 0, N))):
     step = i + 1
     model.feed_data(data)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

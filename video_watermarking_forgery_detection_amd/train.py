@@ -40,6 +40,9 @@ def davis_batches(opt, rank, world, n):
 
 
 def synthetic_batches(opt, per_rank_batch, rank, n):
+    """frames / clips of the loader's shape contract, drawn on ONE host thread: a multi-threaded torch.rand burst inside the training
+    loop exhausts a cgroup CPU quota (a 16-CPU share of a 256-core host) and gets the whole process throttled for tens of ms"""
+    torch.set_num_threads(1)
     size = opt['datasets']['train']['GT_size']
     T = opt['datasets']['train']['clip_length']
     g = torch.Generator().manual_seed((opt['train']['manual_seed'] or 10) + max(rank, 0))
