@@ -425,6 +425,60 @@ int wm_mask_threshold(const float* p, float threshold, uint8_t* out, size_t n, v
 int wm_clip_coef(const float* const* partials, const int* nparts, int ngroups, float max_norm, float* out2, void* stream);
 int wm_scale_dev(float* x, size_t n, const float* scale_dev, void* stream);
 
+/* ------------------------------------------------------------------ general layer family
+ * replaces, for models/networks.py:631-749 (Discriminator), models/conditional_jpeg_generator.py:40-79 (conv()), :83-96 (ResBlock),
+ * :185-200 (QFAttention), :202-374 (FBCNN), :697-826 (QF_predictor): nn.Conv2d / nn.ConvTranspose2d / nn.Linear of any kernel size
+ * up to 5x5, stride 1 or 2, zero padding, with bias; their input and weight gradients; the activations; AdaptiveAvgPool2d((1,1));
+ * symm_pad (:865-885) / ReplicationPad2d; nn.utils.spectral_norm (networks.py:1381-1385); the Bayar constraint (:814-817).
+ * Activations NHWC [B,H,W,Cp] of `dtype` (WM_F32 / WM_BF16 / WM_F16) with the channel stride Cp a multiple of 16 and the padding
+ * channels ignored by every consumer; parameters, per-sample vectors and their gradients f32 in torch's layouts.
+ * wm_gconv_pack : w [Cout][Cin][KH][KW] f32 -> wp [KH*KW][RP][CP] dtype, rows = Cout, cols = Cin (transpose 0) or rows = Cin,
+ *                 cols = Cout (transpose 1: the operand of the input gradient / of ConvTranspose2d's forward); padding zero.
+ * wm_gconv_fwd  : dgrad 0: out [B,OH,OW,NC] = conv(in [B,IH,IW,KC], w [taps][NC][KC]) + bias [NC] (may be NULL);
+ *                 dgrad 1: in = the conv's output-side tensor [B,IH,IW,KC], out = its input-side tensor [B,OH,OW,NC]
+ *                 (the conv's input gradient, or ConvTranspose2d's forward), w packed with transpose 1.
+ * wm_gconv_wgrad: dw [Cout][Cin][KH][KW] (+)= sum_pixels dout x in; dbias [Cout] (+)= column sums of dout (may be NULL);
+ *                 partial = f32 scratch [wm_gconv_wgrad_nsplit(..)][KH*KW][NC][KC].  IH/IW/KC describe `in`, OH/OW/NC `dout`.
+ * wm_gcolsum    : out [Creal] (+)= column sums of x [npix][C].
+ * wm_unary_fwd / _bwd: kind 0 ReLU, 1 LeakyReLU(0.2), 2 GELU (erf), 3 ELU, 4 Sigmoid, 5 Tanh; the backward reads the INPUT x.
+ * wm_add_scaled : out = a + alpha * b.
+ * wm_qfatt_fwd  : out = x + gamma[b,c] * res + beta[b,c] (gamma / beta f32 [B][ldv]); wm_qfatt_bwd: gres = gamma * g,
+ *                 ggamma[b,c] = sum_p g * res, gbeta[b,c] = sum_p g (the gradient wrt x is g itself).
+ * wm_gpool_fwd  : out f32 [B][C] = mean over the hw pixels of x [B,hw,C]; wm_gpool_bwd: gx = g / hw.
+ * wm_pad_nchw_to_nhwc(_bwd): x [B,C,H,W] f32 -> out [B,H+top+bottom,W+left+right,CP], mode 0 symmetric, 1 replicate (pads may
+ *                 be 0: a plain layout change); the backward sums every padded position back onto its source pixel.
+ * wm_gunpack_nchw(_bwd): the top-left H x W window and first C channels of x [B,PH,PW,CP] -> [B,C,H,W] f32, and its adjoint.
+ * wm_spectral_norm_fwd: W [M][N] = weight_orig.view(Cout,-1); do_iter != 0 (training): v = normalize(W^T u), u = normalize(W v)
+ *                 in place (eps 1e-12); sigma = u.(W v); Wsn = W / sigma.   wm_spectral_norm_bwd: gW (+)= (G - <G,Wsn> u v^T)/sigma
+ *                 (u, v detached, as torch computes them under no_grad); partial = f32[256] scratch.
+ * wm_bayar_constrain: every 5x5 filter of w [nfilters][25] in place: centre := 0, filter /= its sum, centre := -1. */
+int wm_gconv_pack(const float* w, void* wp, int Cout, int Cin, int KH, int KW, int RP, int CP, int transpose, int dtype, void* stream);
+int wm_gconv_fwd(const void* in, const void* w, const float* bias, void* out, int B, int IH, int IW, int KC, int OH, int OW, int NC,
+                 int KH, int KW, int stride, int pad, int dgrad, int dtype, void* stream);
+int wm_gconv_wgrad_nsplit(int B, int OH, int OW, int KC, int NC, int KH, int KW);
+int wm_gconv_wgrad(const void* dout, const void* in, float* partial, float* dw, float* dbias, int accumulate, int B, int IH, int IW,
+                   int KC, int OH, int OW, int NC, int KH, int KW, int stride, int pad, int Cout, int Cin, int dtype, void* stream);
+int wm_gcolsum(const void* x, size_t npix, int C, float* out, int Creal, int accumulate, int dtype, void* stream);
+int wm_unary_fwd(const void* x, void* y, size_t n, int kind, int dtype, void* stream);
+int wm_unary_bwd(const void* x, const void* gy, void* gx, size_t n, int kind, int dtype, void* stream);
+int wm_add_scaled(const void* a, const void* b, void* out, size_t n, float alpha, int dtype, void* stream);
+int wm_qfatt_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* out, int B, size_t hw, int C, int ldv,
+                 int dtype, void* stream);
+int wm_qfatt_bwd(const void* g, const void* res, const float* gamma, void* gres, float* ggamma, float* gbeta, int B, size_t hw, int C,
+                 int ldv, int dtype, void* stream);
+int wm_gpool_fwd(const void* x, float* out, int B, size_t hw, int C, int dtype, void* stream);
+int wm_gpool_bwd(const float* g, void* gx, int B, size_t hw, int C, int dtype, void* stream);
+int wm_pad_nchw_to_nhwc(const float* x, void* out, int B, int C, int H, int W, int left, int right, int top, int bottom, int mode,
+                        int CP, int dtype, void* stream);
+int wm_pad_nchw_to_nhwc_bwd(const void* gp, float* gx, int B, int C, int H, int W, int left, int right, int top, int bottom, int mode,
+                            int CP, int dtype, void* stream);
+int wm_gunpack_nchw(const void* x, float* out, int B, int C, int H, int W, int PH, int PW, int CP, int dtype, void* stream);
+int wm_gunpack_nchw_bwd(const float* g, void* gx, int B, int C, int H, int W, int PH, int PW, int CP, int dtype, void* stream);
+int wm_spectral_norm_fwd(const float* W, float* u, float* v, float* sigma, float* Wsn, int M, int N, int do_iter, void* stream);
+int wm_spectral_norm_bwd(const float* G, const float* Wsn, const float* u, const float* v, const float* sigma, float* partial,
+                         float* gW, int M, int N, int accumulate, void* stream);
+int wm_bayar_constrain(float* w, int nfilters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

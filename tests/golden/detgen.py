@@ -69,3 +69,16 @@ def fill_module(module, salt=0):
 def subsample(t, stride=97):
     """Every `stride`-th element of the flattened tensor (fixture size control)."""
     return t.detach().reshape(-1)[::stride].clone()
+
+
+@torch.no_grad()
+def fill_f1(net):
+    """fill_module for the row-f1 networks, then: spectral-norm u / v normalised like torch leaves them; the Bayar filter positive
+    (its constraint divides by the filter sum)."""
+    fill_module(net)
+    for k, v in net.state_dict().items():
+        if k.endswith("weight_u") or k.endswith("weight_v"):
+            v.copy_(torch.nn.functional.normalize(v, dim=0, eps=1e-12))
+        if k == "BayarConv2D.weight":
+            v.copy_(uniform(tuple(v.shape), key_seed(k, 7)) + 0.5)
+    return net

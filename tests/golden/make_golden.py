@@ -41,8 +41,11 @@ def install_shims():
     tv = types.ModuleType("torchvision")
     tvt = types.ModuleType("torchvision.transforms")
     tv.transforms = tvt
+    tvm = types.ModuleType("torchvision.models")     # imported, never called, by models/conditional_jpeg_generator.py:6
+    tv.models = tvm
     sys.modules["torchvision"] = tv
     sys.modules["torchvision.transforms"] = tvt
+    sys.modules["torchvision.models"] = tvm
     sys.modules["cv2"] = types.ModuleType("cv2")
     k = types.ModuleType("kornia")
     kf = types.ModuleType("kornia.filters")
@@ -588,6 +591,71 @@ def gen_localise(out, Cfg):
 
 
 # --------------------------------------------------------------------------- TensorBoard scalar log written by the reference's own run
+# --------------------------------------------------------------------------- row f1: Discriminator / FBCNN / QF_predictor
+def _store_grads(out, key, net, stride=997):
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            out[f"{key}/nograd/{n}"] = np.int64(1)
+            continue
+        out[f"{key}/g/{n}"] = npy(detgen.subsample(p.grad, stride))
+        out[f"{key}/gnorm/{n}"] = np.float64(p.grad.norm().item())
+
+
+def gen_f1(out):
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self      # QF_predictor.__init__ moves its 5x5 masks with .cuda() (:732-736); CPU here
+    try:
+        from models.networks import Discriminator
+        from models.conditional_jpeg_generator import FBCNN, QF_predictor, symm_pad
+
+        # ---- Discriminator (networks.py:631-749)
+        net = detgen.fill_f1(Discriminator(in_channels=3, use_sigmoid=True)).train()
+        out["disc/keys"] = np.array([f"{k}:{tuple(v.shape)}" for k, v in net.state_dict().items()])
+        x = detgen.uniform((2, 3, 64, 64), 9100).requires_grad_(True)
+        y = net(x)
+        g = detgen.normal(tuple(y.shape), 9101)
+        (y * g).sum().backward()
+        out["disc/y"], out["disc/gx"] = npy(y), npy(x.grad)
+        _store_grads(out, "disc", net)
+        for k, v in net.state_dict().items():
+            if k.endswith("weight_u") or k.endswith("weight_v"):
+                out[f"disc/after/{k}"] = npy(detgen.subsample(v, 7))
+        net.eval()
+        with torch.no_grad():
+            out["disc/y_eval"] = npy(net(x))
+
+        # ---- FBCNN (conditional_jpeg_generator.py:202-374); 36x44 exercises the replication padding to 40x48
+        net = detgen.fill_f1(FBCNN(nc=[16, 32, 48, 64], nb=2)).train()
+        out["fbcnn/keys"] = np.array([f"{k}:{tuple(v.shape)}" for k, v in net.state_dict().items()])
+        x = detgen.uniform((2, 3, 36, 44), 9200).requires_grad_(True)
+        qf = detgen.uniform((2, 1), 9201).requires_grad_(True)
+        y, feats = net(x, qf)
+        loss = (y * detgen.normal(tuple(y.shape), 9202)).sum()
+        for i, f in enumerate(feats):
+            loss = loss + 0.1 * (f * detgen.normal(tuple(f.shape), 9210 + i)).sum()
+            out[f"fbcnn/feat{i}"] = npy(detgen.subsample(f, 13))
+            out[f"fbcnn/feat{i}_shape"] = np.array(f.shape)
+        loss.backward()
+        out["fbcnn/y"], out["fbcnn/gx"], out["fbcnn/gqf"] = npy(y), npy(x.grad), npy(qf.grad)
+        _store_grads(out, "fbcnn", net, 97)
+
+        # ---- QF_predictor (:697-826)
+        net = detgen.fill_f1(QF_predictor(nc=[16, 32, 48, 64], nb=2, classes=5)).train()
+        out["qfp/keys"] = np.array([f"{k}:{tuple(v.shape)}" for k, v in net.state_dict().items()])
+        x = detgen.uniform((2, 3, 32, 32), 9300).requires_grad_(True)
+        bayar, qf = net(x)
+        ((qf * detgen.normal(tuple(qf.shape), 9301)).sum() + 0.05 * (bayar * detgen.normal(tuple(bayar.shape), 9302)).sum()).backward()
+        out["qfp/bayar"], out["qfp/qf"], out["qfp/gx"] = npy(bayar), npy(qf), npy(x.grad)
+        out["qfp/bayar_weight_after"] = npy(net.BayarConv2D.weight)
+        _store_grads(out, "qfp", net, 97)
+
+        # ---- symm_pad (:865-885), pads larger than a trivial case
+        im = detgen.uniform((1, 2, 5, 7), 9400)
+        out["sympad/y"] = npy(symm_pad(im, (2, 3, 4, 1)))
+    finally:
+        torch.Tensor.cuda = _cuda
+
+
 def gen_tfevents():
     """the first records of one of the reference's TensorBoard event files (runs/RHI3: `PSNR Forward` ... scalars written through
     torch.utils.tensorboard at models/IRNcrop_model.py:399-400) -- DATA, kept as a known-answer file for utils/tb_writer.read_events and
@@ -618,6 +686,7 @@ def main():
         "unet": lambda o: gen_unet(o),
         "step_c3": lambda o: gen_step_c3(o, Cfg),
         "localise": lambda o: gen_localise(o, Cfg),
+        "f1": lambda o: gen_f1(o),
     }
     which = sys.argv[1:] or list(jobs)
     for name in which:

@@ -349,3 +349,87 @@ def test_localise_branch(golden, case):
                     np.testing.assert_allclose(gr.norm().item(), float(g[f"{key}/g{tag}norm/{n}"]), rtol=2e-3, atol=1e-6)
                     close(detgen.subsample(gr, st), g[f"{key}/g{tag}/{n}"], rtol=2e-3, atol=2e-5)
     assert {float(g[f"{key}/logs_it0"][7]), float(g[f"{key}/logs_it1"][7])} == ({0.8, 1.0} if case == "gauss_hipsnr" else {1.0})
+
+
+# ----------------------------------------------------------------------------- Discriminator / FBCNN / QF_predictor
+def _f1_net(name):
+    """the build's module tree on the CPU (parameters only -- its forward needs the GPU): gives the reference's state_dict keys"""
+    from video_watermarking_forgery_detection_amd.models.networks import Discriminator
+    from video_watermarking_forgery_detection_amd.models.conditional_jpeg_generator import FBCNN, QF_predictor
+    if name == "disc":
+        return Discriminator(in_channels=3, use_sigmoid=True)
+    if name == "fbcnn":
+        return FBCNN(nc=[16, 32, 48, 64], nb=2)
+    return QF_predictor(nc=[16, 32, 48, 64], nb=2, classes=5)
+
+
+def _check_grads(g, key, sd, rtol=2e-3, stride=97):
+    n = 0
+    for k in [f[len(key) + 3:] for f in g.files if f.startswith(key + "/g/")]:
+        got = sd[k].grad
+        assert got is not None, k
+        ref_norm = float(g[f"{key}/gnorm/{k}"])
+        assert abs(got.norm().item() - ref_norm) <= rtol * ref_norm + 1e-6, (k, got.norm().item(), ref_norm)
+        close(detgen.subsample(got, stride), g[f"{key}/g/{k}"], rtol=rtol, atol=rtol * max(ref_norm / max(got.numel(), 1) ** 0.5, 1e-6))
+        n += 1
+    return n
+
+
+@pytest.mark.parametrize("name", ["disc", "fbcnn", "qfp"])
+def test_f1_state_dict_keys_are_the_references(golden, name):
+    g = golden("f1")
+    net = _f1_net(name)
+    mine = [f"{k}:{tuple(v.shape)}" for k, v in net.state_dict().items()]
+    assert sorted(mine) == sorted(str(s) for s in g[name + "/keys"])
+
+
+def test_f1_discriminator_oracle(golden):
+    from oracle import f1_ref
+    g = golden("f1")
+    sd = f1_ref.params(detgen.fill_f1(_f1_net("disc")).state_dict())
+    x = detgen.uniform((2, 3, 64, 64), 9100).requires_grad_(True)
+    y = f1_ref.discriminator(sd, x, training=True)
+    (y * detgen.normal(tuple(y.shape), 9101)).sum().backward()
+    close(y, g["disc/y"], rtol=1e-4, atol=1e-6)
+    close(x.grad, g["disc/gx"], rtol=1e-3, atol=1e-7)
+    assert _check_grads(g, "disc", sd, stride=997) == 11
+    for k in [f[len("disc/after/"):] for f in g.files if f.startswith("disc/after/")]:
+        close(detgen.subsample(sd[k], 7), g["disc/after/" + k], rtol=1e-4, atol=1e-6)
+    with torch.no_grad():
+        close(f1_ref.discriminator(sd, x, training=False), g["disc/y_eval"], rtol=1e-4, atol=1e-6)
+
+
+def test_f1_fbcnn_oracle(golden):
+    from oracle import f1_ref
+    g = golden("f1")
+    sd = f1_ref.params(detgen.fill_f1(_f1_net("fbcnn")).state_dict())
+    x = detgen.uniform((2, 3, 36, 44), 9200).requires_grad_(True)
+    qf = detgen.uniform((2, 1), 9201).requires_grad_(True)
+    y, feats = f1_ref.fbcnn(sd, x, qf, nb=2)
+    loss = (y * detgen.normal(tuple(y.shape), 9202)).sum()
+    for i, f in enumerate(feats):
+        assert tuple(f.shape) == tuple(g[f"fbcnn/feat{i}_shape"])
+        loss = loss + 0.1 * (f * detgen.normal(tuple(f.shape), 9210 + i)).sum()
+        close(detgen.subsample(f, 13), g[f"fbcnn/feat{i}"], rtol=1e-4, atol=1e-4)
+    loss.backward()
+    close(y, g["fbcnn/y"], rtol=1e-4, atol=1e-4)
+    scale = float(np.abs(g["fbcnn/gx"]).max())
+    close(x.grad, g["fbcnn/gx"], rtol=1e-3, atol=1e-4 * scale)
+    close(qf.grad, g["fbcnn/gqf"], rtol=1e-3, atol=1e-3 * float(np.abs(g["fbcnn/gqf"]).max()))
+    assert _check_grads(g, "fbcnn", sd) > 60
+    assert sum(1 for f in g.files if f.startswith("fbcnn/nograd/")) == 10          # qf_downsample: saved, never on the forward path
+
+
+def test_f1_qf_predictor_oracle(golden):
+    from oracle import f1_ref
+    g = golden("f1")
+    sd = f1_ref.params(detgen.fill_f1(_f1_net("qfp")).state_dict())
+    x = detgen.uniform((2, 3, 32, 32), 9300).requires_grad_(True)
+    bayar, qf = f1_ref.qf_predictor(sd, x, nb=2)
+    ((qf * detgen.normal(tuple(qf.shape), 9301)).sum() + 0.05 * (bayar * detgen.normal(tuple(bayar.shape), 9302)).sum()).backward()
+    close(bayar, g["qfp/bayar"], rtol=1e-4, atol=1e-5)
+    close(qf, g["qfp/qf"], rtol=1e-4, atol=1e-4 * float(np.abs(g["qfp/qf"]).max()))
+    close(sd["BayarConv2D.weight"], g["qfp/bayar_weight_after"], rtol=1e-5, atol=1e-6)
+    close(x.grad, g["qfp/gx"], rtol=1e-3, atol=1e-4 * float(np.abs(g["qfp/gx"]).max()))
+    assert _check_grads(g, "qfp", sd) > 40
+    close(f1_ref.symm_pad(detgen.uniform((1, 2, 5, 7), 9400), (2, 3, 4, 1)), g["sympad/y"], rtol=0, atol=0)

@@ -1,0 +1,317 @@
+// General convolution family for the networks either side of the HiDDeN path (models/networks.py:631-749
+// Discriminator, models/conditional_jpeg_generator.py:185-374 FBCNN, :697-826 QF_predictor): any kernel size up to 5x5, stride 1 or 2,
+// zero padding, bias; forward, input gradient (also = ConvTranspose2d forward) and weight gradient, NHWC, f32 / bf16 / f16.
+//
+// These layers are outside the benchmarked step, so the kernels are DIRECT implicit GEMMs on MFMA without an LDS stage: a wave owns 16
+// output pixels x 64 output channels; per filter tap and 32-channel chunk every lane loads its 16 bytes of the pixel fragment and of the
+// filter fragments straight from global memory (the filter is L1/L2-resident: every wave reads the same rows).  The filter is the A
+// operand, so accumulator rows are channels and a lane ends with 16 adjacent channels of one pixel (the store pattern of
+// conv3x3_ws.hip).  f32 runs the same loop on v_mfma_f32_16x16x4_f32 (an exact f32 FMA chain: the parity path).
+//   forward : out[b,oy,ox,n] = bias[n] + sum_{ky,kx,k} in[b, oy*s - p + ky, ox*s - p + kx, k] * w[tap][n][k]
+//   dgrad   : din[b,iy,ix,k] = sum_{ky,kx,n} dout[b,(iy + p - ky)/s, (ix + p - kx)/s, n] * wT[tap][k][n]   (taps with a non-integer or
+//             out-of-range source contribute nothing) -- the same kernel with the source geometry inverted
+//   wgrad   : dw[tap][n][k] = sum_{b,oy,ox} dout[b,oy,ox,n] * in[b, oy*s - p + ky, ox*s - p + kx, k], pixels as the MFMA K dimension
+#include "wm_common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct GArgs {
+    const void* in; const void* w; const float* bias; void* out;
+    int B, IH, IW, KC;     // input tensor [B,IH,IW,KC] (KC = its channel stride)
+    int OH, OW, NC;        // output tensor [B,OH,OW,NC]
+    int KH, KW, stride, pad;
+    int dgrad;             // 0: forward geometry, 1: transposed geometry (in = dout [B,IH,IW,KC] of the forward conv whose INPUT is `out`)
+};
+
+// source pixel of output pixel (oy, ox) for tap (ky, kx); returns false if it contributes nothing
+__device__ __forceinline__ bool src_of(const GArgs& a, int oy, int ox, int ky, int kx, int& sy, int& sx) {
+    if (!a.dgrad) {
+        sy = oy * a.stride - a.pad + ky;
+        sx = ox * a.stride - a.pad + kx;
+        return sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW;
+    }
+    const int ty = oy + a.pad - ky, tx = ox + a.pad - kx;
+    if (ty < 0 || tx < 0) return false;
+    if (a.stride == 2) {
+        if ((ty | tx) & 1) return false;
+        sy = ty >> 1; sx = tx >> 1;
+    } else { sy = ty; sx = tx; }
+    return sy < a.IH && sx < a.IW;
+}
+
+template <typename T> struct GOp;   // one MFMA K-step of T
+template <> struct GOp<float> {
+    static constexpr int KSTEP = 4;
+    typedef float frag;
+    static __device__ __forceinline__ frag load(const float* p, int q, int krem) { return q < krem ? p[q] : 0.f; }
+    static __device__ __forceinline__ frag zero() { return 0.f; }
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+};
+template <typename H> struct GOp16 {
+    static constexpr int KSTEP = 32;
+    typedef typename h16<H>::x8 frag;
+    // 8 consecutive channels starting at 8q; channels at or beyond krem (a multiple of 8) read as zero
+    static __device__ __forceinline__ frag load(const H* p, int q, int krem) {
+        if (8 * q >= krem) return zero();
+        return *reinterpret_cast<const frag*>(p + 8 * q);
+    }
+    static __device__ __forceinline__ frag zero() { return __builtin_bit_cast(frag, u32x4{0u, 0u, 0u, 0u}); }
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return h16<H>::mfma16(a, b, c); }
+};
+template <> struct GOp<bf16_t> : GOp16<bf16_t> {};
+template <> struct GOp<f16_t> : GOp16<f16_t> {};
+
+// grid.x = 64-pixel blocks of the flattened output, grid.y = 64-channel blocks; 256 threads = 4 waves x 16 pixels
+template <typename T>
+__global__ __launch_bounds__(256) void gconv_kernel(GArgs a) {
+    typedef GOp<T> Op;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    const size_t npix = (size_t)a.B * a.OH * a.OW;
+    const size_t pix = ((size_t)blockIdx.x * 4 + wave) * 16 + p;
+    const bool pok = pix < npix;
+    const size_t pc = pok ? pix : npix - 1;
+    const int ox = (int)(pc % a.OW), oy = (int)((pc / a.OW) % a.OH), b = (int)(pc / ((size_t)a.OW * a.OH));
+    const int n0 = blockIdx.y * 64;
+    const T* in = (const T*)a.in;
+    const T* w = (const T*)a.w;
+    // A rows: row r of fragment f <-> channel n0 + 16 (r >> 2) + 4 f + (r & 3); this lane provides row p
+    int arow[4];
+    bool aok[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        arow[f] = n0 + 16 * (p >> 2) + 4 * f + (p & 3);
+        aok[f] = arow[f] < a.NC;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int taps = a.KH * a.KW;
+    for (int tap = 0; tap < taps; ++tap) {
+        const int ky = tap / a.KW, kx = tap - ky * a.KW;
+        int sy = 0, sx = 0;
+        const bool ok = src_of(a, oy, ox, ky, kx, sy, sx) && pok;
+        const T* px = in + (((size_t)b * a.IH + (ok ? sy : 0)) * a.IW + (ok ? sx : 0)) * a.KC;
+        const T* wt = w + (size_t)tap * a.NC * a.KC;
+        for (int c0 = 0; c0 < a.KC; c0 += Op::KSTEP) {
+            const int krem = a.KC - c0;
+            const typename Op::frag bf = ok ? Op::load(px + c0, q, krem) : Op::zero();
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const typename Op::frag af = aok[f] ? Op::load(wt + (size_t)arow[f] * a.KC + c0, q, krem) : Op::zero();
+                acc[f] = Op::mma(af, bf, acc[f]);
+            }
+        }
+    }
+    // lane (p, q): channels n0 + 16 q + 4 f + i of pixel p
+    const int cb = n0 + 16 * q;
+    if (pok && cb < a.NC) {
+        T* o = (T*)a.out + pix * a.NC + cb;
+        float v[16];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[4 * f + i] = acc[f][i] + (a.bias ? a.bias[cb + 4 * f + i] : 0.f);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = from_f32<T>(v[e]);
+    }
+}
+
+// ---- weight gradient.  job = (tap, 16-row block of n, 16-column block of k); grid.y = pixel splits; the 4 waves of a workgroup take
+// interleaved 32-pixel (f32: 4-pixel) steps of the split and are summed through LDS.  partial: [nsplit][taps][NC][KC] f32.
+struct GWArgs {
+    const void* dout; const void* in; float* partial;
+    int B, IH, IW, KC, OH, OW, NC, KH, KW, stride, pad, nsplit;
+};
+template <typename T> struct GLd { static __device__ __forceinline__ float f(const T* p) { return to_f32(*p); } };
+
+template <typename T>
+__global__ __launch_bounds__(256) void gconv_wgrad_kernel(GWArgs a) {
+    constexpr bool F32 = sizeof(T) == 4;
+    constexpr int KS = F32 ? 4 : 32, PER = F32 ? 1 : 8;   // pixels per MFMA step, per lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int nb = a.NC / 16, kb = (a.KC + 15) / 16;
+    int job = blockIdx.x;
+    const int kblk = job % kb; job /= kb;
+    const int nblk = job % nb; job /= nb;
+    const int tap = job, ky = tap / a.KW, kx = tap - ky * a.KW;
+    const size_t npix = (size_t)a.B * a.OH * a.OW;
+    const size_t per = (npix + a.nsplit - 1) / a.nsplit, p0 = (size_t)blockIdx.y * per, p1 = p0 + per < npix ? p0 + per : npix;
+    const T* dout = (const T*)a.dout;
+    const T* in = (const T*)a.in;
+    const int n = nblk * 16 + r, k = kblk * 16 + r;
+    const bool kok = k < a.KC;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t s0 = p0 + (size_t)wave * KS; s0 < p1; s0 += 4 * KS) {
+        float av[PER], bv[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const size_t pix = s0 + (size_t)PER * q + e;
+            av[e] = 0.f; bv[e] = 0.f;
+            if (pix < p1) {
+                av[e] = to_f32(dout[pix * a.NC + n]);
+                const int ox = (int)(pix % a.OW), oy = (int)((pix / a.OW) % a.OH), b = (int)(pix / ((size_t)a.OW * a.OH));
+                const int sy = oy * a.stride - a.pad + ky, sx = ox * a.stride - a.pad + kx;
+                if (kok && sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW) bv[e] = to_f32(in[(((size_t)b * a.IH + sy) * a.IW + sx) * a.KC + k]);
+            }
+        }
+        if constexpr (F32) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc, 0, 0, 0);
+        } else {
+            const unsigned a0 = h16_pack<T>(av[0], av[1]), a1 = h16_pack<T>(av[2], av[3]), a2 = h16_pack<T>(av[4], av[5]), a3 = h16_pack<T>(av[6], av[7]);
+            const unsigned b0 = h16_pack<T>(bv[0], bv[1]), b1 = h16_pack<T>(bv[2], bv[3]), b2 = h16_pack<T>(bv[4], bv[5]), b3 = h16_pack<T>(bv[6], bv[7]);
+            typedef typename h16<T>::x8 fr;
+            acc = h16<T>::mfma16(__builtin_bit_cast(fr, u32x4{a0, a1, a2, a3}), __builtin_bit_cast(fr, u32x4{b0, b1, b2, b3}), acc);
+        }
+    }
+    // D[row = n index 4q + i][col = k index r]
+    __shared__ float red[4][16][17];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][4 * q + i][r] = acc[i];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * q + i;
+            const float v = (red[0][row][r] + red[1][row][r]) + (red[2][row][r] + red[3][row][r]);
+            const int kk = kblk * 16 + r;
+            if (kk < a.KC) a.partial[(((size_t)blockIdx.y * a.KH * a.KW + tap) * a.NC + nblk * 16 + row) * a.KC + kk] = v;
+        }
+    }
+}
+
+// dw[co][ci][ky][kx] (+)= sum over splits of partial[split][tap][co][ci]   (co < Cout, ci < Cin: the real extents)
+__global__ __launch_bounds__(256) void gconv_wreduce_kernel(const float* __restrict__ partial, int nsplit, int taps, int NC, int KC, float* __restrict__ dw,
+                                                            int Cout, int Cin, int accumulate) {
+    const size_t total = (size_t)Cout * Cin * taps;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps), ci = (int)((i / taps) % Cin), co = (int)(i / ((size_t)taps * Cin));
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += partial[(((size_t)sp * taps + tap) * NC + co) * KC + ci];
+        dw[i] = (accumulate ? dw[i] : 0.f) + s;
+    }
+}
+
+// pack w [Cout][Cin][KH][KW] f32 -> [taps][RP][CP] T with rows = Cout, cols = Cin (transpose == 0) or rows = Cin, cols = Cout (== 1,
+// the dgrad operand); padding rows / columns are zero
+template <typename T>
+__global__ void gconv_pack_kernel(const float* __restrict__ w, T* __restrict__ wp, int Cout, int Cin, int taps, int RP, int CP, int transpose) {
+    const size_t total = (size_t)taps * RP * CP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CP), r = (int)((i / CP) % RP), tap = (int)(i / ((size_t)CP * RP));
+        const int co = transpose ? c : r, ci = transpose ? r : c;
+        wp[i] = from_f32<T>((co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * taps + tap] : 0.f);
+    }
+}
+
+// column sums of x [npix][C] (the bias gradient): out[c] (+)= sum_pix x[pix][c]; one workgroup per 64 channels, deterministic
+template <typename T>
+__global__ __launch_bounds__(256) void gcolsum_kernel(const T* __restrict__ x, size_t npix, int C, float* __restrict__ out, int Creal, int accumulate) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C)
+        for (size_t p = part; p < npix; p += 4) acc += to_f32(x[p * C + c]);
+    __shared__ float s[4][64];
+    s[part][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (part == 0 && c < Creal) out[c] = (accumulate ? out[c] : 0.f) + (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+}
+
+inline int grid1(size_t n, int cap = 4096) {
+    const size_t g = (n + 255) / 256;
+    return (int)(g > (size_t)cap ? cap : (g < 1 ? 1 : g));
+}
+
+int check_geo(const char* name, int B, int IH, int IW, int KC, int OH, int OW, int NC, int KH, int KW, int stride, int pad, int dtype) {
+    WM_REQUIRE(B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && KC > 0 && NC > 0, WM_E_BADARG, "%s: bad shape", name);
+    WM_REQUIRE(KH >= 1 && KH <= 5 && KW >= 1 && KW <= 5 && (stride == 1 || stride == 2) && pad >= 0 && pad <= 4, WM_E_SHAPE,
+               "%s: kernel %dx%d stride %d pad %d unsupported (<= 5x5, stride 1 or 2)", name, KH, KW, stride, pad);
+    WM_REQUIRE(dtype == WM_F32 || dtype == WM_BF16 || dtype == WM_F16, WM_E_BADARG, "%s: unsupported dtype %d", name, dtype);
+    const int cm = dtype == WM_F32 ? 4 : 16;
+    WM_REQUIRE(KC % cm == 0 && NC % 16 == 0, WM_E_SHAPE, "%s: channel strides KC=%d NC=%d must be multiples of %d / 16 (pad the channels)", name, KC, NC, cm);
+    return WM_OK;
+}
+
+}  // namespace
+
+extern "C" int wm_gconv_pack(const float* w, void* wp, int Cout, int Cin, int KH, int KW, int RP, int CP, int transpose, int dtype, void* stream) {
+    WM_REQUIRE(w && wp && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, WM_E_BADARG, "wm_gconv_pack: bad arguments");
+    WM_REQUIRE(RP >= (transpose ? Cin : Cout) && CP >= (transpose ? Cout : Cin), WM_E_BADARG, "wm_gconv_pack: padded extents smaller than the weight");
+    const size_t total = (size_t)KH * KW * RP * CP;
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_gconv_pack",
+        hipLaunchKernelGGL(gconv_pack_kernel<T>, dim3(grid1(total)), dim3(256), 0, s, w, (T*)wp, Cout, Cin, KH * KW, RP, CP, transpose));
+    WM_LAUNCH_CHECK("wm_gconv_pack");
+    return WM_OK;
+}
+
+// forward (dgrad == 0): in [B,IH,IW,KC], w [KH*KW][NC][KC] (wm_gconv_pack transpose 0), out [B,OH,OW,NC], OH = (IH + 2 pad - KH)/stride + 1.
+// input gradient / ConvTranspose2d forward (dgrad == 1): in = dout [B,IH,IW,KC] on the conv's OUTPUT grid, w [KH*KW][NC][KC] (pack with
+// transpose 1: rows = the conv's input channels), out = din [B,OH,OW,NC] on the conv's INPUT grid.
+extern "C" int wm_gconv_fwd(const void* in, const void* w, const float* bias, void* out, int B, int IH, int IW, int KC, int OH, int OW, int NC,
+                            int KH, int KW, int stride, int pad, int dgrad, int dtype, void* stream) {
+    WM_REQUIRE(in && w && out, WM_E_BADARG, "wm_gconv_fwd: null pointer");
+    int rc = check_geo("wm_gconv_fwd", B, IH, IW, KC, OH, OW, NC, KH, KW, stride, pad, dtype);
+    if (rc) return rc;
+    WM_REQUIRE((((uintptr_t)in | (uintptr_t)w | (uintptr_t)out) & 15) == 0, WM_E_SHAPE, "wm_gconv_fwd: pointers must be 16-byte aligned");
+    GArgs a;
+    a.in = in; a.w = w; a.bias = bias; a.out = out; a.B = B; a.IH = IH; a.IW = IW; a.KC = KC; a.OH = OH; a.OW = OW; a.NC = NC;
+    a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dgrad = dgrad ? 1 : 0;
+    const size_t npix = (size_t)B * OH * OW;
+    const dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((NC + 63) / 64));
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_gconv_fwd", hipLaunchKernelGGL(gconv_kernel<T>, grid, dim3(256), 0, s, a));
+    WM_LAUNCH_CHECK("wm_gconv_fwd");
+    return WM_OK;
+}
+
+extern "C" int wm_gconv_wgrad_nsplit(int B, int OH, int OW, int KC, int NC, int KH, int KW) {
+    const size_t npix = (size_t)B * OH * OW;
+    const long jobs = (long)KH * KW * (NC / 16) * ((KC + 15) / 16);
+    long ns = jobs > 0 ? (4096 + jobs - 1) / jobs : 1;
+    const long cap = (long)((npix + 255) / 256);
+    if (ns > cap) ns = cap;
+    if (ns < 1) ns = 1;
+    if (ns > 256) ns = 256;
+    return (int)ns;
+}
+
+// dw [Cout][Cin][KH][KW] f32 (+)= the weight gradient; dbias [Cout] (+)= column sums of dout (may be NULL).
+// partial: f32 scratch [wm_gconv_wgrad_nsplit(..)][KH*KW][NC][KC].
+extern "C" int wm_gconv_wgrad(const void* dout, const void* in, float* partial, float* dw, float* dbias, int accumulate, int B, int IH, int IW,
+                              int KC, int OH, int OW, int NC, int KH, int KW, int stride, int pad, int Cout, int Cin, int dtype, void* stream) {
+    WM_REQUIRE(dout && in && partial && dw, WM_E_BADARG, "wm_gconv_wgrad: null pointer");
+    int rc = check_geo("wm_gconv_wgrad", B, IH, IW, KC, OH, OW, NC, KH, KW, stride, pad, dtype);
+    if (rc) return rc;
+    WM_REQUIRE(Cout > 0 && Cout <= NC && Cin > 0 && Cin <= KC, WM_E_BADARG, "wm_gconv_wgrad: Cout / Cin exceed the tensors' channel strides");
+    GWArgs a;
+    a.dout = dout; a.in = in; a.partial = partial; a.B = B; a.IH = IH; a.IW = IW; a.KC = KC; a.OH = OH; a.OW = OW; a.NC = NC;
+    a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.nsplit = wm_gconv_wgrad_nsplit(B, OH, OW, KC, NC, KH, KW);
+    const int jobs = KH * KW * (NC / 16) * ((KC + 15) / 16);
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_gconv_wgrad", hipLaunchKernelGGL(gconv_wgrad_kernel<T>, dim3((unsigned)jobs, (unsigned)a.nsplit), dim3(256), 0, s, a));
+    WM_LAUNCH_CHECK("wm_gconv_wgrad");
+    hipLaunchKernelGGL(gconv_wreduce_kernel, dim3(grid1((size_t)Cout * Cin * KH * KW)), dim3(256), 0, s, partial, a.nsplit, KH * KW, NC, KC, dw, Cout, Cin,
+                       accumulate);
+    WM_LAUNCH_CHECK("wm_gconv_wgrad(reduce)");
+    if (dbias) {
+        const size_t npix = (size_t)B * OH * OW;
+        WM_DISPATCH_DTYPE(dtype, "wm_gconv_wgrad(bias)",
+            hipLaunchKernelGGL(gcolsum_kernel<T>, dim3((unsigned)((NC + 63) / 64)), dim3(256), 0, s, (const T*)dout, npix, NC, dbias, Cout, accumulate));
+        WM_LAUNCH_CHECK("wm_gconv_wgrad(bias)");
+    }
+    return WM_OK;
+}
+
+// out [Creal] f32 (+)= column sums of x [npix][C] (the bias gradient of a ConvTranspose2d / Linear whose dout is not a wgrad operand)
+extern "C" int wm_gcolsum(const void* x, size_t npix, int C, float* out, int Creal, int accumulate, int dtype, void* stream) {
+    WM_REQUIRE(x && out && npix > 0 && C > 0 && Creal > 0 && Creal <= C, WM_E_BADARG, "wm_gcolsum: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_gcolsum",
+        hipLaunchKernelGGL(gcolsum_kernel<T>, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, (const T*)x, npix, C, out, Creal, accumulate));
+    WM_LAUNCH_CHECK("wm_gcolsum");
+    return WM_OK;
+}

@@ -1,0 +1,418 @@
+// Elementwise / small kernels of the general layer family (gconv.hip) for the networks of SURVEY §8f row 1:
+//   activations  nn.ReLU, nn.LeakyReLU(0.2), nn.GELU (erf), nn.ELU, nn.Sigmoid, nn.Tanh       conditional_jpeg_generator.py:37-58,292-334; networks.py:667-713
+//   residual add / QFAttention  x + gamma * res(x) + beta                                       conditional_jpeg_generator.py:185-200
+//   AdaptiveAvgPool2d((1,1)) over NHWC                                                           conditional_jpeg_generator.py:790-812
+//   symmetric (symm_pad) / replication padding of an NCHW image into the NHWC conv input, and back    conditional_jpeg_generator.py:865-885,306-309,369
+//   torch.nn.utils.spectral_norm: one power iteration + W / sigma, and its backward              networks.py:1381-1385
+//   the Bayar constraint on a 5x5 filter                                                         conditional_jpeg_generator.py:814-817
+// All tensors NHWC with dtype T (f32 / bf16 / f16); per-sample vectors and parameters f32.
+#include "wm_common.h"
+
+namespace {
+
+enum { ACT_RELU = 0, ACT_LRELU = 1, ACT_GELU = 2, ACT_ELU = 3, ACT_SIGMOID = 4, ACT_TANH = 5 };
+
+__device__ __forceinline__ float act_f(int kind, float x) {
+    switch (kind) {
+        case ACT_RELU: return fmaxf(x, 0.f);
+        case ACT_LRELU: return x > 0.f ? x : 0.2f * x;
+        case ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+        case ACT_ELU: return x > 0.f ? x : expm1f(x);
+        case ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+        default: return tanhf(x);
+    }
+}
+__device__ __forceinline__ float act_d(int kind, float x) {
+    switch (kind) {
+        case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case ACT_LRELU: return x > 0.f ? 1.f : 0.2f;
+        case ACT_GELU: return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+        case ACT_ELU: return x > 0.f ? 1.f : expf(x);
+        case ACT_SIGMOID: { const float s = 1.f / (1.f + expf(-x)); return s * (1.f - s); }
+        default: { const float t = tanhf(x); return 1.f - t * t; }
+    }
+}
+
+inline int grid1(size_t n, int cap = 4096) {
+    const size_t g = (n + 255) / 256;
+    return (int)(g > (size_t)cap ? cap : (g < 1 ? 1 : g));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unary_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n, int kind) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = from_f32<T>(act_f(kind, to_f32(x[i])));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void unary_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ gx, size_t n, int kind) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        gx[i] = from_f32<T>(to_f32(gy[i]) * act_d(kind, to_f32(x[i])));
+}
+// out = a + alpha * b
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, size_t n, float alpha) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = from_f32<T>(to_f32(a[i]) + alpha * to_f32(b[i]));
+}
+// QFAttention: out[b,p,c] = x + gamma[b,c] * res + beta[b,c]
+template <typename T>
+__global__ __launch_bounds__(256) void qfatt_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ out, size_t hw, int C, int ldv, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t b = i / ((size_t)C * hw);
+        out[i] = from_f32<T>(to_f32(x[i]) + gamma[b * ldv + c] * to_f32(res[i]) + beta[b * ldv + c]);
+    }
+}
+// backward: gres = gamma * g (elementwise), ggamma[b,c] = sum_p g * res, gbeta[b,c] = sum_p g; grid = (C/64 blocks, B), 4 pixel lanes
+template <typename T>
+__global__ __launch_bounds__(256) void qfatt_bwd_kernel(const T* __restrict__ g, const T* __restrict__ res, const float* __restrict__ gamma,
+                                                        T* __restrict__ gres, float* __restrict__ ggamma, float* __restrict__ gbeta, size_t hw, int C,
+                                                        int ldv) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6, b = blockIdx.y;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        const float gm = gamma[(size_t)b * ldv + c];
+        for (size_t p = part; p < hw; p += 4) {
+            const size_t i = ((size_t)b * hw + p) * C + c;
+            const float gv = to_f32(g[i]), rv = to_f32(res[i]);
+            gres[i] = from_f32<T>(gm * gv);
+            s1 += gv * rv;
+            s2 += gv;
+        }
+    }
+    __shared__ float sh[2][4][64];
+    sh[0][part][threadIdx.x & 63] = s1; sh[1][part][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        ggamma[(size_t)b * ldv + c] = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
+        gbeta[(size_t)b * ldv + c] = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
+    }
+}
+// global average pool x [B,hw,C] -> out f32 [B,C]; backward: gx[b,p,c] = g[b,c] / hw
+template <typename T>
+__global__ __launch_bounds__(256) void gpool_fwd_kernel(const T* __restrict__ x, float* __restrict__ out, size_t hw, int C) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6, b = blockIdx.y;
+    float s = 0.f;
+    if (c < C)
+        for (size_t p = part; p < hw; p += 4) s += to_f32(x[((size_t)b * hw + p) * C + c]);
+    __shared__ float sh[4][64];
+    sh[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && c < C) out[(size_t)b * C + c] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x])) / (float)hw;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gpool_bwd_kernel(const float* __restrict__ g, T* __restrict__ gx, size_t hw, int C, size_t n) {
+    const float inv = 1.f / (float)hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t b = i / ((size_t)C * hw);
+        gx[i] = from_f32<T>(g[b * C + c] * inv);
+    }
+}
+
+// NCHW f32 image -> padded NHWC tensor in one gather.  mode 0: symmetric (edge-including reflect, symm_pad of
+// conditional_jpeg_generator.py:865-885); mode 1: replicate (nn.ReplicationPad2d, :306-309); pads may be zero (plain layout change).
+__device__ __forceinline__ int pad_src(int j, int lo, int n, int mode) {
+    int t = j - lo;
+    if (mode == 1) return t < 0 ? 0 : (t >= n ? n - 1 : t);
+    const int period = 2 * n;
+    t %= period; if (t < 0) t += period;
+    return t < n ? t : period - 1 - t;
+}
+struct PadGeo { int B, C, H, W, left, right, top, bottom, mode, CP; };
+// x [B,C,H,W] f32 -> out [B,PH,PW,CP] T (channels >= C zero)
+template <typename T>
+__global__ __launch_bounds__(256) void pad_fwd_kernel(const float* __restrict__ x, T* __restrict__ out, PadGeo g) {
+    const int PH = g.H + g.top + g.bottom, PW = g.W + g.left + g.right;
+    const size_t n = (size_t)g.B * PH * PW * g.CP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % g.CP);
+        const int px = (int)((i / g.CP) % PW), py = (int)((i / ((size_t)g.CP * PW)) % PH);
+        const size_t b = i / ((size_t)g.CP * PW * PH);
+        float v = 0.f;
+        if (c < g.C) v = x[((b * g.C + c) * g.H + pad_src(py, g.top, g.H, g.mode)) * g.W + pad_src(px, g.left, g.W, g.mode)];
+        out[i] = from_f32<T>(v);
+    }
+}
+// gx [B,C,H,W] f32 = sum over the padded positions that read each pixel of gp [B,PH,PW,CP]: the direct position plus the border
+// rows / columns whose source is this pixel
+template <typename T>
+__global__ __launch_bounds__(256) void pad_bwd_kernel(const T* __restrict__ gp, float* __restrict__ gx, PadGeo g) {
+    const int PH = g.H + g.top + g.bottom, PW = g.W + g.left + g.right;
+    const size_t n = (size_t)g.B * g.C * g.H * g.W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % g.W), h = (int)((i / g.W) % g.H), c = (int)((i / ((size_t)g.W * g.H)) % g.C);
+        const size_t b = i / ((size_t)g.W * g.H * g.C);
+        float acc = 0.f;
+        for (int iy = -1; iy < g.top + g.bottom; ++iy) {
+            const int py = iy < 0 ? h + g.top : (iy < g.top ? iy : g.H + iy);
+            if (iy >= 0 && pad_src(py, g.top, g.H, g.mode) != h) continue;
+            for (int ix = -1; ix < g.left + g.right; ++ix) {
+                const int px = ix < 0 ? w + g.left : (ix < g.left ? ix : g.W + ix);
+                if (ix >= 0 && pad_src(px, g.left, g.W, g.mode) != w) continue;
+                acc += to_f32(gp[((b * PH + py) * PW + px) * g.CP + c]);
+            }
+        }
+        gx[i] = acc;
+    }
+}
+// x [B,PH,PW,CP] T -> out [B,C,H,W] f32 (the top-left H x W window, the first C channels) and its adjoint (everything else zero)
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_fwd_kernel(const T* __restrict__ x, float* __restrict__ out, int B, int C, int H, int W, int PH, int PW, int CP) {
+    const size_t n = (size_t)B * C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W), h = (int)((i / W) % H), c = (int)((i / ((size_t)W * H)) % C);
+        const size_t b = i / ((size_t)W * H * C);
+        out[i] = to_f32(x[((b * PH + h) * PW + w) * CP + c]);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_bwd_kernel(const float* __restrict__ g, T* __restrict__ gx, int B, int C, int H, int W, int PH, int PW, int CP) {
+    const size_t n = (size_t)B * PH * PW * CP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CP);
+        const int px = (int)((i / CP) % PW), py = (int)((i / ((size_t)CP * PW)) % PH);
+        const size_t b = i / ((size_t)CP * PW * PH);
+        gx[i] = from_f32<T>((c < C && py < H && px < W) ? g[((b * C + c) * H + py) * W + px] : 0.f);
+    }
+}
+
+// ---- spectral norm (torch.nn.utils.spectral_norm, one power iteration): W [M][N] f32 = weight_orig.view(Cout, -1)
+//   v = normalize(W^T u), u = normalize(W v), sigma = u . (W v); eps = 1e-12.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void sn_power_iter_kernel(const float* __restrict__ W, float* __restrict__ u, float* __restrict__ v, float* __restrict__ sigma,
+                                                             int M, int N, int do_iter, float eps) {
+    extern __shared__ float sm[];   // su[M] | red[1024]
+    float* su = sm;
+    float* red = sm + M;
+    const int tid = threadIdx.x;
+    auto block_sum = [&](float x) {
+        red[tid] = x;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        const float r = red[0];
+        __syncthreads();
+        return r;
+    };
+    for (int i = tid; i < M; i += 1024) su[i] = u[i];
+    __syncthreads();
+    if (do_iter) {
+        // v = W^T u (thread per column), normalise
+        float nv = 0.f;
+        for (int j = tid; j < N; j += 1024) {
+            float s = 0.f;
+            for (int i = 0; i < M; ++i) s += W[(size_t)i * N + j] * su[i];
+            v[j] = s;
+            nv += s * s;
+        }
+        const float vn = fmaxf(sqrtf(block_sum(nv)), eps);
+        for (int j = tid; j < N; j += 1024) v[j] /= vn;
+        __syncthreads();
+    }
+    // Wv: a wave per row (lanes across the columns), then u = normalize(Wv), sigma = u . Wv
+    float* wv = su;     // su is not needed after v
+    __syncthreads();
+    for (int i = tid >> 6; i < M; i += 16) {
+        float s = 0.f;
+        for (int j = tid & 63; j < N; j += 64) s += W[(size_t)i * N + j] * v[j];
+        s = wave_sum(s);
+        if ((tid & 63) == 0) wv[i] = s;
+    }
+    __syncthreads();
+    float nu = 0.f;
+    for (int i = tid; i < M; i += 1024) nu += wv[i] * wv[i];
+    const float un2 = block_sum(nu);
+    const float un = fmaxf(sqrtf(un2), eps);
+    float dot = 0.f;
+    for (int i = tid; i < M; i += 1024) {
+        const float ui = do_iter ? wv[i] / un : u[i];
+        if (do_iter) u[i] = ui;
+        dot += ui * wv[i];
+    }
+    const float sg = block_sum(dot);
+    if (tid == 0) sigma[0] = sg;
+}
+__global__ __launch_bounds__(256) void sn_apply_kernel(const float* __restrict__ W, const float* __restrict__ sigma, float* __restrict__ Wsn, size_t n) {
+    const float inv = 1.f / sigma[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) Wsn[i] = W[i] * inv;
+}
+// gW = (G - <G, Wsn> u v^T) / sigma : partial dot products per workgroup, then the elementwise pass
+__global__ __launch_bounds__(256) void sn_dot_kernel(const float* __restrict__ G, const float* __restrict__ Wsn, float* __restrict__ partial, size_t n) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += G[i] * Wsn[i];
+    acc = wave_sum(acc);
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+__global__ __launch_bounds__(256) void sn_bwd_kernel(const float* __restrict__ G, const float* __restrict__ partial, int nparts, const float* __restrict__ u,
+                                                     const float* __restrict__ v, const float* __restrict__ sigma, float* __restrict__ gW, int N, size_t n,
+                                                     int accumulate) {
+    __shared__ float sdot;
+    if (threadIdx.x == 0) {
+        float d = 0.f;
+        for (int k = 0; k < nparts; ++k) d += partial[k];
+        sdot = d;
+    }
+    __syncthreads();
+    const float d = sdot, inv = 1.f / sigma[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / N, c = i - r * N;
+        const float val = (G[i] - d * u[r] * v[c]) * inv;
+        gW[i] = (accumulate ? gW[i] : 0.f) + val;
+    }
+}
+
+// Bayar constraint on w [Co][Ci][5][5] in place (conditional_jpeg_generator.py:814-817): centre := 0, every 5x5 filter divided by its
+// sum, centre := -1
+__global__ void bayar_kernel(float* __restrict__ w, int nfilters) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nfilters) return;
+    float* p = w + (size_t)f * 25;
+    p[12] = 0.f;
+    float s = 0.f;
+    for (int i = 0; i < 25; ++i) s += p[i];
+    const float inv = 1.f / s;
+    for (int i = 0; i < 25; ++i) p[i] *= inv;
+    p[12] += -1.f;
+}
+
+}  // namespace
+
+extern "C" int wm_unary_fwd(const void* x, void* y, size_t n, int kind, int dtype, void* stream) {
+    WM_REQUIRE(x && y && n > 0 && kind >= 0 && kind <= 5, WM_E_BADARG, "wm_unary_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_unary_fwd", hipLaunchKernelGGL(unary_fwd_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, (const T*)x, (T*)y, n, kind));
+    WM_LAUNCH_CHECK("wm_unary_fwd");
+    return WM_OK;
+}
+extern "C" int wm_unary_bwd(const void* x, const void* gy, void* gx, size_t n, int kind, int dtype, void* stream) {
+    WM_REQUIRE(x && gy && gx && n > 0 && kind >= 0 && kind <= 5, WM_E_BADARG, "wm_unary_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_unary_bwd", hipLaunchKernelGGL(unary_bwd_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, (const T*)x, (const T*)gy, (T*)gx, n, kind));
+    WM_LAUNCH_CHECK("wm_unary_bwd");
+    return WM_OK;
+}
+extern "C" int wm_add_scaled(const void* a, const void* b, void* out, size_t n, float alpha, int dtype, void* stream) {
+    WM_REQUIRE(a && b && out && n > 0, WM_E_BADARG, "wm_add_scaled: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_add_scaled", hipLaunchKernelGGL(add_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, (const T*)a, (const T*)b, (T*)out, n, alpha));
+    WM_LAUNCH_CHECK("wm_add_scaled");
+    return WM_OK;
+}
+extern "C" int wm_qfatt_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* out, int B, size_t hw, int C, int ldv, int dtype,
+                            void* stream) {
+    WM_REQUIRE(x && res && gamma && beta && out && B > 0 && hw > 0 && C > 0 && ldv >= C, WM_E_BADARG, "wm_qfatt_fwd: bad arguments");
+    const size_t n = (size_t)B * hw * C;
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_qfatt_fwd",
+        hipLaunchKernelGGL(qfatt_fwd_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, (const T*)x, (const T*)res, gamma, beta, (T*)out, hw, C, ldv, n));
+    WM_LAUNCH_CHECK("wm_qfatt_fwd");
+    return WM_OK;
+}
+extern "C" int wm_qfatt_bwd(const void* g, const void* res, const float* gamma, void* gres, float* ggamma, float* gbeta, int B, size_t hw, int C, int ldv,
+                            int dtype, void* stream) {
+    WM_REQUIRE(g && res && gamma && gres && ggamma && gbeta && B > 0 && hw > 0 && C > 0 && ldv >= C, WM_E_BADARG, "wm_qfatt_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_qfatt_bwd",
+        hipLaunchKernelGGL(qfatt_bwd_kernel<T>, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0, s, (const T*)g, (const T*)res, gamma, (T*)gres, ggamma,
+                           gbeta, hw, C, ldv));
+    WM_LAUNCH_CHECK("wm_qfatt_bwd");
+    return WM_OK;
+}
+extern "C" int wm_gpool_fwd(const void* x, float* out, int B, size_t hw, int C, int dtype, void* stream) {
+    WM_REQUIRE(x && out && B > 0 && hw > 0 && C > 0, WM_E_BADARG, "wm_gpool_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_gpool_fwd",
+        hipLaunchKernelGGL(gpool_fwd_kernel<T>, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0, s, (const T*)x, out, hw, C));
+    WM_LAUNCH_CHECK("wm_gpool_fwd");
+    return WM_OK;
+}
+extern "C" int wm_gpool_bwd(const float* g, void* gx, int B, size_t hw, int C, int dtype, void* stream) {
+    WM_REQUIRE(g && gx && B > 0 && hw > 0 && C > 0, WM_E_BADARG, "wm_gpool_bwd: bad arguments");
+    const size_t n = (size_t)B * hw * C;
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_gpool_bwd", hipLaunchKernelGGL(gpool_bwd_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, g, (T*)gx, hw, C, n));
+    WM_LAUNCH_CHECK("wm_gpool_bwd");
+    return WM_OK;
+}
+static int pad_check(const char* name, const PadGeo& g) {
+    WM_REQUIRE(g.B > 0 && g.C > 0 && g.H > 0 && g.W > 0 && g.left >= 0 && g.right >= 0 && g.top >= 0 && g.bottom >= 0 && g.CP >= g.C, WM_E_BADARG,
+               "%s: bad arguments", name);
+    WM_REQUIRE(g.mode == 0 || g.mode == 1, WM_E_BADARG, "%s: mode %d (0 symmetric, 1 replicate)", name, g.mode);
+    return WM_OK;
+}
+extern "C" int wm_pad_nchw_to_nhwc(const float* x, void* out, int B, int C, int H, int W, int left, int right, int top, int bottom, int mode, int CP,
+                                   int dtype, void* stream) {
+    WM_REQUIRE(x && out, WM_E_BADARG, "wm_pad_nchw_to_nhwc: null pointer");
+    const PadGeo g{B, C, H, W, left, right, top, bottom, mode, CP};
+    int rc = pad_check("wm_pad_nchw_to_nhwc", g);
+    if (rc) return rc;
+    const size_t n = (size_t)B * (H + top + bottom) * (W + left + right) * CP;
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_pad_nchw_to_nhwc", hipLaunchKernelGGL(pad_fwd_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, x, (T*)out, g));
+    WM_LAUNCH_CHECK("wm_pad_nchw_to_nhwc");
+    return WM_OK;
+}
+extern "C" int wm_pad_nchw_to_nhwc_bwd(const void* gp, float* gx, int B, int C, int H, int W, int left, int right, int top, int bottom, int mode, int CP,
+                                       int dtype, void* stream) {
+    WM_REQUIRE(gp && gx, WM_E_BADARG, "wm_pad_nchw_to_nhwc_bwd: null pointer");
+    const PadGeo g{B, C, H, W, left, right, top, bottom, mode, CP};
+    int rc = pad_check("wm_pad_nchw_to_nhwc_bwd", g);
+    if (rc) return rc;
+    const size_t n = (size_t)B * C * H * W;
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_pad_nchw_to_nhwc_bwd", hipLaunchKernelGGL(pad_bwd_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, (const T*)gp, gx, g));
+    WM_LAUNCH_CHECK("wm_pad_nchw_to_nhwc_bwd");
+    return WM_OK;
+}
+extern "C" int wm_gunpack_nchw(const void* x, float* out, int B, int C, int H, int W, int PH, int PW, int CP, int dtype, void* stream) {
+    WM_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0 && PH >= H && PW >= W && CP >= C, WM_E_BADARG, "wm_gunpack_nchw: bad arguments");
+    const size_t n = (size_t)B * C * H * W;
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_gunpack_nchw", hipLaunchKernelGGL(unpack_fwd_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, (const T*)x, out, B, C, H, W, PH, PW, CP));
+    WM_LAUNCH_CHECK("wm_gunpack_nchw");
+    return WM_OK;
+}
+extern "C" int wm_gunpack_nchw_bwd(const float* g, void* gx, int B, int C, int H, int W, int PH, int PW, int CP, int dtype, void* stream) {
+    WM_REQUIRE(g && gx && B > 0 && C > 0 && H > 0 && W > 0 && PH >= H && PW >= W && CP >= C, WM_E_BADARG, "wm_gunpack_nchw_bwd: bad arguments");
+    const size_t n = (size_t)B * PH * PW * CP;
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_gunpack_nchw_bwd", hipLaunchKernelGGL(unpack_bwd_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, g, (T*)gx, B, C, H, W, PH, PW, CP));
+    WM_LAUNCH_CHECK("wm_gunpack_nchw_bwd");
+    return WM_OK;
+}
+
+// u [M], v [N] updated in place when do_iter != 0 (training); sigma [1]; then Wsn = W / sigma
+extern "C" int wm_spectral_norm_fwd(const float* W, float* u, float* v, float* sigma, float* Wsn, int M, int N, int do_iter, void* stream) {
+    WM_REQUIRE(W && u && v && sigma && Wsn && M > 0 && N > 0, WM_E_BADARG, "wm_spectral_norm_fwd: bad arguments");
+    WM_REQUIRE(M <= 8192, WM_E_SHAPE, "wm_spectral_norm_fwd: M=%d too large for the one-workgroup power iteration", M);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sn_power_iter_kernel, dim3(1), dim3(1024), (size_t)(M + 1024) * sizeof(float), s, W, u, v, sigma, M, N, do_iter, 1e-12f);
+    WM_LAUNCH_CHECK("wm_spectral_norm_fwd(power iteration)");
+    const size_t n = (size_t)M * N;
+    hipLaunchKernelGGL(sn_apply_kernel, dim3(grid1(n)), dim3(256), 0, s, W, sigma, Wsn, n);
+    WM_LAUNCH_CHECK("wm_spectral_norm_fwd");
+    return WM_OK;
+}
+// gW (+)= (G - <G, Wsn> u v^T) / sigma; partial: f32[256] scratch
+extern "C" int wm_spectral_norm_bwd(const float* G, const float* Wsn, const float* u, const float* v, const float* sigma, float* partial, float* gW, int M,
+                                    int N, int accumulate, void* stream) {
+    WM_REQUIRE(G && Wsn && u && v && sigma && partial && gW && M > 0 && N > 0, WM_E_BADARG, "wm_spectral_norm_bwd: bad arguments");
+    const size_t n = (size_t)M * N;
+    hipStream_t s = (hipStream_t)stream;
+    const int nparts = grid1(n, 256);
+    hipLaunchKernelGGL(sn_dot_kernel, dim3(nparts), dim3(256), 0, s, G, Wsn, partial, n);
+    hipLaunchKernelGGL(sn_bwd_kernel, dim3(grid1(n)), dim3(256), 0, s, G, partial, nparts, u, v, sigma, gW, N, n, accumulate);
+    WM_LAUNCH_CHECK("wm_spectral_norm_bwd");
+    return WM_OK;
+}
+extern "C" int wm_bayar_constrain(float* w, int nfilters, void* stream) {
+    WM_REQUIRE(w && nfilters > 0, WM_E_BADARG, "wm_bayar_constrain: bad arguments");
+    hipLaunchKernelGGL(bayar_kernel, dim3((nfilters + 63) / 64), dim3(64), 0, (hipStream_t)stream, w, nfilters);
+    WM_LAUNCH_CHECK("wm_bayar_constrain");
+    return WM_OK;
+}

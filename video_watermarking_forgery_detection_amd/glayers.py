@@ -1,0 +1,329 @@
+"""General HIP layer toolkit for the networks either side of the HiDDeN path: nn.Conv2d / nn.ConvTranspose2d /
+nn.Linear / the activations / residual and QF-attention combines / global average pooling / symmetric and replication padding /
+spectral norm, each an autograd Function over the C ABI's wm_gconv_* / wm_unary_* / ... entry points (include/wm_hip.h, "general
+layer family").  Parameters keep torch's layouts and names, so a reference state_dict loads unchanged
+(models/networks.py:631-749, models/conditional_jpeg_generator.py:40-374,697-826).
+
+Between layers an activation is a contiguous NHWC tensor [B,H,W,Cp] (Cp = channels rounded up to 16, padding channels zero or
+ignored) of the network's compute dtype (float32 = the parity path, bfloat16 / float16); images enter and leave as NCHW float32
+through `to_nhwc` / `to_nchw`.  There is no CPU or PyTorch fallback: every Function launches HIP kernels.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import ops
+
+cpad = ops.cpad
+
+
+def _pad_bias(bias, n):
+    if bias is None:
+        return None
+    out = torch.zeros(n, device=bias.device, dtype=torch.float32)
+    out[: bias.numel()] = bias.detach()
+    return out
+
+
+class _ConvFn(Function):
+    """nn.Conv2d on NHWC: weight [Cout,Cin,KH,KW] f32"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        Cout, Cin, KH, KW = weight.shape
+        B, IH, IW, KC = x.shape
+        if KC != cpad(Cin):
+            raise ValueError(f"conv expects {Cin} input channels (stride {cpad(Cin)}), the activation has stride {KC}")
+        NC = cpad(Cout)
+        OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
+        wp = ops.gconv_pack(weight.detach(), NC, KC, False, x.dtype)
+        out = ops.gconv_fwd(x, wp, _pad_bias(bias, NC), (OH, OW), KH, KW, stride, pad)
+        ctx.save_for_backward(x, weight)
+        ctx.geo = (stride, pad, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        stride, pad, has_bias = ctx.geo
+        Cout, Cin, KH, KW = weight.shape
+        g = g.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wt = ops.gconv_pack(weight.detach(), x.shape[3], g.shape[3], True, g.dtype)
+            gx = ops.gconv_fwd(g, wt, None, (x.shape[1], x.shape[2]), KH, KW, stride, pad, dgrad=True)
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            gw, gb = ops.gconv_wgrad(g, x, Cout, Cin, KH, KW, stride, pad, want_bias=has_bias)
+        return gx, gw, gb, None, None
+
+
+class _ConvTFn(Function):
+    """nn.ConvTranspose2d on NHWC: weight [Cin,Cout,KH,KW] f32 -- the input gradient of the conv Cout -> Cin with the same filter"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        Cin, Cout, KH, KW = weight.shape
+        B, IH, IW, KC = x.shape
+        if KC != cpad(Cin):
+            raise ValueError(f"transposed conv expects {Cin} input channels, the activation has stride {KC}")
+        NC = cpad(Cout)
+        OH, OW = (IH - 1) * stride - 2 * pad + KH, (IW - 1) * stride - 2 * pad + KW
+        wt = ops.gconv_pack(weight.detach(), NC, KC, True, x.dtype)
+        out = ops.gconv_fwd(x, wt, _pad_bias(bias, NC), (OH, OW), KH, KW, stride, pad, dgrad=True)
+        ctx.save_for_backward(x, weight)
+        ctx.geo = (stride, pad, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        stride, pad, has_bias = ctx.geo
+        Cin, Cout, KH, KW = weight.shape
+        g = g.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wp = ops.gconv_pack(weight.detach(), x.shape[3], g.shape[3], False, g.dtype)
+            gx = ops.gconv_fwd(g, wp, None, (x.shape[1], x.shape[2]), KH, KW, stride, pad)
+        if ctx.needs_input_grad[1]:
+            gw, _ = ops.gconv_wgrad(x, g, Cin, Cout, KH, KW, stride, pad, want_bias=False)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = ops.gcolsum(g, Cout)
+        return gx, gw, gb, None, None
+
+
+class _ActFn(Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return ops.unary_fwd(x, kind)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.unary_bwd(x, g, ctx.kind), None
+
+
+class _AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add_scaled(a, b, 1.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class _QFAttFn(Function):
+    """x + gamma * res + beta, gamma / beta f32 [B, Cp] (conditional_jpeg_generator.py:196-200)"""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta):
+        ctx.save_for_backward(res, gamma)
+        return ops.qfatt_fwd(x, res, gamma, beta)
+
+    @staticmethod
+    def backward(ctx, g):
+        res, gamma = ctx.saved_tensors
+        gres, gg, gb = ops.qfatt_bwd(g, res, gamma)
+        return g, gres, gg, gb
+
+
+class _PoolFn(Function):
+    """AdaptiveAvgPool2d((1,1)) + Flatten: NHWC [B,H,W,Cp] -> f32 [B,1,1,Cp]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.meta = (tuple(x.shape), x.dtype)
+        return ops.gpool_fwd(x).view(x.shape[0], 1, 1, x.shape[3])
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dtype = ctx.meta
+        return ops.gpool_bwd(g.reshape(shape[0], shape[3]), shape, dtype)
+
+
+class _ToNHWC(Function):
+    @staticmethod
+    def forward(ctx, img, pads, mode, dtype):
+        ctx.meta = (tuple(img.shape), pads, mode)
+        return ops.pad_nchw_to_nhwc(img, pads, mode, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, pads, mode = ctx.meta
+        return ops.pad_nchw_to_nhwc_bwd(g, shape, pads, mode), None, None, None
+
+
+class _ToNCHW(Function):
+    @staticmethod
+    def forward(ctx, x, C, H, W):
+        ctx.meta = (tuple(x.shape), x.dtype)
+        return ops.gunpack_nchw(x, C, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dtype = ctx.meta
+        return ops.gunpack_nchw_bwd(g, shape, dtype), None, None, None
+
+
+class _SpectralNormFn(Function):
+    @staticmethod
+    def forward(ctx, weight_orig, u, v, do_iter):
+        wsn, sigma = ops.spectral_norm_fwd(weight_orig.detach(), u, v, do_iter)
+        ctx.save_for_backward(wsn, u.clone(), v.clone(), sigma)
+        return wsn
+
+    @staticmethod
+    def backward(ctx, g):
+        wsn, u, v, sigma = ctx.saved_tensors
+        return ops.spectral_norm_bwd(g, wsn, u, v, sigma), None, None, None
+
+
+def to_nhwc(img, dtype, pads=(0, 0, 0, 0), mode=ops.PAD_SYMMETRIC):
+    """NCHW f32 image -> NHWC activation, optionally padded (left, right, top, bottom) symmetrically or by replication"""
+    if not img.is_cuda:
+        raise RuntimeError("the HIP layer toolkit runs on the GPU only; there is no CPU fallback")
+    return _ToNHWC.apply(img, tuple(int(p) for p in pads), mode, dtype)
+
+
+def to_nchw(x, C, H=None, W=None):
+    """NHWC activation -> NCHW f32 [B,C,H,W] (the top-left window when H / W are smaller than the activation's)"""
+    return _ToNCHW.apply(x, C, x.shape[1] if H is None else H, x.shape[2] if W is None else W)
+
+
+def add(a, b):
+    return _AddFn.apply(a, b)
+
+
+def qf_attention(x, res, gamma, beta):
+    B, Cp = x.shape[0], x.shape[3]
+    return _QFAttFn.apply(x, res, gamma.reshape(B, -1).float(), beta.reshape(B, -1).float())
+
+
+def global_avg_pool(x):
+    return _PoolFn.apply(x)
+
+
+def _kaiming_uniform_(w, fan_in):
+    # torch's default reset_parameters of Conv2d / Linear: kaiming_uniform_(a=sqrt(5)) = U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+    bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+    with torch.no_grad():
+        w.uniform_(-bound, bound)
+
+
+class Conv2d(nn.Module):
+    """nn.Conv2d(in, out, k, stride, padding, bias) on NHWC activations; parameters `weight` [out,in,k,k], `bias` [out]"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = int(kernel_size), int(stride), int(padding)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, self.kernel_size, self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        fan_in = in_channels * self.kernel_size ** 2
+        _kaiming_uniform_(self.weight, fan_in)
+        if bias:
+            _kaiming_uniform_(self.bias, fan_in)
+
+    def effective_weight(self):
+        return self.weight
+
+    def forward(self, x):
+        return _ConvFn.apply(x, self.effective_weight(), self.bias, self.stride, self.padding)
+
+
+class SpectralNormConv2d(Conv2d):
+    """nn.utils.spectral_norm(nn.Conv2d(..)) (networks.py:1381-1385): parameters `weight_orig`, buffers `weight_u`, `weight_v`,
+    one power iteration per training forward, none in eval."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, bias)
+        w = self.weight
+        del self._parameters["weight"]
+        self.weight_orig = nn.Parameter(w.data)
+        n = in_channels * self.kernel_size ** 2
+        self.register_buffer("weight_u", nn.functional.normalize(torch.randn(out_channels), dim=0, eps=1e-12))
+        self.register_buffer("weight_v", nn.functional.normalize(torch.randn(n), dim=0, eps=1e-12))
+
+    def effective_weight(self):
+        return _SpectralNormFn.apply(self.weight_orig, self.weight_u, self.weight_v, self.training)
+
+
+class ConvTranspose2d(nn.Module):
+    """nn.ConvTranspose2d(in, out, k, stride, padding, bias); `weight` [in,out,k,k]"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = int(kernel_size), int(stride), int(padding)
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, self.kernel_size, self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        fan_in = out_channels * self.kernel_size ** 2      # torch computes fan_in from dim 1 of the weight
+        _kaiming_uniform_(self.weight, fan_in)
+        if bias:
+            _kaiming_uniform_(self.bias, fan_in)
+
+    def forward(self, x):
+        return _ConvTFn.apply(x, self.weight, self.bias, self.stride, self.padding)
+
+
+class Linear(nn.Module):
+    """nn.Linear on [B,1,1,Cp] activations (a 1x1 convolution); `weight` [out,in], `bias` [out]"""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        _kaiming_uniform_(self.weight, in_features)
+        if bias:
+            _kaiming_uniform_(self.bias, in_features)
+
+    def forward(self, x):
+        return _ConvFn.apply(x, self.weight.view(self.out_features, self.in_features, 1, 1), self.bias, 1, 0)
+
+
+class Act(nn.Module):
+    """ReLU / LeakyReLU(0.2) / GELU / ELU / Sigmoid / Tanh"""
+
+    def __init__(self, kind):
+        super().__init__()
+        if kind not in ops.ACT_KINDS:
+            raise ValueError(f"unknown activation {kind}")
+        self.kind = kind
+
+    def forward(self, x):
+        return _ActFn.apply(x, self.kind)
+
+    def extra_repr(self):
+        return self.kind
+
+
+class GlobalAvgPool(nn.Module):
+    """torch.nn.AdaptiveAvgPool2d((1,1)); the result is f32 [B,1,1,Cp] and stays f32 through the Linear layers after it"""
+
+    def forward(self, x):
+        return global_avg_pool(x)
+
+
+class Flatten(nn.Module):
+    """torch.nn.Flatten after the pool: nothing to do on [B,1,1,Cp]; keeps the reference's Sequential indices"""
+
+    def forward(self, x):
+        return x
+
+
+def vector_in(v, dtype=torch.float32):
+    """[B,F] f32 -> [B,1,1,cpad(F)] activation (the input of a Linear stack)"""
+    if not v.is_cuda:
+        raise RuntimeError("the HIP layer toolkit runs on the GPU only; there is no CPU fallback")
+    B, F = v.shape
+    return to_nhwc(v.reshape(B, F, 1, 1).float(), dtype)
+
+
+def vector_out(x, F):
+    """[B,1,1,Cp] -> [B,F] f32"""
+    return to_nchw(x, F, 1, 1).reshape(x.shape[0], F)

@@ -1071,3 +1071,232 @@ def diffjpeg_bwd(x, gy, rounding, factor):
     rc = _lib.lib().wm_diffjpeg_bwd(_p(x), _p(gy), _p(gx), c_int(B), c_int(H), c_int(W), c_int(rounding), c_float(factor), _stream())
     _lib.check(rc, "wm_diffjpeg_bwd")
     return gx
+
+
+# ----------------------------------------------------------------------------- general layer family (include/wm_hip.h)
+ACT_KINDS = {"relu": 0, "lrelu": 1, "gelu": 2, "elu": 3, "sigmoid": 4, "tanh": 5}
+
+
+def cpad(c):
+    """channel stride of an NHWC activation with c real channels"""
+    return (int(c) + 15) // 16 * 16
+
+
+def _nhwc(x):
+    _need_cuda(x)
+    if x.dim() != 4 or not x.is_contiguous() or x.shape[3] % 16:
+        raise ValueError(f"expected a contiguous NHWC tensor with a channel stride that is a multiple of 16, got {tuple(x.shape)}")
+    return x
+
+
+def gconv_pack(w, rows, cols, transpose, dtype):
+    """w [Cout,Cin,KH,KW] f32 -> [KH*KW][rows][cols] of dtype (rows = Cout / cols = Cin, or swapped with transpose)"""
+    _need_cuda(w)
+    assert w.dim() == 4 and w.dtype == torch.float32
+    w = w.contiguous()
+    Cout, Cin, KH, KW = w.shape
+    wp = torch.empty(KH * KW, rows, cols, device=w.device, dtype=dtype)
+    rc = _lib.lib().wm_gconv_pack(_p(w), _p(wp), c_int(Cout), c_int(Cin), c_int(KH), c_int(KW), c_int(rows), c_int(cols), c_int(1 if transpose else 0),
+                                  c_int(dt_id(dtype)), _stream())
+    _lib.check(rc, "wm_gconv_pack")
+    return wp
+
+
+def gconv_fwd(x, wp, bias, out_hw, KH, KW, stride, pad, dgrad=False):
+    """x [B,IH,IW,KC]; wp [taps][NC][KC] (gconv_pack); bias f32 [NC] or None; -> [B,OH,OW,NC]"""
+    x = _nhwc(x)
+    B, IH, IW, KC = x.shape
+    taps, NC, KC2 = wp.shape
+    if taps != KH * KW or KC2 != KC or wp.dtype != x.dtype:
+        raise ValueError(f"packed filter {tuple(wp.shape)} {wp.dtype} does not fit the input {tuple(x.shape)} {x.dtype} / {KH}x{KW}")
+    if bias is not None and (bias.numel() != NC or bias.dtype != torch.float32):
+        raise ValueError("bias must be f32 with one entry per (padded) output channel")
+    OH, OW = out_hw
+    out = torch.empty(B, OH, OW, NC, device=x.device, dtype=x.dtype)
+    rc = _lib.lib().wm_gconv_fwd(_p(x), _p(wp), _p(bias), _p(out), c_int(B), c_int(IH), c_int(IW), c_int(KC), c_int(OH), c_int(OW), c_int(NC),
+                                 c_int(KH), c_int(KW), c_int(stride), c_int(pad), c_int(1 if dgrad else 0), c_int(dt_id(x.dtype)), _stream())
+    _lib.check(rc, "wm_gconv_fwd")
+    return out
+
+
+def gconv_wgrad(dout, x, Cout, Cin, KH, KW, stride, pad, want_bias=True):
+    """dw [Cout,Cin,KH,KW] f32, dbias [Cout] f32 (or None) of the conv x [B,IH,IW,KC] -> dout [B,OH,OW,NC]"""
+    dout, x = _nhwc(dout), _nhwc(x)
+    B, OH, OW, NC = dout.shape
+    _, IH, IW, KC = x.shape
+    if x.shape[0] != B or x.dtype != dout.dtype:
+        raise ValueError("gconv_wgrad: operands disagree")
+    ns = _lib.lib().wm_gconv_wgrad_nsplit(c_int(B), c_int(OH), c_int(OW), c_int(KC), c_int(NC), c_int(KH), c_int(KW))
+    partial = torch.empty(ns * KH * KW * NC * KC, device=x.device, dtype=torch.float32)
+    dw = torch.empty(Cout, Cin, KH, KW, device=x.device, dtype=torch.float32)
+    db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_bias else None
+    rc = _lib.lib().wm_gconv_wgrad(_p(dout), _p(x), _p(partial), _p(dw), _p(db), c_int(0), c_int(B), c_int(IH), c_int(IW), c_int(KC), c_int(OH),
+                                   c_int(OW), c_int(NC), c_int(KH), c_int(KW), c_int(stride), c_int(pad), c_int(Cout), c_int(Cin),
+                                   c_int(dt_id(x.dtype)), _stream())
+    _lib.check(rc, "wm_gconv_wgrad")
+    return dw, db
+
+
+def gcolsum(x, creal):
+    x = _nhwc(x)
+    C = x.shape[3]
+    out = torch.empty(creal, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().wm_gcolsum(_p(x), c_size_t(x.numel() // C), c_int(C), _p(out), c_int(creal), c_int(0), c_int(dt_id(x.dtype)), _stream())
+    _lib.check(rc, "wm_gcolsum")
+    return out
+
+
+def unary_fwd(x, kind):
+    _need_cuda(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    rc = _lib.lib().wm_unary_fwd(_p(x), _p(y), c_size_t(x.numel()), c_int(ACT_KINDS[kind]), c_int(dt_id(x.dtype)), _stream())
+    _lib.check(rc, "wm_unary_fwd")
+    return y
+
+
+def unary_bwd(x, gy, kind):
+    _need_cuda(x, gy)
+    gy = gy.contiguous()
+    gx = torch.empty_like(x)
+    rc = _lib.lib().wm_unary_bwd(_p(x), _p(gy), _p(gx), c_size_t(x.numel()), c_int(ACT_KINDS[kind]), c_int(dt_id(x.dtype)), _stream())
+    _lib.check(rc, "wm_unary_bwd")
+    return gx
+
+
+def add_scaled(a, b, alpha=1.0):
+    _need_cuda(a, b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise ValueError("add_scaled: operands disagree")
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    rc = _lib.lib().wm_add_scaled(_p(a), _p(b), _p(out), c_size_t(a.numel()), c_float(alpha), c_int(dt_id(a.dtype)), _stream())
+    _lib.check(rc, "wm_add_scaled")
+    return out
+
+
+def qfatt_fwd(x, res, gamma, beta):
+    """x + gamma[b,c] * res + beta[b,c]; gamma / beta f32 [B, >= C]"""
+    x, res = _nhwc(x), _nhwc(res)
+    B, H, W, C = x.shape
+    gamma, beta = gamma.contiguous(), beta.contiguous()
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.shape == beta.shape and gamma.shape[0] == B
+    out = torch.empty_like(x)
+    rc = _lib.lib().wm_qfatt_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(out), c_int(B), c_size_t(H * W), c_int(C), c_int(gamma.shape[1]),
+                                 c_int(dt_id(x.dtype)), _stream())
+    _lib.check(rc, "wm_qfatt_fwd")
+    return out
+
+
+def qfatt_bwd(g, res, gamma):
+    g, res = _nhwc(g.contiguous()), _nhwc(res)
+    B, H, W, C = g.shape
+    gamma = gamma.contiguous()
+    gres = torch.empty_like(g)
+    gg = torch.zeros_like(gamma)
+    gb = torch.zeros_like(gamma)
+    rc = _lib.lib().wm_qfatt_bwd(_p(g), _p(res), _p(gamma), _p(gres), _p(gg), _p(gb), c_int(B), c_size_t(H * W), c_int(C), c_int(gamma.shape[1]),
+                                 c_int(dt_id(g.dtype)), _stream())
+    _lib.check(rc, "wm_qfatt_bwd")
+    return gres, gg, gb
+
+
+def gpool_fwd(x):
+    x = _nhwc(x)
+    B, H, W, C = x.shape
+    out = torch.empty(B, C, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().wm_gpool_fwd(_p(x), _p(out), c_int(B), c_size_t(H * W), c_int(C), c_int(dt_id(x.dtype)), _stream())
+    _lib.check(rc, "wm_gpool_fwd")
+    return out
+
+
+def gpool_bwd(g, shape, dtype):
+    _need_cuda(g)
+    B, H, W, C = shape
+    g = g.contiguous().float()
+    gx = torch.empty(B, H, W, C, device=g.device, dtype=dtype)
+    rc = _lib.lib().wm_gpool_bwd(_p(g), _p(gx), c_int(B), c_size_t(H * W), c_int(C), c_int(dt_id(dtype)), _stream())
+    _lib.check(rc, "wm_gpool_bwd")
+    return gx
+
+
+PAD_SYMMETRIC, PAD_REPLICATE = 0, 1
+
+
+def pad_nchw_to_nhwc(x, pads, mode, dtype):
+    """x [B,C,H,W] f32 -> [B,H+top+bottom,W+left+right,cpad(C)] of dtype; pads = (left, right, top, bottom)"""
+    _need_cuda(x)
+    x = x.contiguous().float()
+    B, C, H, W = x.shape
+    l, r, t, b = pads
+    out = torch.empty(B, H + t + b, W + l + r, cpad(C), device=x.device, dtype=dtype)
+    rc = _lib.lib().wm_pad_nchw_to_nhwc(_p(x), _p(out), c_int(B), c_int(C), c_int(H), c_int(W), c_int(l), c_int(r), c_int(t), c_int(b), c_int(mode),
+                                        c_int(out.shape[3]), c_int(dt_id(dtype)), _stream())
+    _lib.check(rc, "wm_pad_nchw_to_nhwc")
+    return out
+
+
+def pad_nchw_to_nhwc_bwd(gp, shape, pads, mode):
+    gp = _nhwc(gp.contiguous())
+    B, C, H, W = shape
+    l, r, t, b = pads
+    gx = torch.empty(B, C, H, W, device=gp.device, dtype=torch.float32)
+    rc = _lib.lib().wm_pad_nchw_to_nhwc_bwd(_p(gp), _p(gx), c_int(B), c_int(C), c_int(H), c_int(W), c_int(l), c_int(r), c_int(t), c_int(b), c_int(mode),
+                                            c_int(gp.shape[3]), c_int(dt_id(gp.dtype)), _stream())
+    _lib.check(rc, "wm_pad_nchw_to_nhwc_bwd")
+    return gx
+
+
+def gunpack_nchw(x, C, H, W):
+    x = _nhwc(x)
+    B, PH, PW, CP = x.shape
+    out = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().wm_gunpack_nchw(_p(x), _p(out), c_int(B), c_int(C), c_int(H), c_int(W), c_int(PH), c_int(PW), c_int(CP), c_int(dt_id(x.dtype)),
+                                    _stream())
+    _lib.check(rc, "wm_gunpack_nchw")
+    return out
+
+
+def gunpack_nchw_bwd(g, shape, dtype):
+    _need_cuda(g)
+    g = g.contiguous().float()
+    B, C, H, W = g.shape
+    _, PH, PW, CP = shape
+    gx = torch.empty(B, PH, PW, CP, device=g.device, dtype=dtype)
+    rc = _lib.lib().wm_gunpack_nchw_bwd(_p(g), _p(gx), c_int(B), c_int(C), c_int(H), c_int(W), c_int(PH), c_int(PW), c_int(CP), c_int(dt_id(dtype)),
+                                        _stream())
+    _lib.check(rc, "wm_gunpack_nchw_bwd")
+    return gx
+
+
+def spectral_norm_fwd(w, u, v, do_iter):
+    """w [Cout, ...] f32; u [Cout], v [N] updated in place when do_iter; -> (w / sigma, sigma [1])"""
+    _need_cuda(w, u, v)
+    w = w.contiguous()
+    M, N = w.shape[0], w.numel() // w.shape[0]
+    assert u.numel() == M and v.numel() == N and u.is_contiguous() and v.is_contiguous() and u.dtype == torch.float32 and v.dtype == torch.float32
+    sigma = torch.empty(1, device=w.device, dtype=torch.float32)
+    wsn = torch.empty_like(w)
+    rc = _lib.lib().wm_spectral_norm_fwd(_p(w), _p(u), _p(v), _p(sigma), _p(wsn), c_int(M), c_int(N), c_int(1 if do_iter else 0), _stream())
+    _lib.check(rc, "wm_spectral_norm_fwd")
+    return wsn, sigma
+
+
+def spectral_norm_bwd(g, wsn, u, v, sigma):
+    _need_cuda(g)
+    g = g.contiguous()
+    M, N = g.shape[0], g.numel() // g.shape[0]
+    partial = torch.empty(256, device=g.device, dtype=torch.float32)
+    gw = torch.empty_like(g)
+    rc = _lib.lib().wm_spectral_norm_bwd(_p(g), _p(wsn), _p(u), _p(v), _p(sigma), _p(partial), _p(gw), c_int(M), c_int(N), c_int(0), _stream())
+    _lib.check(rc, "wm_spectral_norm_bwd")
+    return gw
+
+
+def bayar_constrain_(w):
+    """the Bayar constraint on w [Co,Ci,5,5] in place (conditional_jpeg_generator.py:814-817)"""
+    _need_cuda(w)
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.shape[-2:] == (5, 5)
+    rc = _lib.lib().wm_bayar_constrain(_p(w), c_int(w.shape[0] * w.shape[1]), _stream())
+    _lib.check(rc, "wm_bayar_constrain")
+    return w
