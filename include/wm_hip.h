@@ -479,6 +479,23 @@ int wm_spectral_norm_bwd(const float* G, const float* Wsn, const float* u, const
                          float* gW, int M, int N, int accumulate, void* stream);
 int wm_bayar_constrain(float* w, int nfilters, void* stream);
 
+/* ------------------------------------------------------------------ invertible embedder pieces
+ * replaces, for models/invertible_net.py: HaarDownsampling / HaarUpsampling (:178-292: F.conv2d / F.conv_transpose2d with the fixed
+ * 2x2 Haar filters, groups = channels), RNVPCouplingBlock's affine (:140-141,153-173), and the channel narrow / cat around the
+ * subnets (:150-151,175,318-322,363).  NHWC tensors of `dtype`; the coupling subnets' convolutions are wm_gconv_*.
+ * wm_haar: up 0 (analysis): in [B,2H,2W,CPin] with C channels -> out [B,H,W,CPout], channel 4c+k = fac * (Haar filter k of channel c),
+ *          k = 0 sum, 1 horizontal, 2 vertical, 3 diagonal difference; up 1 (synthesis): in [B,H,W,CPin] with 4C channels ->
+ *          out [B,2H,2W,CPout] with C channels, scaled by fac.  Each is the other's adjoint (= its backward) for equal fac; padding
+ *          channels of `out` are written as zero.
+ * wm_chan_copy: dst[p][doff + c] = src[p][soff + c] for c < n over npix pixels (strides in elements).
+ * wm_coupling_fwd: rev 0: y = e(s) * x + t; rev 1: y = (x - t) / e(s); e(s) = exp(clamp * (2 sigmoid(s) - 1)) + eps.
+ * wm_coupling_bwd: gradients wrt x, s, t from g = dL/dy; v = x for rev 0, v = the forward's OUTPUT y for rev 1. */
+int wm_haar(const void* in, void* out, int B, int H, int W, int C, int CPin, int CPout, float fac, int up, int dtype, void* stream);
+int wm_chan_copy(const void* src, void* dst, size_t npix, int sstride, int soff, int dstride, int doff, int n, int dtype, void* stream);
+int wm_coupling_fwd(const void* x, const void* s, const void* t, void* y, size_t n, float clamp, float eps, int rev, int dtype, void* stream);
+int wm_coupling_bwd(const void* g, const void* v, const void* s, void* gx, void* gs, void* gt, size_t n, float clamp, float eps, int rev,
+                    int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

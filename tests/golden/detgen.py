@@ -82,3 +82,17 @@ def fill_f1(net):
         if k == "BayarConv2D.weight":
             v.copy_(uniform(tuple(v.shape), key_seed(k, 7)) + 0.5)
     return net
+
+
+@torch.no_grad()
+def fill_f2(net):
+    """fill_module for the invertible embedder: the fixed Haar filters keep their values; each subnet's last conv (zero at the
+    reference's initialisation) is scaled down so ten stacked couplings stay well inside fp32 range."""
+    keep = {k: v.clone() for k, v in net.state_dict().items() if k.endswith("haar_weights")}
+    fill_module(net)
+    for k, v in net.state_dict().items():
+        if k in keep:
+            v.copy_(keep[k])
+        elif k.endswith("conv5.weight"):
+            v.mul_(0.2)
+    return net

@@ -656,6 +656,38 @@ def gen_f1(out):
         torch.Tensor.cuda = _cuda
 
 
+# --------------------------------------------------------------------------- row f2: the invertible embedder
+def gen_f2(out):
+    from models.invertible_net import Inveritible_Decolorization_PAMI, ResBlock, DenseBlock
+
+    # the configuration models/IRNcrop_model.py:132-134 builds (4 channels, block_num [1,1,1], ResBlock subnets), at 32x32
+    net = detgen.fill_f2(Inveritible_Decolorization_PAMI(dims_in=[[4, 32, 32]], block_num=[1, 1, 1], subnet_constructor=ResBlock)).train()
+    out["pami/keys"] = np.array([f"{k}:{tuple(v.shape)}" for k, v in net.state_dict().items()])
+    x = detgen.uniform((2, 4, 32, 32), 9500).requires_grad_(True)
+    y = net(x)
+    (y * detgen.normal(tuple(y.shape), 9501)).sum().backward()
+    out["pami/y"], out["pami/gx"] = npy(y), npy(x.grad)
+    _store_grads(out, "pami", net, 97)
+    net.zero_grad()
+    z = detgen.uniform((2, 4, 32, 32), 9502).requires_grad_(True)
+    r, mid = net(z, rev=True)
+    ((r * detgen.normal(tuple(r.shape), 9503)).sum() + 0.1 * (mid * detgen.normal(tuple(mid.shape), 9504)).sum()).backward()
+    out["pami_rev/y"], out["pami_rev/mid"], out["pami_rev/gx"] = npy(r), npy(mid), npy(z.grad)
+    _store_grads(out, "pami_rev", net, 97)
+    with torch.no_grad():
+        back, _ = net(net(x), rev=True)
+    out["pami/roundtrip_err"] = np.float64((back - x).abs().max().item())
+
+    # DenseBlock subnets, two levels, 3 channels
+    net = detgen.fill_f2(Inveritible_Decolorization_PAMI(dims_in=[[3, 16, 16]], down_num=2, block_num=[1, 1], subnet_constructor=DenseBlock)).train()
+    out["dense/keys"] = np.array([f"{k}:{tuple(v.shape)}" for k, v in net.state_dict().items()])
+    x = detgen.uniform((2, 3, 16, 16), 9600).requires_grad_(True)
+    y = net(x)
+    (y * detgen.normal(tuple(y.shape), 9601)).sum().backward()
+    out["dense/y"], out["dense/gx"] = npy(y), npy(x.grad)
+    _store_grads(out, "dense", net, 97)
+
+
 def gen_tfevents():
     """the first records of one of the reference's TensorBoard event files (runs/RHI3: `PSNR Forward` ... scalars written through
     torch.utils.tensorboard at models/IRNcrop_model.py:399-400) -- DATA, kept as a known-answer file for utils/tb_writer.read_events and
@@ -687,6 +719,7 @@ def main():
         "step_c3": lambda o: gen_step_c3(o, Cfg),
         "localise": lambda o: gen_localise(o, Cfg),
         "f1": lambda o: gen_f1(o),
+        "f2": lambda o: gen_f2(o),
     }
     which = sys.argv[1:] or list(jobs)
     for name in which:

@@ -327,3 +327,89 @@ def vector_in(v, dtype=torch.float32):
 def vector_out(x, F):
     """[B,1,1,Cp] -> [B,F] f32"""
     return to_nchw(x, F, 1, 1).reshape(x.shape[0], F)
+
+
+# ----------------------------------------------------------------------------- invertible-embedder pieces (models/invertible_net.py)
+class _HaarFn(Function):
+    @staticmethod
+    def forward(ctx, x, C, fac, up):
+        ctx.meta = (C, fac, up)
+        return ops.haar(x, C, fac, up)
+
+    @staticmethod
+    def backward(ctx, g):
+        C, fac, up = ctx.meta
+        return ops.haar(g.contiguous(), C, fac, not up), None, None, None
+
+
+class _ChanSliceFn(Function):
+    """x[..., off:off+n] as its own NHWC tensor (stride cpad(n), padding zero)"""
+
+    @staticmethod
+    def forward(ctx, x, off, n):
+        ctx.meta = (tuple(x.shape), off, n)
+        out = torch.zeros(*x.shape[:3], cpad(n), device=x.device, dtype=x.dtype)
+        return ops.chan_copy_(out, 0, x, off, n)
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, off, n = ctx.meta
+        gx = torch.zeros(shape, device=g.device, dtype=g.dtype)
+        return ops.chan_copy_(gx, off, g.contiguous(), 0, n), None, None
+
+
+class _ChanCatFn(Function):
+    """torch.cat((a[..., :na], b[..., :nb]), channel dim)"""
+
+    @staticmethod
+    def forward(ctx, a, na, b, nb):
+        ctx.meta = (na, nb)
+        out = torch.zeros(*a.shape[:3], cpad(na + nb), device=a.device, dtype=a.dtype)
+        ops.chan_copy_(out, 0, a, 0, na)
+        return ops.chan_copy_(out, na, b, 0, nb)
+
+    @staticmethod
+    def backward(ctx, g):
+        na, nb = ctx.meta
+        g = g.contiguous()
+        ga = torch.zeros(*g.shape[:3], cpad(na), device=g.device, dtype=g.dtype)
+        gb = torch.zeros(*g.shape[:3], cpad(nb), device=g.device, dtype=g.dtype)
+        return ops.chan_copy_(ga, 0, g, 0, na), None, ops.chan_copy_(gb, 0, g, na, nb), None
+
+
+class _CouplingFn(Function):
+    """rev False: e(s) * x + t; rev True: (x - t) / e(s)   (invertible_net.py:140-141,153-173)"""
+
+    @staticmethod
+    def forward(ctx, x, s, t, clamp, eps, rev):
+        y = ops.coupling_fwd(x, s, t, clamp, eps, rev)
+        ctx.save_for_backward(y if rev else x, s)
+        ctx.meta = (clamp, eps, rev)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        v, s = ctx.saved_tensors
+        clamp, eps, rev = ctx.meta
+        gx, gs, gt = ops.coupling_bwd(g, v, s, clamp, eps, rev)
+        return gx, gs, gt, None, None, None
+
+
+def haar_down(x, C, fac):
+    return _HaarFn.apply(x, C, float(fac), False)
+
+
+def haar_up(x, C, fac):
+    return _HaarFn.apply(x, C, float(fac), True)
+
+
+def chan_slice(x, off, n):
+    return _ChanSliceFn.apply(x, off, n)
+
+
+def chan_cat(a, na, b, nb):
+    return _ChanCatFn.apply(a, na, b, nb)
+
+
+def coupling(x, s, t, clamp, eps, rev):
+    return _CouplingFn.apply(x, s, t, float(clamp), float(eps), bool(rev))

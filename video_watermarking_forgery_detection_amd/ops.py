@@ -1300,3 +1300,58 @@ def bayar_constrain_(w):
     rc = _lib.lib().wm_bayar_constrain(_p(w), c_int(w.shape[0] * w.shape[1]), _stream())
     _lib.check(rc, "wm_bayar_constrain")
     return w
+
+
+# ----------------------------------------------------------------------------- invertible embedder pieces
+def haar(x, C, fac, up):
+    """up False: [B,2H,2W,cpad(C)] -> [B,H,W,cpad(4C)] (analysis); up True: [B,H,W,cpad(4C)] -> [B,2H,2W,cpad(C)] (synthesis)"""
+    x = _nhwc(x)
+    B, XH, XW, CPin = x.shape
+    if up:
+        if CPin < 4 * C:
+            raise ValueError(f"haar synthesis of {C} channels needs {4 * C} input channels, stride is {CPin}")
+        H, W = XH, XW
+        out = torch.empty(B, 2 * H, 2 * W, cpad(C), device=x.device, dtype=x.dtype)
+    else:
+        if XH % 2 or XW % 2 or CPin < C:
+            raise ValueError(f"haar analysis needs even height / width and {C} channels, got {tuple(x.shape)}")
+        H, W = XH // 2, XW // 2
+        out = torch.empty(B, H, W, cpad(4 * C), device=x.device, dtype=x.dtype)
+    rc = _lib.lib().wm_haar(_p(x), _p(out), c_int(B), c_int(H), c_int(W), c_int(C), c_int(CPin), c_int(out.shape[3]), c_float(fac), c_int(1 if up else 0),
+                            c_int(dt_id(x.dtype)), _stream())
+    _lib.check(rc, "wm_haar")
+    return out
+
+
+def chan_copy_(dst, doff, src, soff, n):
+    """dst[..., doff:doff+n] = src[..., soff:soff+n] (NHWC, same pixel grid)"""
+    dst, src = _nhwc(dst), _nhwc(src)
+    if dst.shape[:3] != src.shape[:3] or dst.dtype != src.dtype:
+        raise ValueError("chan_copy_: pixel grids / dtypes disagree")
+    npix = dst.shape[0] * dst.shape[1] * dst.shape[2]
+    rc = _lib.lib().wm_chan_copy(_p(src), _p(dst), c_size_t(npix), c_int(src.shape[3]), c_int(soff), c_int(dst.shape[3]), c_int(doff), c_int(n),
+                                 c_int(dt_id(dst.dtype)), _stream())
+    _lib.check(rc, "wm_chan_copy")
+    return dst
+
+
+def coupling_fwd(x, s, t, clamp, eps, rev):
+    _need_cuda(x, s, t)
+    if not (x.shape == s.shape == t.shape and x.dtype == s.dtype == t.dtype):
+        raise ValueError("coupling_fwd: operands disagree")
+    x, s, t = x.contiguous(), s.contiguous(), t.contiguous()
+    y = torch.empty_like(x)
+    rc = _lib.lib().wm_coupling_fwd(_p(x), _p(s), _p(t), _p(y), c_size_t(x.numel()), c_float(clamp), c_float(eps), c_int(1 if rev else 0),
+                                    c_int(dt_id(x.dtype)), _stream())
+    _lib.check(rc, "wm_coupling_fwd")
+    return y
+
+
+def coupling_bwd(g, v, s, clamp, eps, rev):
+    _need_cuda(g, v, s)
+    g = g.contiguous()
+    gx, gs, gt = torch.empty_like(g), torch.empty_like(g), torch.empty_like(g)
+    rc = _lib.lib().wm_coupling_bwd(_p(g), _p(v), _p(s), _p(gx), _p(gs), _p(gt), c_size_t(g.numel()), c_float(clamp), c_float(eps),
+                                    c_int(1 if rev else 0), c_int(dt_id(g.dtype)), _stream())
+    _lib.check(rc, "wm_coupling_bwd")
+    return gx, gs, gt
