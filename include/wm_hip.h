@@ -496,6 +496,20 @@ int wm_coupling_fwd(const void* x, const void* s, const void* t, void* y, size_t
 int wm_coupling_bwd(const void* g, const void* v, const void* s, void* gx, void* gs, void* gt, size_t n, float clamp, float eps, int rev,
                     int dtype, void* stream);
 
+/* ------------------------------------------------------------------ losses of the literal IRNrhi step
+ * replaces, in models/IRNrhi_model.py:425-560: nn.SmoothL1Loss (:148,476,481), nn.BCELoss (:147,492-493,505), nn.CrossEntropyLoss
+ * (:156,454,485), torch.clamp(x,0,1) with its gradient mask (:430,472), PSNR of the postprocess()ed images (:527, metrics.py:30-46).
+ * Each loss call writes the mean loss to a device scalar and, when grad_out != NULL, d loss / d input for an upstream gradient of 1
+ * (the host scales it by the loss weight with wm_scale_dev).  partials: f32 scratch [nparts <= 2048] (doubles for the PSNR: feed
+ * them to wm_psnr_gate).  f32 only. */
+int wm_smooth_l1(const float* a, const float* b, size_t n, float beta, float* partials, int nparts, float* loss_out, float* grad_out,
+                 void* stream);
+int wm_bce_prob(const float* p, float target, size_t n, float* partials, int nparts, float* loss_out, float* grad_out, void* stream);
+int wm_cross_entropy(const float* logits, const long long* labels, int B, int K, int ld, float* loss_out, float* grad_out, void* stream);
+int wm_clamp01_fwd(const float* x, float* y, size_t n, void* stream);
+int wm_clamp01_bwd(const float* x, const float* g, float* gx, size_t n, void* stream);
+int wm_psnr255_partials(const float* a, const float* b, size_t n, double* partials, int nparts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

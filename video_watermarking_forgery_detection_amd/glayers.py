@@ -413,3 +413,121 @@ def chan_cat(a, na, b, nb):
 
 def coupling(x, s, t, clamp, eps, rev):
     return _CouplingFn.apply(x, s, t, float(clamp), float(eps), bool(rev))
+
+
+# ----------------------------------------------------------------------------- losses, clamp and the optimiser of the literal IRNrhi step
+def _scaled(grad, g):
+    """grad * g for the 1-element upstream gradient g of a scalar loss (device scalar: no host sync)"""
+    return ops.scale_dev_(grad.clone(), g.reshape(1).float().contiguous())
+
+
+class _SmoothL1Fn(Function):
+    @staticmethod
+    def forward(ctx, a, b, beta):
+        loss, grad = ops.smooth_l1(a, b, beta, want_grad=True)
+        ctx.save_for_backward(grad)
+        ctx.shape = a.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return _scaled(grad, g).reshape(ctx.shape), None, None
+
+
+class _BCEProbFn(Function):
+    @staticmethod
+    def forward(ctx, p, target):
+        loss, grad = ops.bce_prob(p, target, want_grad=True)
+        ctx.save_for_backward(grad)
+        ctx.shape = p.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return _scaled(grad, g).reshape(ctx.shape), None
+
+
+class _CrossEntropyFn(Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, grad = ops.cross_entropy(logits, labels, want_grad=True)
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return _scaled(grad, g), None
+
+
+class _Clamp01Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.clamp01_fwd(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.clamp01_bwd(x, g)
+
+
+def smooth_l1_loss(a, b, beta=1.0):
+    """nn.SmoothL1Loss()(a, b); b carries no gradient (a target)"""
+    return _SmoothL1Fn.apply(a, b.detach(), float(beta))
+
+
+def bce_loss(p, target):
+    """nn.BCELoss()(p, torch.full_like(p, target)) for the constant targets 1.0 / 0.0 of the GAN terms"""
+    return _BCEProbFn.apply(p, float(target))
+
+
+def cross_entropy_loss(logits, labels):
+    return _CrossEntropyFn.apply(logits, labels)
+
+
+def clamp01(x):
+    """torch.clamp(x, 0, 1) (gradient where 0 <= x <= 1)"""
+    return _Clamp01Fn.apply(x)
+
+
+class FlatAdamW:
+    """torch.optim.AdamW over ONE flat f32 buffer holding every trainable parameter of `module` (each nn.Parameter becomes a view of
+    it, each .grad a view of a flat gradient buffer autograd accumulates into): zero_grad = one memset, clip_grad_norm_ = one norm,
+    step = one launch of the library's Adam kernel with decoupled weight decay."""
+
+    def __init__(self, module, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        ps = [p for p in module.parameters() if p.requires_grad]
+        if not ps or not all(p.is_cuda and p.dtype == torch.float32 for p in ps):
+            raise RuntimeError("FlatAdamW: parameters must be float32 CUDA tensors (move the module to the GPU first)")
+        n = sum(p.numel() for p in ps)
+        dev = ps[0].device
+        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.params, o = ps, 0
+        with torch.no_grad():
+            for p in ps:
+                k = p.numel()
+                self.flat[o:o + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat[o:o + k].view(p.shape)
+                p.grad = self.grad[o:o + k].view(p.shape)
+                o += k
+        self.lr, self.betas, self.eps, self.weight_decay, self.t = lr, betas, eps, weight_decay, 0
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p in self.params:           # autograd may have replaced a view (first accumulation into a None grad)
+            if p.grad is None or p.grad.data_ptr() < self.grad.data_ptr() or p.grad.data_ptr() >= self.grad.data_ptr() + 4 * self.grad.numel():
+                raise RuntimeError("FlatAdamW: a parameter's .grad no longer views the flat gradient buffer (do not set grads to None)")
+
+    def clip_grad_norm_(self, max_norm):
+        """nn.utils.clip_grad_norm_(module.parameters(), max_norm); returns the [2] device tensor (coefficient, total norm)"""
+        return ops.clip_grad_norm_([self.grad], float(max_norm))
+
+    def step(self):
+        self.t += 1
+        ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t, decoupled=True)

@@ -1355,3 +1355,89 @@ def coupling_bwd(g, v, s, clamp, eps, rev):
                                     c_int(1 if rev else 0), c_int(dt_id(g.dtype)), _stream())
     _lib.check(rc, "wm_coupling_bwd")
     return gx, gs, gt
+
+
+# ----------------------------------------------------------------------------- losses of the literal IRNrhi step
+def _nparts(n):
+    return max(1, min(1024, (n + 4095) // 4096))
+
+
+def smooth_l1(a, b, beta=1.0, want_grad=True):
+    """nn.SmoothL1Loss()(a, b) -> (loss [1] device scalar, d loss / d a or None)"""
+    _need_cuda(a, b)
+    a, b = a.contiguous().float(), b.contiguous().float()
+    if a.shape != b.shape:
+        raise ValueError("smooth_l1: shapes disagree")
+    n = a.numel()
+    part = torch.empty(_nparts(n), device=a.device, dtype=torch.float32)
+    loss = torch.empty(1, device=a.device, dtype=torch.float32)
+    grad = torch.empty_like(a) if want_grad else None
+    rc = _lib.lib().wm_smooth_l1(_p(a), _p(b), c_size_t(n), c_float(beta), _p(part), c_int(part.numel()), _p(loss), _p(grad), _stream())
+    _lib.check(rc, "wm_smooth_l1")
+    return loss, grad
+
+
+def bce_prob(p, target, want_grad=True):
+    """nn.BCELoss()(p, full_like(p, target)) -> (loss [1], d loss / d p or None)"""
+    _need_cuda(p)
+    p = p.contiguous().float()
+    n = p.numel()
+    part = torch.empty(_nparts(n), device=p.device, dtype=torch.float32)
+    loss = torch.empty(1, device=p.device, dtype=torch.float32)
+    grad = torch.empty_like(p) if want_grad else None
+    rc = _lib.lib().wm_bce_prob(_p(p), c_float(target), c_size_t(n), _p(part), c_int(part.numel()), _p(loss), _p(grad), _stream())
+    _lib.check(rc, "wm_bce_prob")
+    return loss, grad
+
+
+def cross_entropy(logits, labels, want_grad=True):
+    """nn.CrossEntropyLoss()(logits [B,K] f32, labels [B] int64) -> (loss [1], d loss / d logits or None)"""
+    _need_cuda(logits, labels)
+    logits = logits.contiguous().float()
+    labels = labels.contiguous()
+    if logits.dim() != 2 or labels.dtype != torch.int64 or labels.numel() != logits.shape[0]:
+        raise ValueError("cross_entropy: logits [B,K] f32 and labels [B] int64 expected")
+    B, K = logits.shape
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    grad = torch.empty_like(logits) if want_grad else None
+    rc = _lib.lib().wm_cross_entropy(_p(logits), _p(labels), c_int(B), c_int(K), c_int(K), _p(loss), _p(grad), _stream())
+    _lib.check(rc, "wm_cross_entropy")
+    return loss, grad
+
+
+def clamp01_fwd(x):
+    _need_cuda(x)
+    x = x.contiguous().float()
+    y = torch.empty_like(x)
+    rc = _lib.lib().wm_clamp01_fwd(_p(x), _p(y), c_size_t(x.numel()), _stream())
+    _lib.check(rc, "wm_clamp01_fwd")
+    return y
+
+
+def clamp01_bwd(x, g):
+    _need_cuda(x, g)
+    g = g.contiguous().float()
+    gx = torch.empty_like(g)
+    rc = _lib.lib().wm_clamp01_bwd(_p(x), _p(g), _p(gx), c_size_t(g.numel()), _stream())
+    _lib.check(rc, "wm_clamp01_bwd")
+    return gx
+
+
+def psnr255(a, b):
+    """PSNR of int(255 a) against int(255 b) (metrics.py:30-46 on postprocess()ed images) -> [1] device scalar (0 when equal)"""
+    _need_cuda(a, b)
+    a, b = a.contiguous().float(), b.contiguous().float()
+    n = a.numel()
+    part = torch.empty(_nparts(n), device=a.device, dtype=torch.float64)
+    rc = _lib.lib().wm_psnr255_partials(_p(a), _p(b), c_size_t(n), _p(part), c_int(part.numel()), _stream())
+    _lib.check(rc, "wm_psnr255_partials")
+    return psnr_gate(part, n)[0:1]
+
+
+def scale_dev_(x, scale_dev):
+    """x *= scale_dev[0] (a device scalar)"""
+    _need_cuda(x, scale_dev)
+    assert x.is_contiguous() and x.dtype == torch.float32 and scale_dev.dtype == torch.float32
+    rc = _lib.lib().wm_scale_dev(_p(x), c_size_t(x.numel()), _p(scale_dev), _stream())
+    _lib.check(rc, "wm_scale_dev")
+    return x
