@@ -907,3 +907,41 @@ def test_after_concat_layer_without_the_concat(case, dtype):
     ops.concat_side_msg_wgrad(dyh, msg.cuda(), dw2, True, 0, L)
     torch.testing.assert_close(dw2[:, :L].cpu(), 2 * dw[:, :L].cpu(), rtol=1e-5, atol=1e-5 * g.abs().max().item())
     assert torch.equal(dw2[:, L:], dw[:, L:])
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, torch.bfloat16, False), (3, 40, 56, torch.bfloat16, True), (1, 21, 37, torch.float16, False),
+                                  (16, 128, 128, torch.bfloat16, True)])
+def test_fused_backward_kernel_against_the_two_kernel_form(case):
+    """csrc/bwd_ws.hip (input gradient + the feeding layer's BatchNorm sums + weight gradient from one staged dy / a tile) against
+    wm_conv3x3_dgrad_applyfused + wm_conv3x3_wgrad on the same operands: dx bit-identical (same dy, same MFMA order over K), the
+    sums and the weight gradient equal up to the summation order over tiles."""
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, dt, rev = case
+    C = 64
+    g = nhwc(detgen.normal((B, C, H, W), 901), dt, C)
+    y = nhwc(detgen.normal((B, C, H, W), 902, mean=0.2), dt, C)
+    xr = nhwc(detgen.normal((B, C, H, W), 903, mean=0.1), dt, C)
+    stats = torch.empty(4, C, device="cuda")
+    stats[0] = detgen.normal((C,), 904, mean=1.0, std=0.3).cuda(); stats[1] = detgen.normal((C,), 905, std=0.3).cuda()
+    stats[2] = detgen.normal((C,), 906, std=0.2).cuda(); stats[3] = detgen.uniform((C,), 907).cuda() + 0.5
+    coef = torch.empty(3, C, device="cuda")
+    coef[0] = detgen.normal((C,), 908, mean=1.0, std=0.2).cuda(); coef[1] = detgen.normal((C,), 909, std=0.01).cuda(); coef[2] = detgen.normal((C,), 910, std=0.01).cuda()
+    in_scale = detgen.normal((C,), 911, mean=1.0, std=0.3).cuda(); in_shift = detgen.normal((C,), 912, std=0.3).cuda()
+    w = detgen.normal((C, C, 3, 3), 913, std=0.05).cuda()
+    wpt = ops.pack_w3x3(w, C, C, dt, transpose=True)
+    dw0 = torch.zeros(C, C, 3, 3, device="cuda"); dw1 = torch.full((C, C, 3, 3), 0.25, device="cuda")
+    dy, dx0, part0 = ops.conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, xr, in_scale, in_shift, reverse=rev)
+    ops.conv3x3_wgrad(xr, C, in_scale, in_shift, dy, dw0, False, reverse=not rev)
+    dx1, part1, _ = ops.conv3x3_bwd_fused(g, y, stats, coef, wpt, xr, in_scale, in_shift, dw1, True, reverse=rev)
+    torch.cuda.synchronize()
+    assert dx0.float().abs().max().item() > 0
+    if dt == torch.bfloat16:
+        assert torch.equal(dx0, dx1)
+    else:   # f16: one dy element in ~50,000 lands on the other side of a rounding tie (an f32 last-bit difference in the folded constants'
+        # evaluation order); its 3x3 neighbourhood of dx then differs by one f16 ulp here and there
+        diff = (dx0.float() - dx1.float()).abs()
+        assert (diff > 0).float().mean().item() < 2e-3 and diff.max().item() <= 2.0 ** -10 * max(1.0, dx0.float().abs().max().item())
+    s0, s1 = part0.double().sum(0), part1.double().sum(0)
+    assert (s0 - s1).abs().max().item() <= (1e-5 if dt == torch.bfloat16 else 1e-3) * s0.abs().max().item()
+    ref = dw0 + 0.25
+    assert (dw1 - ref).abs().max().item() <= 2e-4 * dw0.abs().max().item()

@@ -34,14 +34,15 @@ for rnd in range(ROUNDS):
     for v in variants:
         setter(v)
         h.train_on_batch([images, messages])
-        timer = ops.KernelTimer(lambda name, i: name == "conv3x3_fwd" and i["Cin"] == 64 and i["CoutP"] == 64)
+        tname = os.environ.get("AB_TIME")   # time another op family's launches instead (e.g. AB_TIME=conv3x3_bwd_fused)
+        timer = ops.KernelTimer((lambda name, i: name == tname) if tname else (lambda name, i: name == "conv3x3_fwd" and i["Cin"] == 64 and i["CoutP"] == 64))
         ops.set_kernel_timer(timer)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(STEPS):
             h.train_on_batch([images, messages])
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / STEPS * 1e3
         ops.set_kernel_timer(None)
-        k = timer.elapsed_ms()
+        k = timer.elapsed_ms() or [0.0]
         res[v].append(dt); kres[v].append(1e3 * sum(k) / len(k))
 for v in variants:
-    print(f"variant {v}: step ms median {statistics.median(res[v]):.3f} min {min(res[v]):.3f} | 64->64 conv launches avg us median {statistics.median(kres[v]):.1f} min {min(kres[v]):.1f} | rounds {['%.2f' % x for x in res[v]]}")
+    print(f"variant {v}: step ms median {statistics.median(res[v]):.3f} min {min(res[v]):.3f} | timed launches avg us median {statistics.median(kres[v]):.1f} min {min(kres[v]):.1f} | rounds {['%.2f' % x for x in res[v]]}")

@@ -25,7 +25,7 @@ EXTRA = {"conv3x3_ws.hip": ["-fno-slp-vectorize"], "wgrad_ws.hip": ["-fno-slp-ve
 
 
 # kernels of these files exist for both 16-bit activation dtypes: compiled a second time with -DWM_H16_F16 (the f16 twins)
-TWICE = ("conv3x3_ws.hip", "wgrad_ws.hip", "conv3x3_stream.hip", "upconv_mfma.hip", "concat_side.hip")
+TWICE = ("conv3x3_ws.hip", "wgrad_ws.hip", "conv3x3_stream.hip", "upconv_mfma.hip", "concat_side.hip", "bwd_ws.hip")
 
 
 def _sources():

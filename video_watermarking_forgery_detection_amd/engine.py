@@ -215,7 +215,12 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
             and ops.conv3x3_dgrad_applyfused_supported(64, rows, dtype)):
         coef = coef_of()
         wpt = _packed(conv, 64, rows, dtype, None, True)
-        if feed_stats:
+        if feed_stats and rows == 64 and ops.conv3x3_bwd_fused_supported(dtype):
+            # one kernel: dy is formed in the LDS and feeds BOTH gradients; the feeding layer's raw output is read once (csrc/bwd_ws.hip)
+            gx, part, pcoef = ops.conv3x3_bwd_fused(g, y, ctx.stats, coef, wpt, x.t, x.scale, x.shift, grads[conv.weight], accumulate,
+                                                    reverse=d, fin=rider)
+            x.bwd = (gx, part, pcoef, gx._version)
+        elif feed_stats:
             dy, gx, part = ops.conv3x3_dgrad_applyfused(g, y, ctx.stats, coef, wpt, x.t, x.scale, x.shift, reverse=d)
             pcoef = ops.conv3x3_wgrad(x.t, x.t.shape[-1], x.scale, x.shift, dy, grads[conv.weight], accumulate, reverse=not d, fin=rider(part))
             x.bwd = (gx, part, pcoef, gx._version)

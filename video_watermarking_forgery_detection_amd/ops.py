@@ -487,6 +487,32 @@ def conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry=None, r_scale=None, r_sh
     return dy, dx, part
 
 
+def conv3x3_bwd_fused_supported(dtype):
+    return bool(_lib.lib().wm_conv3x3_bwd_fused_supported(c_int(dt_id(dtype))))
+
+
+def conv3x3_bwd_fused(g, y, stats, coef, wpt, xr, in_scale, in_shift, dw, accumulate, reverse=False, fin=None):
+    """The whole backward of a 64 -> 64 body layer fed by another ConvBNRelu in one pass (csrc/bwd_ws.hip): returns
+    (dx, partials [nwg,2,64] = the feeding layer's BatchNorm-backward sums, the rider's coef or None); dw is written in place."""
+    B, H, W, C = y.shape
+    assert C == 64 and g.shape == y.shape and xr.shape == y.shape and g.is_contiguous() and y.is_contiguous() and xr.is_contiguous()
+    assert tuple(wpt.shape) == (9, 64, 64) and stats.is_contiguous() and coef.is_contiguous() and dw.is_contiguous()
+    L = _lib.lib()
+    nwg = L.wm_conv3x3_bwd_fused_nwg(c_int(B), c_int(H), c_int(W))
+    dx = torch.empty_like(y)
+    part = torch.empty(nwg, 2, 64, device=y.device, dtype=torch.float32)
+    fst, fcoef = _fin_rider(fin(part) if callable(fin) else fin)     # fin: a rider dict, or a function of the partial rows this call produces
+    ws = torch.empty(nwg * 9 * 64 * 64, device=y.device, dtype=torch.float32)
+    Cout, Cin = dw.shape[0], dw.shape[1]
+    info = {"B": B, "H": H, "W": W, "dtype": y.dtype}
+    rc = _timed("conv3x3_bwd_fused", info, lambda: L.wm_conv3x3_bwd_fused(
+        _p(g), _p(y), _p(stats), _p(coef), _p(wpt), _p(xr), _p(in_scale), _p(in_shift), _p(dx), _p(part), _p(ws), _p(dw),
+        c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(Cout), c_int(dtype_id(y)),
+        ctypes.byref(fst) if fst is not None else None, _sweep(reverse), _stream()))
+    _lib.check(rc, "wm_conv3x3_bwd_fused")
+    return dx, part, fcoef
+
+
 def linear_head_fwd(pooled, w, bias, I):
     """pooled [B,ldp] f32 (first I columns used), w [O,I], bias [O] -> [B,O]"""
     _need_cuda(pooled, w)
