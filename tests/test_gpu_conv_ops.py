@@ -628,6 +628,7 @@ def test_fused_apply_keeps_the_training_step(debug_lib):
     L = debug_lib   # the -DWM_DEBUG build: the release library has no A/B switches
     outs = []
     try:
+        L.wm_debug_bwd_fuse(ctypes.c_int(0))   # (the one-kernel backward sums over 8x16 tiles: compared at a tolerance in the test below)
         for on in (1, 0):
             L.wm_debug_apply_fuse(ctypes.c_int(on))
             torch.manual_seed(10)
@@ -638,9 +639,40 @@ def test_fused_apply_keeps_the_training_step(debug_lib):
             outs.append((dict(losses), [p.detach().clone() for p in list(h.encoder_decoder.parameters()) + list(h.discriminator.parameters())]))
     finally:
         L.wm_debug_apply_fuse(ctypes.c_int(1))
+        L.wm_debug_bwd_fuse(ctypes.c_int(1))
     assert outs[0][0] == outs[1][0]
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
+
+
+def test_one_kernel_backward_keeps_the_training_step(debug_lib):
+    """the HiDDeN step with the body layers' backward in one kernel (csrc/bwd_ws.hip) against the two-kernel form: the same gradients up
+    to the summation order of the weight gradient and the BatchNorm sums (f32), so the first step's parameters agree to f32 round-off
+    through Adam"""
+    import ctypes
+    from video_watermarking_forgery_detection_amd.hidden_models import Hidden
+    from video_watermarking_forgery_detection_amd import noise_layers as NL
+    from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
+    L = debug_lib
+    outs = []
+    try:
+        for on in (1, 0):
+            L.wm_debug_bwd_fuse(ctypes.c_int(on))
+            torch.manual_seed(10)
+            h = Hidden(HiDDenConfiguration(H=64, W=64), torch.device("cuda"), NL.Jpeg(50), None, compute_dtype=torch.bfloat16)
+            images = detgen.uniform((4, 3, 64, 64), 171).cuda(); messages = (detgen.uniform((4, 30), 172) > 0.5).float().cuda()
+            g = [p.detach().clone() for p in h.encoder_decoder.parameters()]
+            losses, _ = h.train_on_batch([images, messages])
+            outs.append((dict(losses), [p.detach().clone() for p in list(h.encoder_decoder.parameters()) + list(h.discriminator.parameters())],
+                         h.enc_dec_flat_grad().clone() if hasattr(h, "enc_dec_flat_grad") else None))
+    finally:
+        L.wm_debug_bwd_fuse(ctypes.c_int(1))
+    for k, v in outs[0][0].items():
+        assert abs(v - outs[1][0][k]) <= 1e-5 * max(1.0, abs(v)), k       # the losses are computed before any backward
+    worst = 0.0
+    for a, b in zip(outs[0][1], outs[1][1]):
+        worst = max(worst, (a - b).abs().max().item())
+    assert worst <= 2.5e-3, worst      # one Adam step of lr 1e-3: a sign-like update flips where a gradient is at round-off level, nothing larger
 
 
 @pytest.mark.parametrize("case", [(3, 40, 36, 64, torch.bfloat16), (2, 17, 50, 30, torch.bfloat16), (2, 32, 32, 64, torch.float32)])
