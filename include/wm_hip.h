@@ -222,18 +222,22 @@ int wm_conv3x3_dgrad_applyfused(const void* g, const void* y, const float* stats
                                 void* dy_out, void* dx, const void* ry, const float* r_scale, const float* r_shift,
                                 float* partials, int B, int H, int W, int CinP, int dtype, int sweep_reverse, void* stream);
 /* The whole backward of a 64 -> 64 body layer fed by another ConvBNRelu (16-bit activations), in ONE pass over its operands:
- * reads g, y (this layer: gradient wrt its ReLU output, raw conv output) and xr (the FEEDING layer's raw conv output, with its
- * BatchNorm in_scale / in_shift), forms dy while staging and produces
- *   dx [B,H,W,64]              = conv(dy, wpt), the gradient wrt the feeding layer's ReLU output (as wm_conv3x3_dgrad_applyfused),
+ * wm_conv3x3_bwd_fused reads g, y (this layer: gradient wrt its ReLU output, raw conv output) and xr (the FEEDING layer's raw conv
+ * output, with its BatchNorm in_scale / in_shift), forms dy while staging and produces
+ *   dx [B,H,W,64]              = conv(dy, wpt) * [in_scale * xr + in_shift > 0]: the gradient wrt the feeding layer's ReLU output,
+ *                                already multiplied by that ReLU's mask (every consumer applies the mask itself; twice is the identity),
  *   partials [nwg][2][64]      = the feeding layer's BatchNorm-backward sums of dx (as wm_conv3x3_dgrad_bwdstats),
- *   dw [Cout][Cin][3][3] (+)=  the weight gradient sum dy (x) ReLU(in_scale * xr + in_shift) (as wm_conv3x3_wgrad_fin, incl. `fin`),
- * without writing dy or re-reading xr (537 MB instead of 939 MB per layer at B = 16, 256x256).
- * nwg = wm_conv3x3_bwd_fused_nwg(B,H,W) workgroups; ws: f32 scratch [nwg][9][64][64]. */
+ *   ws [nwg][9][64][64]        = per-workgroup slabs of the weight gradient sum dy (x) ReLU(in_scale * xr + in_shift),
+ * without writing dy or re-reading xr (537 MB instead of 939 MB per layer at B = 16, 256x256).  g_premasked != 0: g is such a masked
+ * gradient (the staging then skips the mask arithmetic; the results are the same).  nwg = wm_conv3x3_bwd_fused_nwg(B,H,W).
+ * wm_conv3x3_bwd_fused_reduce: dw [Cout][Cin][3][3] (+)= the sum of the slabs (wm_conv3x3_wgrad_fin's reduction, incl. `fin`). */
 int wm_conv3x3_bwd_fused_supported(int dtype);
 int wm_conv3x3_bwd_fused_nwg(int B, int H, int W);
 int wm_conv3x3_bwd_fused(const void* g, const void* y, const float* stats4, const float* coef, const void* wpt, const void* xr,
-                         const float* in_scale, const float* in_shift, void* dx, float* partials, float* ws, float* dw, int accumulate,
-                         int B, int H, int W, int Cin, int Cout, int dtype, const WmBnBwdFin* fin, int sweep_reverse, void* stream);
+                         const float* in_scale, const float* in_shift, void* dx, float* partials, float* ws, int B, int H, int W,
+                         int dtype, int g_premasked, int sweep_reverse, void* stream);
+int wm_conv3x3_bwd_fused_reduce(float* ws, float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, const WmBnBwdFin* fin,
+                                void* stream);
 int wm_conv3x3_dgrad_bwdstats_supported(int CoutY, int CinP, int dtype);
 int wm_conv3x3_dgrad_bwdstats(const void* src, int lds, int CoutY, const void* wpt, const float* gvec, const float* stats4,
                               const float* coef, const void* ry, const float* r_scale, const float* r_shift, void* dx,

@@ -967,12 +967,26 @@ def test_fused_backward_kernel_against_the_two_kernel_form(case):
     dx1, part1, _ = ops.conv3x3_bwd_fused(g, y, stats, coef, wpt, xr, in_scale, in_shift, dw1, True, reverse=rev)
     torch.cuda.synchronize()
     assert dx0.float().abs().max().item() > 0
+    # the one-kernel form writes dx already multiplied by the feeding layer's ReLU mask (its consumers apply the mask anyway)
+    z = in_scale * xr.float() + in_shift
+    sure = z.abs() > 1e-4                       # (the kernel evaluates z with one fma: the sign may differ within round-off of zero)
+    dx0m = torch.where(z > 0, dx0, torch.zeros_like(dx0))
     if dt == torch.bfloat16:
-        assert torch.equal(dx0, dx1)
+        assert torch.equal(dx0m[sure], dx1[sure])
     else:   # f16: one dy element in ~50,000 lands on the other side of a rounding tie (an f32 last-bit difference in the folded constants'
         # evaluation order); its 3x3 neighbourhood of dx then differs by one f16 ulp here and there
-        diff = (dx0.float() - dx1.float()).abs()
+        diff = (dx0m.float() - dx1.float()).abs()[sure]
         assert (diff > 0).float().mean().item() < 2e-3 and diff.max().item() <= 2.0 ** -10 * max(1.0, dx0.float().abs().max().item())
+    # a gradient that arrives already masked by this layer's ReLU (what this kernel itself emits) gives the same results with the flag
+    zl = stats[0] * y.float() + stats[1]
+    gm = torch.where(zl > 0, g, torch.zeros_like(g))
+    dw2 = torch.full((C, C, 3, 3), 0.25, device="cuda")
+    dx2, part2, _ = ops.conv3x3_bwd_fused(gm, y, stats, coef, wpt, xr, in_scale, in_shift, dw2, True, reverse=rev, premasked=True)
+    dw3 = torch.full((C, C, 3, 3), 0.25, device="cuda")
+    dx3, part3, _ = ops.conv3x3_bwd_fused(gm, y, stats, coef, wpt, xr, in_scale, in_shift, dw3, True, reverse=rev, premasked=False)
+    assert torch.equal(dx2, dx3) and torch.equal(part2, part3) and torch.equal(dw2, dw3)
+    near0 = (zl.abs() <= 1e-4).float().mean().item()
+    assert near0 < 1e-3 and (dx2.float() - dx1.float()).abs().max().item() <= (1e-6 if near0 == 0 else 1.0)   # = the unmasked g's result unless a z sits at zero
     s0, s1 = part0.double().sum(0), part1.double().sum(0)
     assert (s0 - s1).abs().max().item() <= (1e-5 if dt == torch.bfloat16 else 1e-3) * s0.abs().max().item()
     ref = dw0 + 0.25

@@ -72,7 +72,9 @@ __device__ __forceinline__ hx8 tr_frag(const char* p0, const char* p1) {
 // DBG (debug build only, tools/ab_step.py wm_debug_bwd_variant): phase ablations -- 1 skip the input-gradient MFMAs, 2 the weight-gradient
 // MFMAs, 4 the epilogue, 8 the staging of the next tile, 16 stage the same tile again and again (results are then meaningless; compile-
 // time so the real kernel is untouched)
-template <int DBG>
+// PREMASKED: g arrives already multiplied by its layer's ReLU mask (this kernel's own dx is written that way, see the epilogue), so the
+// staging's compare + select + the z fma disappear; masking twice is the identity, so results do not depend on the flag
+template <int DBG, bool PREMASKED>
 __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SW_BYTES + 2 * BUF_BYTES + 4 * 2 * C * 4 + 2 * C * 4 + (C * 8 + 32) * 4];
     hx_t* sW = reinterpret_cast<hx_t*>(smem);
@@ -167,8 +169,14 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
             for (int k = 0; k < XV; ++k) {
                 u32x4 w = __builtin_bit_cast(u32x4, dG[k]);
                 const u32x4 wy = __builtin_bit_cast(u32x4, dY[k]);
-                const float d0 = wm_bn_fold_dyg(HX::lo(wy[pq]), HX::lo(w[pq]), ka[0], ka[1], ka[2], ka[3], ka2[0]);
-                const float d1 = wm_bn_fold_dyg(HX::hi(wy[pq]), HX::hi(w[pq]), kb[0], kb[1], kb[2], kb[3], kb2[0]);
+                float d0, d1;
+                if constexpr (PREMASKED) {
+                    d0 = __builtin_fmaf(ka[2], HX::lo(w[pq]), __builtin_fmaf(-ka[3], HX::lo(wy[pq]), ka2[0]));
+                    d1 = __builtin_fmaf(kb[2], HX::hi(w[pq]), __builtin_fmaf(-kb[3], HX::hi(wy[pq]), kb2[0]));
+                } else {
+                    d0 = wm_bn_fold_dyg(HX::lo(wy[pq]), HX::lo(w[pq]), ka[0], ka[1], ka[2], ka[3], ka2[0]);
+                    d1 = wm_bn_fold_dyg(HX::hi(wy[pq]), HX::hi(w[pq]), kb[0], kb[1], kb[2], kb[3], kb2[0]);
+                }
                 const hx2 pk = {(hx_t)d0, (hx_t)d1};
                 w[pq] = __builtin_bit_cast(unsigned, pk);
                 dG[k] = __builtin_bit_cast(hx8, w);
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                 u32x4 w = __builtin_bit_cast(u32x4, dG[k]);
                 const u32x4 wy = __builtin_bit_cast(u32x4, dY[k]);
                 float d0, d1;
-                if constexpr ((DBG & 256) != 0) {   // DBG 256 (timing probe): g taken as already masked
+                if constexpr (PREMASKED || (DBG & 256) != 0) {   // (DBG 256: timing probe of the same on unmasked data)
                     d0 = __builtin_fmaf(pka[2], HX::lo(w[pq]), __builtin_fmaf(-pka[3], HX::lo(wy[pq]), pka2[0]));
                     d1 = __builtin_fmaf(pkb[2], HX::hi(w[pq]), __builtin_fmaf(-pkb[3], HX::hi(wy[pq]), pkb2[0]));
                 } else {
@@ -457,6 +465,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                 const f32x2 rs = *reinterpret_cast<const f32x2*>(sTab + 16 * q + 2 * j), rh = *reinterpret_cast<const f32x2*>(sTab + C + 16 * q + 2 * j);
                 const float z0 = __builtin_fmaf(rs[0], y0, rh[0]), z1 = __builtin_fmaf(rs[1], y1, rh[1]);
                 const float gz0 = z0 > 0.f ? g0 : 0.f, gz1 = z1 > 0.f ? g1 : 0.f;
+                pk[j] = (z0 > 0.f ? pk[j] & 0xffffu : 0u) | (z1 > 0.f ? pk[j] & 0xffff0000u : 0u);   // dx leaves masked: gz, not g
                 s1[2 * j] += gz0; s1[2 * j + 1] += gz1;
                 s2[2 * j] = __builtin_fmaf(gz0, y0, s2[2 * j]);
                 s2[2 * j + 1] = __builtin_fmaf(gz1, y1, s2[2 * j + 1]);
@@ -513,7 +522,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
 // nwg workgroups (= slabs = partial rows), each a run of 8x16-pixel tiles
 void WM_HSYM(wm_launch_bwd_ws)(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt, const void* xr,
                                const float* in_scale, const float* in_shift, void* dx, float* stat, float* ws, int B, int H, int W, int nwg,
-                               int reverse, hipStream_t s, int dbg) {
+                               int reverse, hipStream_t s, int dbg, int premasked) {
     BwdArgs a;
     a.g = (const hx_t*)g; a.y = (const hx_t*)y; a.stats4 = stats4; a.st_ld = st_ld; a.coef = coef; a.wpt = (const hx_t*)wpt;
     a.xr = (const hx_t*)xr; a.in_scale = in_scale; a.in_shift = in_shift; a.dx = (hx_t*)dx; a.stat = stat; a.ws = ws;
@@ -521,23 +530,24 @@ void WM_HSYM(wm_launch_bwd_ws)(const void* g, const void* y, const float* stats4
     a.reverse = wm_sweep_dir(reverse);
 #ifdef WM_DEBUG
     switch (dbg) {
-        case 1: hipLaunchKernelGGL(bwd_ws_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 2: hipLaunchKernelGGL(bwd_ws_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 3: hipLaunchKernelGGL(bwd_ws_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 4: hipLaunchKernelGGL(bwd_ws_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 8: hipLaunchKernelGGL(bwd_ws_kernel<8>, dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 7: hipLaunchKernelGGL(bwd_ws_kernel<7>, dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 12: hipLaunchKernelGGL(bwd_ws_kernel<12>, dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 32: hipLaunchKernelGGL(bwd_ws_kernel<32>, dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 64: hipLaunchKernelGGL(bwd_ws_kernel<64>, dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 96: hipLaunchKernelGGL(bwd_ws_kernel<96>, dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 256: hipLaunchKernelGGL(bwd_ws_kernel<256>, dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 128: hipLaunchKernelGGL(bwd_ws_kernel<128>, dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 16: hipLaunchKernelGGL(bwd_ws_kernel<16>, dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 15: hipLaunchKernelGGL(bwd_ws_kernel<15>, dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 1: hipLaunchKernelGGL((bwd_ws_kernel<1, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 2: hipLaunchKernelGGL((bwd_ws_kernel<2, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 3: hipLaunchKernelGGL((bwd_ws_kernel<3, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 4: hipLaunchKernelGGL((bwd_ws_kernel<4, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 8: hipLaunchKernelGGL((bwd_ws_kernel<8, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 7: hipLaunchKernelGGL((bwd_ws_kernel<7, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 12: hipLaunchKernelGGL((bwd_ws_kernel<12, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 32: hipLaunchKernelGGL((bwd_ws_kernel<32, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 64: hipLaunchKernelGGL((bwd_ws_kernel<64, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 96: hipLaunchKernelGGL((bwd_ws_kernel<96, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 256: hipLaunchKernelGGL((bwd_ws_kernel<256, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 128: hipLaunchKernelGGL((bwd_ws_kernel<128, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 16: hipLaunchKernelGGL((bwd_ws_kernel<16, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 15: hipLaunchKernelGGL((bwd_ws_kernel<15, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         default: break;
     }
 #endif
     (void)dbg;
-    hipLaunchKernelGGL(bwd_ws_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, s, a);
+    if (premasked) hipLaunchKernelGGL((bwd_ws_kernel<0, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((bwd_ws_kernel<0, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
 }

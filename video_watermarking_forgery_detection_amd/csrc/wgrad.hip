@@ -42,7 +42,7 @@ static inline bool is16(int dtype) { return dtype == WM_BF16 || dtype == WM_F16;
 #define WM_DECL_BWDWS(sfx)                                                                                                             \
     void wm_launch_bwd_ws##sfx(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt,      \
                                const void* xr, const float* in_scale, const float* in_shift, void* dx, float* stat, float* ws, int B,  \
-                               int H, int W, int nwg, int reverse, hipStream_t s, int dbg)
+                               int H, int W, int nwg, int reverse, hipStream_t s, int dbg, int premasked)
 WM_DECL_BWDWS(_bf16);
 WM_DECL_BWDWS(_f16);
 
@@ -488,22 +488,30 @@ extern "C" int wm_conv3x3_bwd_fused_nwg(int B, int H, int W) {
     return (int)(n < 256 ? n : 256);
 }
 extern "C" int wm_conv3x3_bwd_fused(const void* g, const void* y, const float* stats4, const float* coef, const void* wpt, const void* xr,
-                                    const float* in_scale, const float* in_shift, void* dx, float* partials, float* ws, float* dw, int accumulate,
-                                    int B, int H, int W, int Cin, int Cout, int dtype, const WmBnBwdFin* fin, int sweep_reverse, void* stream) {
-    WM_REQUIRE(g && y && stats4 && coef && wpt && xr && in_scale && in_shift && dx && partials && ws && dw, WM_E_BADARG, "wm_conv3x3_bwd_fused: null pointer");
+                                    const float* in_scale, const float* in_shift, void* dx, float* partials, float* ws, int B, int H, int W,
+                                    int dtype, int g_premasked, int sweep_reverse, void* stream) {
+    WM_REQUIRE(g && y && stats4 && coef && wpt && xr && in_scale && in_shift && dx && partials && ws, WM_E_BADARG, "wm_conv3x3_bwd_fused: null pointer");
     WM_REQUIRE(wm_conv3x3_bwd_fused_supported(dtype), WM_E_SHAPE, "wm_conv3x3_bwd_fused: 16-bit activations only (dtype %d)", dtype);
-    WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 64 && Cout > 0 && Cout <= 64, WM_E_BADARG, "wm_conv3x3_bwd_fused: bad shape");
+    WM_REQUIRE(B > 0 && H > 0 && W > 0, WM_E_BADARG, "wm_conv3x3_bwd_fused: bad shape");
     WM_REQUIRE((long long)B * H * W * 64 < (1LL << 31) && (long long)B * H < (1 << 23) && W < (1 << 23), WM_E_SHAPE,
                "wm_conv3x3_bwd_fused: tensors of 2^31 elements or more (32-bit element offsets, 24-bit row / column counts)");
-    WM_REQUIRE(fin_rider_ok(fin), WM_E_BADARG, "wm_conv3x3_bwd_fused: bad finalisation rider (null pointer, or more than 256 partial rows)");
     WM_REQUIRE((((uintptr_t)g | (uintptr_t)y | (uintptr_t)wpt | (uintptr_t)xr | (uintptr_t)dx | (uintptr_t)ws) & 15) == 0, WM_E_SHAPE,
                "wm_conv3x3_bwd_fused: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int nwg = wm_conv3x3_bwd_fused_nwg(B, H, W);
-    if (dtype == WM_F16) wm_launch_bwd_ws_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg);
-    else wm_launch_bwd_ws_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg);
+    if (dtype == WM_F16) wm_launch_bwd_ws_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked);
+    else wm_launch_bwd_ws_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked);
     WM_LAUNCH_CHECK("wm_conv3x3_bwd_fused");
-    WM_REQUIRE(launch_wgrad_reduce(ws, nwg, 64, 64, dw, Cin, Cout, nullptr, accumulate, fin, s) == WM_OK, WM_E_BADARG, "wm_conv3x3_bwd_fused: bad finalisation rider");
-    WM_LAUNCH_CHECK("wm_conv3x3_bwd_fused(reduce)");
+    return WM_OK;
+}
+// the slab reduction of wm_conv3x3_bwd_fused's workspace (its own call so that the kernel above can be timed alone): dw (+)= sum of the
+// nwg slabs; `fin`: an optional BatchNorm-backward finalisation riding on the launch, as in wm_conv3x3_wgrad_fin
+extern "C" int wm_conv3x3_bwd_fused_reduce(float* ws, float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, const WmBnBwdFin* fin,
+                                           void* stream) {
+    WM_REQUIRE(ws && dw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 64 && Cout > 0 && Cout <= 64, WM_E_BADARG, "wm_conv3x3_bwd_fused_reduce: bad arguments");
+    WM_REQUIRE(fin_rider_ok(fin), WM_E_BADARG, "wm_conv3x3_bwd_fused_reduce: bad finalisation rider (null pointer, or more than 256 partial rows)");
+    WM_REQUIRE(launch_wgrad_reduce(ws, wm_conv3x3_bwd_fused_nwg(B, H, W), 64, 64, dw, Cin, Cout, nullptr, accumulate, fin, (hipStream_t)stream) == WM_OK,
+               WM_E_BADARG, "wm_conv3x3_bwd_fused_reduce: bad finalisation rider");
+    WM_LAUNCH_CHECK("wm_conv3x3_bwd_fused_reduce");
     return WM_OK;
 }

@@ -217,8 +217,11 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
         wpt = _packed(conv, 64, rows, dtype, None, True)
         if feed_stats and rows == 64 and ops.conv3x3_bwd_fused_supported(dtype):
             # one kernel: dy is formed in the LDS and feeds BOTH gradients; the feeding layer's raw output is read once (csrc/bwd_ws.hip)
+            # (g itself may come from such a kernel, which writes its gradient already multiplied by this layer's ReLU mask: the staging
+            # then skips the mask arithmetic -- trusted only for exactly that tensor, unmodified: the check in coef_of())
             gx, part, pcoef = ops.conv3x3_bwd_fused(g, y, ctx.stats, coef, wpt, x.t, x.scale, x.shift, grads[conv.weight], accumulate,
-                                                    reverse=d, fin=rider)
+                                                    reverse=d, fin=rider, premasked=pre is not None and getattr(g, "_wm_masked", False))
+            gx._wm_masked = True
             x.bwd = (gx, part, pcoef, gx._version)
         elif feed_stats:
             dy, gx, part = ops.conv3x3_dgrad_applyfused(g, y, ctx.stats, coef, wpt, x.t, x.scale, x.shift, reverse=d)

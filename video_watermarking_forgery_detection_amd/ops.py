@@ -491,9 +491,10 @@ def conv3x3_bwd_fused_supported(dtype):
     return bool(_lib.lib().wm_conv3x3_bwd_fused_supported(c_int(dt_id(dtype))))
 
 
-def conv3x3_bwd_fused(g, y, stats, coef, wpt, xr, in_scale, in_shift, dw, accumulate, reverse=False, fin=None):
+def conv3x3_bwd_fused(g, y, stats, coef, wpt, xr, in_scale, in_shift, dw, accumulate, reverse=False, fin=None, premasked=False):
     """The whole backward of a 64 -> 64 body layer fed by another ConvBNRelu in one pass (csrc/bwd_ws.hip): returns
-    (dx, partials [nwg,2,64] = the feeding layer's BatchNorm-backward sums, the rider's coef or None); dw is written in place."""
+    (dx -- multiplied by the feeding layer's ReLU mask --, partials [nwg,2,64] = the feeding layer's BatchNorm-backward sums, the
+    rider's coef or None); dw is written in place by the slab reduction that follows the kernel."""
     B, H, W, C = y.shape
     assert C == 64 and g.shape == y.shape and xr.shape == y.shape and g.is_contiguous() and y.is_contiguous() and xr.is_contiguous()
     assert tuple(wpt.shape) == (9, 64, 64) and stats.is_contiguous() and coef.is_contiguous() and dw.is_contiguous()
@@ -506,10 +507,12 @@ def conv3x3_bwd_fused(g, y, stats, coef, wpt, xr, in_scale, in_shift, dw, accumu
     Cout, Cin = dw.shape[0], dw.shape[1]
     info = {"B": B, "H": H, "W": W, "dtype": y.dtype}
     rc = _timed("conv3x3_bwd_fused", info, lambda: L.wm_conv3x3_bwd_fused(
-        _p(g), _p(y), _p(stats), _p(coef), _p(wpt), _p(xr), _p(in_scale), _p(in_shift), _p(dx), _p(part), _p(ws), _p(dw),
-        c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(Cout), c_int(dtype_id(y)),
-        ctypes.byref(fst) if fst is not None else None, _sweep(reverse), _stream()))
+        _p(g), _p(y), _p(stats), _p(coef), _p(wpt), _p(xr), _p(in_scale), _p(in_shift), _p(dx), _p(part), _p(ws), c_int(B), c_int(H), c_int(W),
+        c_int(dtype_id(y)), c_int(1 if premasked else 0), _sweep(reverse), _stream()))
     _lib.check(rc, "wm_conv3x3_bwd_fused")
+    rc = L.wm_conv3x3_bwd_fused_reduce(_p(ws), _p(dw), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(Cout),
+                                       ctypes.byref(fst) if fst is not None else None, _stream())
+    _lib.check(rc, "wm_conv3x3_bwd_fused_reduce")
     return dx, part, fcoef
 
 
