@@ -13,15 +13,17 @@ decoder 7x64, discriminator 3x64; bf16 activations, f32 accumulate/params; synth
 random-init weights; inputs resident in HBM before the timed region.  One step = one batch.
 
 The JSON line carries, besides the driver contract:
-  roofline     -- the dominant kernel (most time per step, 12 launches): conv3x3_ws_kernel<64,64,...,BNBWD=2,BWDST> = the
-                  64->64 input-gradient conv with the BatchNorm-backward apply pass and the feeding layer's BatchNorm sums
-                  fused.  Its 77.3 GFLOP ride on 5 tensor passes (reads g, y, y of the layer below; writes dy, dx =
-                  671 MB algorithmic per launch at B=16 256x256: 115 FLOP/B, below the 312 FLOP/B ridge), so the bound
-                  is HBM: achieved = algorithmic bytes / launch duration measured live with events on the launch stream
-                  inside the timed region; peak = 8 TB/s; `traffic` = HBM bytes / launch from the committed rocprofv3
-                  PMC passes of this round (profiles/r02_pmc_traffic.json; FETCH_SIZE doubled as the gfx950 guide says);
-                  `mfma_util_pmc` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) from the committed counter pass
-                  (profiles/r02_bench_c2_pmc_mfma.csv); `step_mfma_util_pmc` = the same ratio over every kernel of the step
+  roofline     -- the dominant kernel (most time per step, 13 launches): bwd_ws_kernel (csrc/bwd_ws.hip) = the whole backward of a
+                  64->64 body layer in one pass: input gradient with the BatchNorm-backward apply fused, the feeding layer's
+                  BatchNorm sums, and the weight gradient, from one staged dy / activation tile.  Its 154.6 GFLOP ride on 4 tensor
+                  passes (reads g, y, y of the layer below; writes dx = 537 MB algorithmic per launch at B=16 256x256:
+                  288 FLOP/B, just under the 312 FLOP/B ridge), so the bound is HBM: achieved = algorithmic bytes / launch
+                  duration measured live with events on the launch stream inside the timed region; peak = 8 TB/s; `traffic` =
+                  HBM bytes / launch from the committed rocprofv3 PMC passes of this round (profiles/r02_pmc_traffic.json;
+                  FETCH_SIZE doubled as the gfx950 guide says); `mfma_util_pmc` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x
+                  1024 SIMDs) from the committed counter pass (profiles/r02_bench_c2_pmc_mfma.csv); `step_mfma_util_pmc` = the same
+                  ratio over every kernel of the step.  (Until this kernel the work was two launches -- the fused input gradient,
+                  671 MB, and the weight gradient, 268 MB: 939 MB for the same result.)
   roofline_mfma -- the runner-up, conv3x3_ws_kernel<64,64,XFORM,STATS,M16> (forward 64->64 conv, fused BN+ReLU input and
                   BatchNorm statistics, 15 launches / step): 77.3 GFLOP per launch against 2.5 PFLOP/s dense bf16
   cpu_baseline -- the oracle (oracle/hidden_ref.py, torch CPU fp32, all host cores) on a bounded
@@ -215,9 +217,9 @@ def main():
 
     for _ in range(args.warmup):
         h.train_on_batch([images, messages])
-    # the two heaviest kernels: the fused 64->64 input-gradient conv (12 launches / step, bf16 only) and the forward 64->64
-    # conv with fused BN+ReLU input transform (15 launches / step)
-    timer = ops.KernelTimer(lambda name, i: (name == "conv3x3_dgrad_applyfused" and i["feed"]) or
+    # the two heaviest kernels: the one-pass backward of the 64->64 body layers (13 launches / step, 16-bit activations only) and the
+    # forward 64->64 conv with fused BN+ReLU input transform (15 launches / step)
+    timer = ops.KernelTimer(lambda name, i: name == "conv3x3_bwd_fused" or
                             (name == "conv3x3_fwd" and i["Cin"] == 64 and i["CoutP"] == 64 and i["xform"]) or
                             name in ("jpeg_fwd", "jpeg_bwd"))
     ops.set_kernel_timer(timer)
@@ -241,7 +243,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kms = timer.elapsed_ms("conv3x3_fwd")
-    dms = timer.elapsed_ms("conv3x3_dgrad_applyfused")
+    dms = timer.elapsed_ms("conv3x3_bwd_fused")
     if rank == 0:
         fps = world * B * args.steps / dt
         esz = 2 if dtype == torch.bfloat16 else 4
@@ -256,16 +258,17 @@ def main():
                 "traffic": pmc_traffic(args, S, B, "fwd_hbm_bytes_per_launch"), "mfma_util_pmc": pmc_traffic(args, S, B, "fwd.mfma_util"),
                 "launches_timed": len(kms), "avg_launch_ms": avg_ms,
                 "flops_per_launch": flops_per_launch, "hbm_algorithmic_bytes_per_launch": 2.0 * tensor_bytes}
-        if dms:   # bf16: the fused input-gradient kernel is the dominant one, and it is HBM-bound
+        if dms:   # bf16: the one-pass backward kernel is the dominant one; 288 FLOP/B sits just under the ridge: HBM-bound
             davg = sum(dms) / len(dms)
-            dbytes = 5.0 * tensor_bytes   # reads g, y, y of the layer below; writes dy, dx
+            dbytes = 4.0 * tensor_bytes   # reads g, y, y of the layer below; writes dx
+            dflops = 2.0 * flops_per_launch   # the input gradient and the weight gradient
             roof = {"bound": "hbm",
-                    "kernel": "conv3x3_ws_kernel<64,64,M16,BNBWD=2,BWDST> (64->64 input-gradient implicit GEMM + BatchNorm-backward apply + the feeding layer's BatchNorm sums)",
+                    "kernel": "bwd_ws_kernel (64->64 body layer, one pass: input gradient + BatchNorm-backward apply + the feeding layer's BatchNorm sums + weight gradient)",
                     "achieved": dbytes / (davg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": dbytes / (davg * 1e-3) / 1e9 / 8000.0,
-                    "traffic": pmc_traffic(args, S, B), "mfma_util_pmc": pmc_traffic(args, S, B, "dgrad_fused.mfma_util"),
+                    "traffic": pmc_traffic(args, S, B), "mfma_util_pmc": pmc_traffic(args, S, B, "bwd_fused.mfma_util"),
                     "launches_timed": len(dms), "avg_launch_ms": davg,
-                    "algorithmic_bytes_per_launch": dbytes, "flops_per_launch": flops_per_launch,
-                    "flops_frac_of_mfma_peak": flops_per_launch / (davg * 1e-3) / 1e12 / peak}
+                    "algorithmic_bytes_per_launch": dbytes, "flops_per_launch": dflops,
+                    "flops_frac_of_mfma_peak": dflops / (davg * 1e-3) / 1e12 / peak}
         else:
             roof = mfma
         out = {

@@ -93,11 +93,14 @@ def kern(pattern):
 
 res = {"note": "FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads); KB = 1024 B; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 * 4)",
        "step_mfma_util": step_util,
+       "bwd_fused": kern("bwd_ws_kernel<0"),
        "dgrad_fused": kern("conv3x3_ws_kernel<64, 64, false, false, true, false, 2, true"),
        "fwd": kern("conv3x3_ws_kernel<64, 64, true, true"),
        "wgrad": kern("wgrad_ws16_kernel<64, true, 0>")}
 # round-1 keys bench.py reads
-if res["dgrad_fused"]:
+if res["bwd_fused"]:
+    res["hbm_bytes_per_launch"] = res["bwd_fused"]["hbm_bytes_per_launch"]
+elif res["dgrad_fused"]:
     res["hbm_bytes_per_launch"] = res["dgrad_fused"]["hbm_bytes_per_launch"]
 if res["fwd"]:
     res["fwd_hbm_bytes_per_launch"] = res["fwd"]["hbm_bytes_per_launch"]

@@ -106,12 +106,21 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
     const int run = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const int t_begin = (int)(((long)run * a.ntiles) / G), t_end = (int)(((long)(run + 1) * a.ntiles) / G);
     struct TileGeo { int b, ty0, tx0; };
+    // tile order: pairs of tile rows walked column by column (upper tile, lower tile, next column ...), so the two halo rows a tile
+    // shares with the one below it and the two halo columns it shares with its right neighbour are re-read within 1 and 2 tiles -- from
+    // this XCD's L2, not from the Infinity Cache 16 tiles later (tilesY odd: plain row-major order)
     auto geo = [&](int tile) {
         TileGeo g;
         int t = a.reverse ? t_begin + (t_end - 1 - tile) : tile;
-        const int txi = t % a.tilesX; t /= a.tilesX;
-        const int tyi = t % a.tilesY; t /= a.tilesY;
-        g.b = t; g.ty0 = tyi * TH; g.tx0 = txi * TW;
+        if (a.tilesY & 1) {
+            const int txi = t % a.tilesX; t /= a.tilesX;
+            const int tyi = t % a.tilesY; t /= a.tilesY;
+            g.b = t; g.ty0 = tyi * TH; g.tx0 = txi * TW;
+        } else {
+            const int rem = t % (2 * a.tilesX), pr = t / (2 * a.tilesX);     // pr: pair of tile rows, over all images
+            const int row = 2 * pr + (rem & 1);
+            g.b = row / a.tilesY; g.ty0 = (row - g.b * a.tilesY) * TH; g.tx0 = (rem >> 1) * TW;
+        }
         return g;
     };
 
