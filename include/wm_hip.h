@@ -229,13 +229,16 @@ int wm_conv3x3_dgrad_applyfused(const void* g, const void* y, const float* stats
  *   partials [nwg][2][64]      = the feeding layer's BatchNorm-backward sums of dx (as wm_conv3x3_dgrad_bwdstats),
  *   ws [nwg][9][64][64]        = per-workgroup slabs of the weight gradient sum dy (x) ReLU(in_scale * xr + in_shift),
  * without writing dy or re-reading xr (537 MB instead of 939 MB per layer at B = 16, 256x256).  g_premasked != 0: g is such a masked
- * gradient (the staging then skips the mask arithmetic; the results are the same).  nwg = wm_conv3x3_bwd_fused_nwg(B,H,W).
+ * gradient (the staging then skips the mask arithmetic; the results are the same).  Exactly one of g and gvec is non-NULL: gvec
+ * f32 [B][64] is the gradient of a globally pooled layer, one row per sample (B <= wm_conv3x3_bwd_fused_gvec_max_batch(); dy is then
+ * formed from y alone, as in wm_conv3x3_dgrad_gvfused).  nwg = wm_conv3x3_bwd_fused_nwg(B,H,W).
  * wm_conv3x3_bwd_fused_reduce: dw [Cout][Cin][3][3] (+)= the sum of the slabs (wm_conv3x3_wgrad_fin's reduction, incl. `fin`). */
 int wm_conv3x3_bwd_fused_supported(int dtype);
 int wm_conv3x3_bwd_fused_nwg(int B, int H, int W);
-int wm_conv3x3_bwd_fused(const void* g, const void* y, const float* stats4, const float* coef, const void* wpt, const void* xr,
-                         const float* in_scale, const float* in_shift, void* dx, float* partials, float* ws, int B, int H, int W,
-                         int dtype, int g_premasked, int sweep_reverse, void* stream);
+int wm_conv3x3_bwd_fused_gvec_max_batch(void);
+int wm_conv3x3_bwd_fused(const void* g, const float* gvec, const void* y, const float* stats4, const float* coef, const void* wpt,
+                         const void* xr, const float* in_scale, const float* in_shift, void* dx, float* partials, float* ws, int B,
+                         int H, int W, int dtype, int g_premasked, int sweep_reverse, void* stream);
 int wm_conv3x3_bwd_fused_reduce(float* ws, float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, const WmBnBwdFin* fin,
                                 void* stream);
 int wm_conv3x3_dgrad_bwdstats_supported(int CoutY, int CinP, int dtype);

@@ -991,3 +991,42 @@ def test_fused_backward_kernel_against_the_two_kernel_form(case):
     assert (s0 - s1).abs().max().item() <= (1e-5 if dt == torch.bfloat16 else 1e-3) * s0.abs().max().item()
     ref = dw0 + 0.25
     assert (dw1 - ref).abs().max().item() <= 2e-4 * dw0.abs().max().item()
+
+
+@pytest.mark.parametrize("case", [(4, 64, 64, torch.bfloat16), (3, 40, 56, torch.float16), (16, 128, 128, torch.bfloat16)])
+def test_fused_backward_kernel_gvec_form(case):
+    """the one-kernel backward of a globally pooled layer (one gradient row per sample) against wm_conv3x3_dgrad_bwdstats(gvec) +
+    wm_conv3x3_wgrad_gvfused"""
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, dt = case
+    C = 64
+    y = nhwc(detgen.normal((B, C, H, W), 922, mean=0.2), dt, C)
+    xr = nhwc(detgen.normal((B, C, H, W), 923, mean=0.1), dt, C)
+    gvec = (detgen.normal((B, C), 921) / (H * W)).cuda().contiguous()
+    stats = torch.empty(4, C, device="cuda")
+    stats[0] = detgen.normal((C,), 904, mean=1.0, std=0.3).cuda(); stats[1] = detgen.normal((C,), 905, std=0.3).cuda()
+    stats[2] = detgen.normal((C,), 906, std=0.2).cuda(); stats[3] = detgen.uniform((C,), 907).cuda() + 0.5
+    coef = torch.empty(3, C, device="cuda")
+    coef[0] = detgen.normal((C,), 908, mean=1.0, std=0.2).cuda(); coef[1] = detgen.normal((C,), 909, std=1e-5).cuda(); coef[2] = detgen.normal((C,), 910, std=1e-5).cuda()
+    in_scale = detgen.normal((C,), 911, mean=1.0, std=0.3).cuda(); in_shift = detgen.normal((C,), 912, std=0.3).cuda()
+    w = detgen.normal((C, C, 3, 3), 913, std=0.05).cuda()
+    wpt = ops.pack_w3x3(w, C, C, dt, transpose=True)
+    dw0 = torch.zeros(C, C, 3, 3, device="cuda"); dw1 = torch.zeros(C, C, 3, 3, device="cuda")
+    dx0, part0 = ops.conv3x3_dgrad_bwdstats(y, wpt, xr, in_scale, in_shift, gvec, stats, coef)
+    ops.conv3x3_wgrad_gvfused(xr, in_scale, in_shift, gvec, y, stats, coef, dw0, False)
+    dx1, part1, _ = ops.conv3x3_bwd_fused(None, y, stats, coef, wpt, xr, in_scale, in_shift, dw1, False, gvec=gvec)
+    torch.cuda.synchronize()
+    assert dx0.float().abs().max().item() > 0
+    z = in_scale * xr.float() + in_shift
+    sure = z.abs() > 1e-4
+    dx0m = torch.where(z > 0, dx0, torch.zeros_like(dx0))
+    diff = (dx0m.float() - dx1.float()).abs()[sure]
+    if dt == torch.bfloat16:
+        assert diff.max().item() == 0.0
+    else:
+        assert (diff > 0).float().mean().item() < 2e-3
+    s0, s1 = part0.double().sum(0), part1.double().sum(0)
+    assert (s0 - s1).abs().max().item() <= (1e-5 if dt == torch.bfloat16 else 1e-3) * s0.abs().max().item()
+    assert (dw1 - dw0).abs().max().item() <= 2e-4 * dw0.abs().max().item()
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_bwd_fused(None, y, stats, coef, wpt, xr, in_scale, in_shift, dw1, False)      # neither g nor gvec

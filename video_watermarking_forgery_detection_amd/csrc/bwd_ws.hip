@@ -40,6 +40,7 @@ constexpr int TH = 8, TW = 16, HH = 10, HW = 18, NPX = HH * HW, C = 64;
 constexpr int SW_BYTES = 9 * C * C * 2, SDY_BYTES = NPX * 128, SA_BYTES = TH * TW * 128, BUF_BYTES = SDY_BYTES + SA_BYTES;
 constexpr int XV = (NPX * 8 + 255) / 256;        // dy halo vectors per thread (6; the last one partially live)
 constexpr int AV = TH * TW * 8 / 256;            // a-tile vectors per thread (4)
+constexpr int GV_MAXB = 24;                      // GVEC: samples whose k3g rows fit the LDS left over (24 x 256 B)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
@@ -47,6 +48,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct BwdArgs {
     const hx_t* g; const hx_t* y;                          // layer L: gradient wrt its ReLU output, its raw conv output [B,H,W,64]
+    const float* gvec; int gv_ld;                          // GVEC: the gradient is one row per sample [B][gv_ld] (a globally pooled layer); g unused
     const float* stats4; int st_ld; const float* coef;     // [scale | shift | mean | invstd][st_ld], wm_bn_bwd_finalize's coef [3][st_ld]
     const hx_t* wpt;                                       // [9][64][64] filter packed for the input gradient (rows = input channels)
     const hx_t* xr; const float* in_scale; const float* in_shift;   // layer L-1: raw conv output, its BatchNorm scale / shift
@@ -74,13 +76,16 @@ __device__ __forceinline__ hx8 tr_frag(const char* p0, const char* p1) {
 // time so the real kernel is untouched)
 // PREMASKED: g arrives already multiplied by its layer's ReLU mask (this kernel's own dx is written that way, see the epilogue), so the
 // staging's compare + select + the z fma disappear; masking twice is the identity, so results do not depend on the flag
-template <int DBG, bool PREMASKED>
+// GVEC: the layer's output was globally pooled, so its gradient is one value per (sample, channel): the staging reads y only and takes
+// k3 + ca * gvec[b][c] (wm_bn_fold_g) from an LDS table [B][64] built at the start (bit-identical to conv3x3_ws.hip's BNBWD = 1 form)
+template <int DBG, bool PREMASKED, bool GVEC = false>
 __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SW_BYTES + 2 * BUF_BYTES + 4 * 2 * C * 4 + 2 * C * 4 + (C * 8 + 32) * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SW_BYTES + 2 * BUF_BYTES + 4 * 2 * C * 4 + 2 * C * 4 + (C * 8 + 32) * 4 + (GVEC ? GV_MAXB * C * 4 : 0)];
     hx_t* sW = reinterpret_cast<hx_t*>(smem);
     unsigned char* sBuf = smem + SW_BYTES;
     float* sRed = reinterpret_cast<float*>(smem + SW_BYTES + 2 * BUF_BYTES);
     float* sTab = sRed + 4 * 2 * C;   // in_scale | in_shift of the feeding layer (the epilogue's mask)
+    float* sG = sTab + 2 * C + C * 8 + 32;   // GVEC: [B][64] k3 + ca * gvec[b][c]
     float* sK = sTab + 2 * C;         // per channel: scale, shift, ca, k2, k3 (wm_bn_fold) of layer L; in_scale, in_shift of layer L-1; 0
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < C) {
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         const int gy = t.ty0 - 1 + py, gx = t.tx0 - 1 + px;
         const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
         const unsigned o = ((unsigned)__mul24(t.b * a.H + gyc, a.W) + (unsigned)gxc) * C + vec * 8;
-        dG[k] = *reinterpret_cast<const hx8*>(a.g + o);
+        if constexpr (!GVEC) dG[k] = *reinterpret_cast<const hx8*>(a.g + o);
         dY[k] = *reinterpret_cast<const hx8*>(a.y + o);
         okh = (okh & ~(1u << k)) | (((gy == gyc && gx == gxc) ? 1u : 0u) << k);
     };
@@ -168,18 +173,23 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         for (int k = 0; k < AV; ++k) load_a_slot(t, k);
     };
     // transform + LDS writes, one channel pair at a time (its constants come from the LDS table: a dozen registers live, not 56)
-    auto publish_tile = [&](unsigned char* buf) {
+    auto publish_tile = [&](unsigned char* buf, int bsample) {
 #pragma unroll
         for (int pq = 0; pq < 4; ++pq) {
             const float* kp = sK + (vec * 8 + 2 * pq) * 8 + vec * 4;
+            f32x2 kg = {0.f, 0.f};
+            if constexpr (GVEC) kg = *reinterpret_cast<const f32x2*>(sG + bsample * C + vec * 8 + 2 * pq);
             const f32x4 ka = *reinterpret_cast<const f32x4*>(kp), ka2 = *reinterpret_cast<const f32x4*>(kp + 4);
             const f32x4 kb = *reinterpret_cast<const f32x4*>(kp + 8), kb2 = *reinterpret_cast<const f32x4*>(kp + 12);
 #pragma unroll
             for (int k = 0; k < XV; ++k) {
-                u32x4 w = __builtin_bit_cast(u32x4, dG[k]);
+                u32x4 w = __builtin_bit_cast(u32x4, GVEC ? dY[k] : dG[k]);
                 const u32x4 wy = __builtin_bit_cast(u32x4, dY[k]);
                 float d0, d1;
-                if constexpr (PREMASKED) {
+                if constexpr (GVEC) {
+                    d0 = wm_bn_fold_dy(HX::lo(wy[pq]), ka[0], ka[1], ka[3], ka2[0], kg[0]);
+                    d1 = wm_bn_fold_dy(HX::hi(wy[pq]), kb[0], kb[1], kb[3], kb2[0], kg[1]);
+                } else if constexpr (PREMASKED) {
                     d0 = __builtin_fmaf(ka[2], HX::lo(w[pq]), __builtin_fmaf(-ka[3], HX::lo(wy[pq]), ka2[0]));
                     d1 = __builtin_fmaf(kb[2], HX::hi(w[pq]), __builtin_fmaf(-kb[3], HX::hi(wy[pq]), kb2[0]));
                 } else {
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                 }
                 const hx2 pk = {(hx_t)d0, (hx_t)d1};
                 w[pq] = __builtin_bit_cast(unsigned, pk);
-                dG[k] = __builtin_bit_cast(hx8, w);
+                if constexpr (GVEC) dY[k] = __builtin_bit_cast(hx8, w); else dG[k] = __builtin_bit_cast(hx8, w);
             }
 #pragma unroll
             for (int k = 0; k < AV; ++k) {
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < XV; ++k) {
-            u32x4 w = __builtin_bit_cast(u32x4, dG[k]);
+            u32x4 w = __builtin_bit_cast(u32x4, GVEC ? dY[k] : dG[k]);
             const unsigned keep = 0u - ((okh >> k) & 1u);
 #pragma unroll
             for (int q = 0; q < 4; ++q) w[q] &= keep;
@@ -265,10 +275,18 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
             for (int j = 0; j < 2; ++j) wacc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();   // the constant table
+    if constexpr (GVEC) {
+        for (int i = tid; i < a.B * C; i += 256) {
+            const int b = i / C, c = i - b * C;
+            const float* kc = sK + c * 8 + (c >> 3) * 4;
+            sG[i] = wm_bn_fold_g(kc[2], a.gvec[(size_t)b * a.gv_ld + c], kc[4]);
+        }
+        __syncthreads();
+    }
     if (t_begin < t_end) {
         load_halo(geo(t_begin));
         load_atile(geo(t_begin));
-        publish_tile(sBuf);
+        publish_tile(sBuf, geo(t_begin).b);
     }
     __syncthreads();   // filter + first tile visible
 
@@ -276,7 +294,10 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
     // 2 a-tile vectors each); per group: 4 channel pairs x 5 transform units (the pair's constants are fetched from the LDS table at the
     // first), then 5 publish units: zero padding, the LDS write, and the request of the slot's content two tiles ahead.
     f32x4 pka, pka2, pkb, pkb2;
+    f32x2 pkg = {0.f, 0.f};   // GVEC: k3 + ca * gvec of the channel pair, for the sample of the tile being published
+    int bpub = 0;
     auto pub_consts = [&](int pq) {
+        if constexpr (GVEC) pkg = *reinterpret_cast<const f32x2*>(sG + bpub * C + vec * 8 + 2 * pq);
         const float* kp = sK + (vec * 8 + 2 * pq) * 8 + vec * 4;
         pka = *reinterpret_cast<const f32x4*>(kp); pka2 = *reinterpret_cast<const f32x4*>(kp + 4);
         pkb = *reinterpret_cast<const f32x4*>(kp + 8); pkb2 = *reinterpret_cast<const f32x4*>(kp + 12);
@@ -295,10 +316,13 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
             if constexpr ((DBG & 32) != 0) return;   // DBG 32: no transform arithmetic (raw operands are published)
             const int pq = v / 5;
             if (is_dy) {
-                u32x4 w = __builtin_bit_cast(u32x4, dG[k]);
+                u32x4 w = __builtin_bit_cast(u32x4, GVEC ? dY[k] : dG[k]);
                 const u32x4 wy = __builtin_bit_cast(u32x4, dY[k]);
                 float d0, d1;
-                if constexpr (PREMASKED || (DBG & 256) != 0) {   // (DBG 256: timing probe of the same on unmasked data)
+                if constexpr (GVEC) {
+                    d0 = wm_bn_fold_dy(HX::lo(wy[pq]), pka[0], pka[1], pka[3], pka2[0], pkg[0]);
+                    d1 = wm_bn_fold_dy(HX::hi(wy[pq]), pkb[0], pkb[1], pkb[3], pkb2[0], pkg[1]);
+                } else if constexpr (PREMASKED || (DBG & 256) != 0) {   // (DBG 256: timing probe of the same on unmasked data)
                     d0 = __builtin_fmaf(pka[2], HX::lo(w[pq]), __builtin_fmaf(-pka[3], HX::lo(wy[pq]), pka2[0]));
                     d1 = __builtin_fmaf(pkb[2], HX::hi(w[pq]), __builtin_fmaf(-pkb[3], HX::hi(wy[pq]), pkb2[0]));
                 } else {
@@ -307,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                 }
                 const hx2 pk = {(hx_t)d0, (hx_t)d1};
                 w[pq] = __builtin_bit_cast(unsigned, pk);
-                dG[k] = __builtin_bit_cast(hx8, w);
+                if constexpr (GVEC) dY[k] = __builtin_bit_cast(hx8, w); else dG[k] = __builtin_bit_cast(hx8, w);
             } else {
                 u32x4 w = __builtin_bit_cast(u32x4, dA[k]);
                 const float f0 = __builtin_fmaf(HX::lo(w[pq]), pka2[1], pka2[2]);
@@ -318,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                 dA[k] = __builtin_bit_cast(hx8, w);
             }
         } else if (is_dy) {
-            u32x4 w = __builtin_bit_cast(u32x4, dG[k]);
+            u32x4 w = __builtin_bit_cast(u32x4, GVEC ? dY[k] : dG[k]);
             const unsigned keep = 0u - ((okh >> k) & 1u);
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) w[q4] &= keep;
@@ -346,6 +370,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         const TileGeo g = geo(tile);
         const unsigned char* cur = sBuf + ((tile - t_begin) & 1) * BUF_BYTES;
         unsigned char* nxt = sBuf + (((tile - t_begin) & 1) ^ 1) * BUF_BYTES;
+        if constexpr (GVEC && decltype(stage_c)::value) bpub = geo(tile + 1).b;
         const TileGeo g2 = (DBG & 16) ? geo(t_begin) : geo(refill ? tile + 2 : tile);   // DBG 16: every refill re-reads the run's first tile (L2 hits)
         // this tile's epilogue operand (the feeding layer's y at this lane's two output pixels): requested first, used last
         unsigned ryv[2][8];
@@ -528,12 +553,15 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
 
 }  // namespace
 
+int WM_HSYM(wm_bwd_ws_gvec_max_batch)() { return GV_MAXB; }
+
 // nwg workgroups (= slabs = partial rows), each a run of 8x16-pixel tiles
 void WM_HSYM(wm_launch_bwd_ws)(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt, const void* xr,
                                const float* in_scale, const float* in_shift, void* dx, float* stat, float* ws, int B, int H, int W, int nwg,
-                               int reverse, hipStream_t s, int dbg, int premasked) {
+                               int reverse, hipStream_t s, int dbg, int premasked, const float* gvec, int gv_ld) {
     BwdArgs a;
     a.g = (const hx_t*)g; a.y = (const hx_t*)y; a.stats4 = stats4; a.st_ld = st_ld; a.coef = coef; a.wpt = (const hx_t*)wpt;
+    a.gvec = gvec; a.gv_ld = gv_ld;
     a.xr = (const hx_t*)xr; a.in_scale = in_scale; a.in_shift = in_shift; a.dx = (hx_t*)dx; a.stat = stat; a.ws = ws;
     a.B = B; a.H = H; a.W = W; a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
     a.reverse = wm_sweep_dir(reverse);
@@ -557,6 +585,7 @@ void WM_HSYM(wm_launch_bwd_ws)(const void* g, const void* y, const float* stats4
     }
 #endif
     (void)dbg;
-    if (premasked) hipLaunchKernelGGL((bwd_ws_kernel<0, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+    if (gvec) hipLaunchKernelGGL((bwd_ws_kernel<0, false, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+    else if (premasked) hipLaunchKernelGGL((bwd_ws_kernel<0, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((bwd_ws_kernel<0, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
 }

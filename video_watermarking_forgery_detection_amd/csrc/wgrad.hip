@@ -42,7 +42,8 @@ static inline bool is16(int dtype) { return dtype == WM_BF16 || dtype == WM_F16;
 #define WM_DECL_BWDWS(sfx)                                                                                                             \
     void wm_launch_bwd_ws##sfx(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt,      \
                                const void* xr, const float* in_scale, const float* in_shift, void* dx, float* stat, float* ws, int B,  \
-                               int H, int W, int nwg, int reverse, hipStream_t s, int dbg, int premasked)
+                               int H, int W, int nwg, int reverse, hipStream_t s, int dbg, int premasked, const float* gvec, int gv_ld); \
+    int wm_bwd_ws_gvec_max_batch##sfx()
 WM_DECL_BWDWS(_bf16);
 WM_DECL_BWDWS(_f16);
 
@@ -487,10 +488,13 @@ extern "C" int wm_conv3x3_bwd_fused_nwg(int B, int H, int W) {
     const long n = (long)B * wm_cdiv(H, 8) * wm_cdiv(W, 16);
     return (int)(n < 256 ? n : 256);
 }
-extern "C" int wm_conv3x3_bwd_fused(const void* g, const void* y, const float* stats4, const float* coef, const void* wpt, const void* xr,
-                                    const float* in_scale, const float* in_shift, void* dx, float* partials, float* ws, int B, int H, int W,
-                                    int dtype, int g_premasked, int sweep_reverse, void* stream) {
-    WM_REQUIRE(g && y && stats4 && coef && wpt && xr && in_scale && in_shift && dx && partials && ws, WM_E_BADARG, "wm_conv3x3_bwd_fused: null pointer");
+extern "C" int wm_conv3x3_bwd_fused_gvec_max_batch(void) { return wm_bwd_ws_gvec_max_batch_bf16(); }
+extern "C" int wm_conv3x3_bwd_fused(const void* g, const float* gvec, const void* y, const float* stats4, const float* coef, const void* wpt,
+                                    const void* xr, const float* in_scale, const float* in_shift, void* dx, float* partials, float* ws, int B,
+                                    int H, int W, int dtype, int g_premasked, int sweep_reverse, void* stream) {
+    WM_REQUIRE((g != nullptr) != (gvec != nullptr), WM_E_BADARG, "wm_conv3x3_bwd_fused: exactly one of g (a tensor) and gvec (one row per sample) is given");
+    WM_REQUIRE(!gvec || B <= wm_conv3x3_bwd_fused_gvec_max_batch(), WM_E_SHAPE, "wm_conv3x3_bwd_fused: gvec form holds at most %d samples' rows in the LDS", wm_conv3x3_bwd_fused_gvec_max_batch());
+    WM_REQUIRE(y && stats4 && coef && wpt && xr && in_scale && in_shift && dx && partials && ws, WM_E_BADARG, "wm_conv3x3_bwd_fused: null pointer");
     WM_REQUIRE(wm_conv3x3_bwd_fused_supported(dtype), WM_E_SHAPE, "wm_conv3x3_bwd_fused: 16-bit activations only (dtype %d)", dtype);
     WM_REQUIRE(B > 0 && H > 0 && W > 0, WM_E_BADARG, "wm_conv3x3_bwd_fused: bad shape");
     WM_REQUIRE((long long)B * H * W * 64 < (1LL << 31) && (long long)B * H < (1 << 23) && W < (1 << 23), WM_E_SHAPE,
@@ -499,8 +503,8 @@ extern "C" int wm_conv3x3_bwd_fused(const void* g, const void* y, const float* s
                "wm_conv3x3_bwd_fused: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int nwg = wm_conv3x3_bwd_fused_nwg(B, H, W);
-    if (dtype == WM_F16) wm_launch_bwd_ws_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked);
-    else wm_launch_bwd_ws_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked);
+    if (dtype == WM_F16) wm_launch_bwd_ws_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked, gvec, 64);
+    else wm_launch_bwd_ws_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked, gvec, 64);
     WM_LAUNCH_CHECK("wm_conv3x3_bwd_fused");
     return WM_OK;
 }

@@ -201,6 +201,14 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
             and x.t.shape[-1] == 64 and ctx.stats.is_contiguous() and ops.conv3x3_gvfused_supported(64, y.shape[-1], dtype)):
         coef = coef_of()
         wpt = _packed(conv, y.shape[-1], rows, dtype, None, True)
+        if (feed_stats and y.shape[-1] == 64 and ops.conv3x3_bwd_fused_supported(dtype) and gvec.shape[-1] == 64
+                and y.shape[0] <= ops.conv3x3_bwd_fused_gvec_max_batch()):
+            # one kernel for both gradients (csrc/bwd_ws.hip, gvec form): y and the feeding layer's raw output are read once
+            gx, part, pcoef = ops.conv3x3_bwd_fused(None, y, ctx.stats, coef, wpt, x.t, x.scale, x.shift, grads[conv.weight], accumulate,
+                                                    fin=rider, gvec=gvec)
+            gx._wm_masked = True
+            x.bwd = (gx, part, pcoef, gx._version)
+            return tag(gx)
         if feed_stats:   # input gradient first: the sums it emits are finished by a rider on the weight gradient's reduction
             gx, part = ops.conv3x3_dgrad_bwdstats(y, wpt, x.t, x.scale, x.shift, gvec, ctx.stats, coef)
             pcoef = ops.conv3x3_wgrad_gvfused(x.t, x.scale, x.shift, gvec, y, ctx.stats, coef, grads[conv.weight], accumulate, fin=rider(part))

@@ -491,12 +491,20 @@ def conv3x3_bwd_fused_supported(dtype):
     return bool(_lib.lib().wm_conv3x3_bwd_fused_supported(c_int(dt_id(dtype))))
 
 
-def conv3x3_bwd_fused(g, y, stats, coef, wpt, xr, in_scale, in_shift, dw, accumulate, reverse=False, fin=None, premasked=False):
+def conv3x3_bwd_fused_gvec_max_batch():
+    return int(_lib.lib().wm_conv3x3_bwd_fused_gvec_max_batch())
+
+
+def conv3x3_bwd_fused(g, y, stats, coef, wpt, xr, in_scale, in_shift, dw, accumulate, reverse=False, fin=None, premasked=False, gvec=None):
     """The whole backward of a 64 -> 64 body layer fed by another ConvBNRelu in one pass (csrc/bwd_ws.hip): returns
     (dx -- multiplied by the feeding layer's ReLU mask --, partials [nwg,2,64] = the feeding layer's BatchNorm-backward sums, the
-    rider's coef or None); dw is written in place by the slab reduction that follows the kernel."""
+    rider's coef or None); dw is written in place by the slab reduction that follows the kernel.  gvec [B,64] f32 instead of g: the
+    layer's output was globally pooled (one gradient row per sample)."""
     B, H, W, C = y.shape
-    assert C == 64 and g.shape == y.shape and xr.shape == y.shape and g.is_contiguous() and y.is_contiguous() and xr.is_contiguous()
+    if (g is None) == (gvec is None):
+        raise RuntimeError("conv3x3_bwd_fused: exactly one of g (a tensor) and gvec (one row per sample) is given")
+    assert C == 64 and xr.shape == y.shape and y.is_contiguous() and xr.is_contiguous()
+    assert (g.shape == y.shape and g.is_contiguous()) if g is not None else (tuple(gvec.shape) == (B, 64) and gvec.is_contiguous() and gvec.dtype == torch.float32)
     assert tuple(wpt.shape) == (9, 64, 64) and stats.is_contiguous() and coef.is_contiguous() and dw.is_contiguous()
     L = _lib.lib()
     nwg = L.wm_conv3x3_bwd_fused_nwg(c_int(B), c_int(H), c_int(W))
@@ -505,10 +513,10 @@ def conv3x3_bwd_fused(g, y, stats, coef, wpt, xr, in_scale, in_shift, dw, accumu
     fst, fcoef = _fin_rider(fin(part) if callable(fin) else fin)     # fin: a rider dict, or a function of the partial rows this call produces
     ws = torch.empty(nwg * 9 * 64 * 64, device=y.device, dtype=torch.float32)
     Cout, Cin = dw.shape[0], dw.shape[1]
-    info = {"B": B, "H": H, "W": W, "dtype": y.dtype}
+    info = {"B": B, "H": H, "W": W, "dtype": y.dtype, "gvec": gvec is not None}
     rc = _timed("conv3x3_bwd_fused", info, lambda: L.wm_conv3x3_bwd_fused(
-        _p(g), _p(y), _p(stats), _p(coef), _p(wpt), _p(xr), _p(in_scale), _p(in_shift), _p(dx), _p(part), _p(ws), c_int(B), c_int(H), c_int(W),
-        c_int(dtype_id(y)), c_int(1 if premasked else 0), _sweep(reverse), _stream()))
+        _p(g), _p(gvec), _p(y), _p(stats), _p(coef), _p(wpt), _p(xr), _p(in_scale), _p(in_shift), _p(dx), _p(part), _p(ws), c_int(B), c_int(H),
+        c_int(W), c_int(dtype_id(y)), c_int(1 if premasked else 0), _sweep(reverse), _stream()))
     _lib.check(rc, "wm_conv3x3_bwd_fused")
     rc = L.wm_conv3x3_bwd_fused_reduce(_p(ws), _p(dw), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(Cout),
                                        ctypes.byref(fst) if fst is not None else None, _stream())
