@@ -483,6 +483,7 @@ def test_pooled_layer_fusion_keeps_the_training_step(debug_lib):
     L = debug_lib   # the -DWM_DEBUG build: the release library has no A/B switches
     outs = []
     try:
+        L.wm_debug_bwd_fuse(ctypes.c_int(0))   # (the one-kernel backward sums over other tiles: test_one_kernel_backward_keeps_the_training_step)
         for on in (1, 0):
             L.wm_debug_gv_fuse(ctypes.c_int(on))
             torch.manual_seed(10)
@@ -493,6 +494,7 @@ def test_pooled_layer_fusion_keeps_the_training_step(debug_lib):
             outs.append((losses, [p.detach().clone() for p in list(h.encoder_decoder.parameters()) + list(h.discriminator.parameters())]))
     finally:
         L.wm_debug_gv_fuse(ctypes.c_int(1))
+        L.wm_debug_bwd_fuse(ctypes.c_int(1))
     for k in outs[0][0]:
         assert outs[0][0][k] == outs[1][0][k], k
     for a, b in zip(outs[0][1], outs[1][1]):
