@@ -458,12 +458,13 @@ int wm_scale_dev(float* x, size_t n, const float* scale_dev, void* stream);
  *                 dgrad 1: in = the conv's output-side tensor [B,IH,IW,KC], out = its input-side tensor [B,OH,OW,NC]
  *                 (the conv's input gradient, or ConvTranspose2d's forward), w packed with transpose 1.
  * wm_gconv_wgrad: dw [Cout][Cin][KH][KW] (+)= sum_pixels dout x in; dbias [Cout] (+)= column sums of dout (may be NULL);
- *                 partial = f32 scratch [wm_gconv_wgrad_nsplit(..)][KH*KW][NC][KC].  IH/IW/KC describe `in`, OH/OW/NC `dout`.
- * wm_gcolsum    : out [Creal] (+)= column sums of x [npix][C].
+ *                 partial = f32 scratch of wm_gconv_wgrad_scratch_floats(..) floats.  IH/IW/KC describe `in`, OH/OW/NC `dout`.
+ * wm_gcolsum    : out [Creal] (+)= column sums of x [npix][C]; scratch: wm_gcolsum_scratch_floats(npix, C) floats.
  * wm_unary_fwd / _bwd: kind 0 ReLU, 1 LeakyReLU(0.2), 2 GELU (erf), 3 ELU, 4 Sigmoid, 5 Tanh; the backward reads the INPUT x.
  * wm_add_scaled : out = a + alpha * b.
  * wm_qfatt_fwd  : out = x + gamma[b,c] * res + beta[b,c] (gamma / beta f32 [B][ldv]); wm_qfatt_bwd: gres = gamma * g,
- *                 ggamma[b,c] = sum_p g * res, gbeta[b,c] = sum_p g (the gradient wrt x is g itself).
+ *                 ggamma[b,c] = sum_p g * res, gbeta[b,c] = sum_p g (the gradient wrt x is g itself); scratch:
+ *                 wm_qfatt_bwd_scratch_floats(B, hw, ldv) floats.
  * wm_gpool_fwd  : out f32 [B][C] = mean over the hw pixels of x [B,hw,C]; wm_gpool_bwd: gx = g / hw.
  * wm_pad_nchw_to_nhwc(_bwd): x [B,C,H,W] f32 -> out [B,H+top+bottom,W+left+right,CP], mode 0 symmetric, 1 replicate (pads may
  *                 be 0: a plain layout change); the backward sums every padded position back onto its source pixel.
@@ -478,14 +479,17 @@ int wm_gconv_fwd(const void* in, const void* w, const float* bias, void* out, in
 int wm_gconv_wgrad_nsplit(int B, int OH, int OW, int KC, int NC, int KH, int KW);
 int wm_gconv_wgrad(const void* dout, const void* in, float* partial, float* dw, float* dbias, int accumulate, int B, int IH, int IW,
                    int KC, int OH, int OW, int NC, int KH, int KW, int stride, int pad, int Cout, int Cin, int dtype, void* stream);
-int wm_gcolsum(const void* x, size_t npix, int C, float* out, int Creal, int accumulate, int dtype, void* stream);
+size_t wm_gconv_wgrad_scratch_floats(int B, int OH, int OW, int KC, int NC, int KH, int KW);
+size_t wm_gcolsum_scratch_floats(size_t npix, int C);
+int wm_gcolsum(const void* x, size_t npix, int C, float* out, int Creal, int accumulate, float* scratch, int dtype, void* stream);
 int wm_unary_fwd(const void* x, void* y, size_t n, int kind, int dtype, void* stream);
 int wm_unary_bwd(const void* x, const void* gy, void* gx, size_t n, int kind, int dtype, void* stream);
 int wm_add_scaled(const void* a, const void* b, void* out, size_t n, float alpha, int dtype, void* stream);
 int wm_qfatt_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* out, int B, size_t hw, int C, int ldv,
                  int dtype, void* stream);
-int wm_qfatt_bwd(const void* g, const void* res, const float* gamma, void* gres, float* ggamma, float* gbeta, int B, size_t hw, int C,
-                 int ldv, int dtype, void* stream);
+size_t wm_qfatt_bwd_scratch_floats(int B, size_t hw, int ldv);
+int wm_qfatt_bwd(const void* g, const void* res, const float* gamma, void* gres, float* ggamma, float* gbeta, float* scratch, int B, size_t hw,
+                 int C, int ldv, int dtype, void* stream);
 int wm_gpool_fwd(const void* x, float* out, int B, size_t hw, int C, int dtype, void* stream);
 int wm_gpool_bwd(const float* g, void* gx, int B, size_t hw, int C, int dtype, void* stream);
 int wm_pad_nchw_to_nhwc(const float* x, void* out, int B, int C, int H, int W, int left, int right, int top, int bottom, int mode,

@@ -64,7 +64,7 @@ def test_haar_coupling_and_channel_kernels():
     s1, s2 = G.chan_slice(a, 0, 10), G.chan_slice(a, 10, 13)
     assert s1.shape[3] == 16 and torch.equal(s1[..., :10], a.detach()[..., :10]) and float(s1.detach()[..., 10:].abs().max()) == 0
     cat = G.chan_cat(s1, 10, s2, 13)
-    assert cat.shape[3] == 32 and torch.equal(cat[..., :23], a.detach()[..., :23]) and float(cat[..., 23:].abs().max()) == 0
+    assert cat.shape[3] == 32 and torch.equal(cat[..., :23], a.detach()[..., :23]) and float(cat.detach()[..., 23:].abs().max()) == 0
     cat.sum().backward()
     assert float(a.grad[..., :23].min()) == 1.0 and float(a.grad[..., 23:].abs().max()) == 0.0
 

@@ -11,6 +11,7 @@
 //   dgrad   : din[b,iy,ix,k] = sum_{ky,kx,n} dout[b,(iy + p - ky)/s, (ix + p - kx)/s, n] * wT[tap][k][n]   (taps with a non-integer or
 //             out-of-range source contribute nothing) -- the same kernel with the source geometry inverted
 //   wgrad   : dw[tap][n][k] = sum_{b,oy,ox} dout[b,oy,ox,n] * in[b, oy*s - p + ky, ox*s - p + kx, k], pixels as the MFMA K dimension
+#include <algorithm>
 #include "wm_common.h"
 
 namespace {
@@ -183,6 +184,131 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(GWArgs a) {
     }
 }
 
+// ---- weight gradient, 16-bit dtypes: a workgroup owns a 64 n x 64 k block for a group of <= 8 filter taps and a split of the pixels.  Per
+// chunk of 64 output pixels it stages dout [64 px][64 n] once and, per tap, the gathered input rows [64 px][64 k] (zero where the tap
+// falls outside the image) into the LDS as 128-byte pixel rows (16-byte vector loads, wgrad_ws.hip's bank swizzle); the four waves each
+// keep a 32 x 32 sub-block x taps in registers and read both operands through the transposing ds_read_b64_tr_b16 (pixels are the MFMA's
+// K dimension).  Every input row is read once per (tap, n-block), not once per 16 x 16 block as in the scalar kernel below.
+constexpr int WG_TAPS = 8;
+__device__ __forceinline__ int gswz16(int col) { return (((col >> 1) & 1) << 5) | (((col >> 3) & 1) << 6); }
+template <typename H>
+__device__ __forceinline__ typename h16<H>::x8 g_tr_frag(const char* p0, const char* p1) {
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p0));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p1));
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(typename h16<H>::x8, v);
+}
+template <typename H>
+__global__ __launch_bounds__(256) void gconv_wgrad16_kernel(GWArgs a, int tapgroups) {
+    typedef typename h16<H>::x8 frag;
+    __shared__ __attribute__((aligned(16))) unsigned char sm[3 * 64 * 128];   // dout chunk | two input chunks (double-buffered over the taps)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int taps = a.KH * a.KW;
+    const int kb = (a.KC + 63) / 64;
+    int job = blockIdx.y;
+    const int tg = job % tapgroups; job /= tapgroups;
+    const int kblk = job % kb, nblk = job / kb;
+    const int tap0 = tg * WG_TAPS, ntap = min(WG_TAPS, taps - tap0);
+    const size_t npix = (size_t)a.B * a.OH * a.OW;
+    const size_t chunks = (npix + 63) / 64, cper = (chunks + a.nsplit - 1) / a.nsplit;
+    const size_t c0 = (size_t)blockIdx.x * cper, c1 = c0 + cper < chunks ? c0 + cper : chunks;
+    const H* dout = (const H*)a.dout;
+    const H* in = (const H*)a.in;
+    // staging: thread -> (pixel of the chunk, 16-byte vector), two rounds of 32 pixels
+    const int vec = tid & 7, prow = tid >> 3;
+    // fragment addressing (wgrad_ws.hip): lane (r, kq), (q2, p2); a K-step = 32 pixels = rows 2ks, 2ks+1 of 16 pixels
+    const int mi = wave >> 1, ni = wave & 1;
+    const int r = lane & 15, kq = lane >> 4, q2 = (lane >> 2) & 3, p2 = lane & 3;
+    const int colb = 8 * (kq & 1) + q2;
+    int aof[2][2], bof[2][2];
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int col = colb + 4 * sx;
+            aof[sx][f] = ((kq >> 1) * 16 + col) * 128 + (((mi * 32 + f * 16 + 4 * p2) * 2) ^ gswz16(col));
+            bof[sx][f] = ((kq >> 1) * 16 + col) * 128 + (((ni * 32 + f * 16 + 4 * p2) * 2) ^ gswz16(col));
+        }
+    f32x4 acc[WG_TAPS][2][2];
+#pragma unroll
+    for (int t = 0; t < WG_TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    for (size_t ch = c0; ch < c1; ++ch) {
+        // ---- stage the dout chunk and the first tap's input chunk
+        int oys[2], oxs[2], bs[2]; bool pok[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const size_t pix = ch * 64 + prow + 32 * h;
+            pok[h] = pix < npix;
+            const size_t pc = pok[h] ? pix : 0;
+            oxs[h] = (int)(pc % a.OW); oys[h] = (int)((pc / a.OW) % a.OH); bs[h] = (int)(pc / ((size_t)a.OW * a.OH));
+            const int n = nblk * 64 + vec * 8;
+            u32x4v v = {0u, 0u, 0u, 0u};
+            if (pok[h] && n < a.NC) v = *reinterpret_cast<const u32x4v*>(dout + pc * a.NC + n);
+            const int pl = prow + 32 * h;
+            *reinterpret_cast<u32x4v*>(sm + pl * 128 + ((vec * 16) ^ gswz16(pl & 15))) = v;
+        }
+        auto stage_x = [&](int tap, unsigned char* buf) {
+            const int ky = tap / a.KW, kx = tap - ky * a.KW;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int sy = oys[h] * a.stride - a.pad + ky, sx = oxs[h] * a.stride - a.pad + kx;
+                const int k = kblk * 64 + vec * 8;
+                u32x4v v = {0u, 0u, 0u, 0u};
+                if (pok[h] && k < a.KC && sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW)
+                    v = *reinterpret_cast<const u32x4v*>(in + (((size_t)bs[h] * a.IH + sy) * a.IW + sx) * a.KC + k);
+                const int pl = prow + 32 * h;
+                *reinterpret_cast<u32x4v*>(buf + pl * 128 + ((vec * 16) ^ gswz16(pl & 15))) = v;
+            }
+        };
+        stage_x(tap0, sm + 64 * 128);
+        __syncthreads();
+        for (int t = 0; t < ntap; ++t) {
+            const char* sd = reinterpret_cast<const char*>(sm);
+            const char* sxc = reinterpret_cast<const char*>(sm + (1 + (t & 1)) * 64 * 128);
+            if (t + 1 < ntap) stage_x(tap0 + t + 1, sm + (1 + ((t + 1) & 1)) * 64 * 128);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                frag af[2], bf[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    af[f] = g_tr_frag<H>(sd + 2 * ks * 16 * 128 + aof[0][f], sd + 2 * ks * 16 * 128 + aof[1][f]);
+                    bf[f] = g_tr_frag<H>(sxc + 2 * ks * 16 * 128 + bof[0][f], sxc + 2 * ks * 16 * 128 + bof[1][f]);
+                }
+#pragma unroll
+                for (int tt = 0; tt < WG_TAPS; ++tt)
+                    if (tt == t) {   // (t is a run-time index into register-resident accumulators: a wave-uniform select)
+#pragma unroll
+                        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                            for (int fj = 0; fj < 2; ++fj) acc[tt][fi][fj] = h16<H>::mfma16(af[fi], bf[fj], acc[tt][fi][fj]);
+                    }
+            }
+            __syncthreads();
+        }
+    }
+    // acc[t][fi][fj][i] = dW[tap0 + t][n = 64 nblk + 32 mi + 16 fi + 4 kq + i][k = 64 kblk + 32 ni + 16 fj + r]
+#pragma unroll
+    for (int t = 0; t < WG_TAPS; ++t)
+        if (t < ntap) {
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int n = nblk * 64 + mi * 32 + fi * 16 + 4 * kq + i, k = kblk * 64 + ni * 32 + fj * 16 + r;
+                        if (n < a.NC && k < a.KC) a.partial[(((size_t)blockIdx.x * taps + tap0 + t) * a.NC + n) * a.KC + k] = acc[t][fi][fj][i];
+                    }
+        }
+}
+
 // dw[co][ci][ky][kx] (+)= sum over splits of partial[split][tap][co][ci]   (co < Cout, ci < Cin: the real extents)
 __global__ __launch_bounds__(256) void gconv_wreduce_kernel(const float* __restrict__ partial, int nsplit, int taps, int NC, int KC, float* __restrict__ dw,
                                                             int Cout, int Cin, int accumulate) {
@@ -207,17 +333,30 @@ __global__ void gconv_pack_kernel(const float* __restrict__ w, T* __restrict__ w
     }
 }
 
-// column sums of x [npix][C] (the bias gradient): out[c] (+)= sum_pix x[pix][c]; one workgroup per 64 channels, deterministic
+// column sums of x [npix][C] (the bias gradient), two deterministic stages: grid (64-channel blocks, pixel splits) -> part [nsplit][C], then
+// out[c] (+)= sum over the splits in a fixed order
 template <typename T>
-__global__ __launch_bounds__(256) void gcolsum_kernel(const T* __restrict__ x, size_t npix, int C, float* __restrict__ out, int Creal, int accumulate) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void gcolsum_kernel(const T* __restrict__ x, size_t npix, int C, float* __restrict__ part) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const size_t per = (npix + gridDim.y - 1) / gridDim.y, p0 = (size_t)blockIdx.y * per, p1 = p0 + per < npix ? p0 + per : npix;
     float acc = 0.f;
     if (c < C)
-        for (size_t p = part; p < npix; p += 4) acc += to_f32(x[p * C + c]);
+        for (size_t p = p0 + sub; p < p1; p += 4) acc += to_f32(x[p * C + c]);
     __shared__ float s[4][64];
-    s[part][threadIdx.x & 63] = acc;
+    s[sub][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (part == 0 && c < Creal) out[c] = (accumulate ? out[c] : 0.f) + (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+    if (sub == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void gcolsum_reduce_kernel(const float* __restrict__ part, int nsplit, int C, float* __restrict__ out, int Creal, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Creal) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * C + c];
+    out[c] = (accumulate ? out[c] : 0.f) + s;
+}
+inline int colsum_nsplit(size_t npix) {
+    const size_t n = (npix + 1023) / 1024;
+    return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
 }
 
 inline int grid1(size_t n, int cap = 4096) {
@@ -268,6 +407,15 @@ extern "C" int wm_gconv_fwd(const void* in, const void* w, const float* bias, vo
     return WM_OK;
 }
 
+// pixel splits of the 16-bit kernel: enough workgroups to fill the chip, at most 64 slabs
+static int wgrad16_nsplit(int B, int OH, int OW, int KC, int NC, int KH, int KW) {
+    const size_t chunks = ((size_t)B * OH * OW + 63) / 64;
+    const long jobs = (long)((NC + 63) / 64) * ((KC + 63) / 64) * ((KH * KW + WG_TAPS - 1) / WG_TAPS);
+    long ns = (1024 + jobs - 1) / jobs;
+    if (ns > 64) ns = 64;
+    if ((size_t)ns > chunks) ns = (long)chunks;
+    return (int)(ns < 1 ? 1 : ns);
+}
 extern "C" int wm_gconv_wgrad_nsplit(int B, int OH, int OW, int KC, int NC, int KH, int KW) {
     const size_t npix = (size_t)B * OH * OW;
     const long jobs = (long)KH * KW * (NC / 16) * ((KC + 15) / 16);
@@ -279,8 +427,15 @@ extern "C" int wm_gconv_wgrad_nsplit(int B, int OH, int OW, int KC, int NC, int 
     return (int)ns;
 }
 
+extern "C" size_t wm_gconv_wgrad_scratch_floats(int B, int OH, int OW, int KC, int NC, int KH, int KW) {
+    const int ns = std::max(wm_gconv_wgrad_nsplit(B, OH, OW, KC, NC, KH, KW), wgrad16_nsplit(B, OH, OW, KC, NC, KH, KW));   // either kernel
+    const size_t a = (size_t)ns * KH * KW * NC * KC, b = (size_t)colsum_nsplit((size_t)B * OH * OW) * NC;
+    return a > b ? a : b;
+}
+extern "C" size_t wm_gcolsum_scratch_floats(size_t npix, int C) { return (size_t)colsum_nsplit(npix) * C; }
+
 // dw [Cout][Cin][KH][KW] f32 (+)= the weight gradient; dbias [Cout] (+)= column sums of dout (may be NULL).
-// partial: f32 scratch [wm_gconv_wgrad_nsplit(..)][KH*KW][NC][KC].
+// partial: f32 scratch of wm_gconv_wgrad_scratch_floats(..) floats.
 extern "C" int wm_gconv_wgrad(const void* dout, const void* in, float* partial, float* dw, float* dbias, int accumulate, int B, int IH, int IW,
                               int KC, int OH, int OW, int NC, int KH, int KW, int stride, int pad, int Cout, int Cin, int dtype, void* stream) {
     WM_REQUIRE(dout && in && partial && dw, WM_E_BADARG, "wm_gconv_wgrad: null pointer");
@@ -289,29 +444,43 @@ extern "C" int wm_gconv_wgrad(const void* dout, const void* in, float* partial, 
     WM_REQUIRE(Cout > 0 && Cout <= NC && Cin > 0 && Cin <= KC, WM_E_BADARG, "wm_gconv_wgrad: Cout / Cin exceed the tensors' channel strides");
     GWArgs a;
     a.dout = dout; a.in = in; a.partial = partial; a.B = B; a.IH = IH; a.IW = IW; a.KC = KC; a.OH = OH; a.OW = OW; a.NC = NC;
-    a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.nsplit = wm_gconv_wgrad_nsplit(B, OH, OW, KC, NC, KH, KW);
-    const int jobs = KH * KW * (NC / 16) * ((KC + 15) / 16);
+    a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     hipStream_t s = (hipStream_t)stream;
-    WM_DISPATCH_DTYPE(dtype, "wm_gconv_wgrad", hipLaunchKernelGGL(gconv_wgrad_kernel<T>, dim3((unsigned)jobs, (unsigned)a.nsplit), dim3(256), 0, s, a));
+    if (dtype == WM_F32) {
+        a.nsplit = wm_gconv_wgrad_nsplit(B, OH, OW, KC, NC, KH, KW);
+        const int jobs = KH * KW * (NC / 16) * ((KC + 15) / 16);
+        hipLaunchKernelGGL(gconv_wgrad_kernel<float>, dim3((unsigned)jobs, (unsigned)a.nsplit), dim3(256), 0, s, a);
+    } else {
+        a.nsplit = wgrad16_nsplit(B, OH, OW, KC, NC, KH, KW);
+        const int tapgroups = (KH * KW + WG_TAPS - 1) / WG_TAPS;
+        const dim3 grid((unsigned)a.nsplit, (unsigned)(((NC + 63) / 64) * ((KC + 63) / 64) * tapgroups));
+        if (dtype == WM_BF16) hipLaunchKernelGGL(gconv_wgrad16_kernel<bf16_t>, grid, dim3(256), 0, s, a, tapgroups);
+        else hipLaunchKernelGGL(gconv_wgrad16_kernel<f16_t>, grid, dim3(256), 0, s, a, tapgroups);
+    }
     WM_LAUNCH_CHECK("wm_gconv_wgrad");
     hipLaunchKernelGGL(gconv_wreduce_kernel, dim3(grid1((size_t)Cout * Cin * KH * KW)), dim3(256), 0, s, partial, a.nsplit, KH * KW, NC, KC, dw, Cout, Cin,
                        accumulate);
     WM_LAUNCH_CHECK("wm_gconv_wgrad(reduce)");
-    if (dbias) {
+    if (dbias) {   // (the slab partials have been consumed by the reduce above: the scratch is free again)
         const size_t npix = (size_t)B * OH * OW;
+        const int ns = colsum_nsplit(npix);
         WM_DISPATCH_DTYPE(dtype, "wm_gconv_wgrad(bias)",
-            hipLaunchKernelGGL(gcolsum_kernel<T>, dim3((unsigned)((NC + 63) / 64)), dim3(256), 0, s, (const T*)dout, npix, NC, dbias, Cout, accumulate));
+            hipLaunchKernelGGL(gcolsum_kernel<T>, dim3((unsigned)((NC + 63) / 64), (unsigned)ns), dim3(256), 0, s, (const T*)dout, npix, NC, partial));
+        hipLaunchKernelGGL(gcolsum_reduce_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, s, partial, ns, NC, dbias, Cout, accumulate);
         WM_LAUNCH_CHECK("wm_gconv_wgrad(bias)");
     }
     return WM_OK;
 }
 
-// out [Creal] f32 (+)= column sums of x [npix][C] (the bias gradient of a ConvTranspose2d / Linear whose dout is not a wgrad operand)
-extern "C" int wm_gcolsum(const void* x, size_t npix, int C, float* out, int Creal, int accumulate, int dtype, void* stream) {
-    WM_REQUIRE(x && out && npix > 0 && C > 0 && Creal > 0 && Creal <= C, WM_E_BADARG, "wm_gcolsum: bad arguments");
+// out [Creal] f32 (+)= column sums of x [npix][C] (the bias gradient of a ConvTranspose2d / Linear whose dout is not a wgrad operand);
+// scratch: wm_gcolsum_scratch_floats(npix, C) floats
+extern "C" int wm_gcolsum(const void* x, size_t npix, int C, float* out, int Creal, int accumulate, float* scratch, int dtype, void* stream) {
+    WM_REQUIRE(x && out && scratch && npix > 0 && C > 0 && Creal > 0 && Creal <= C, WM_E_BADARG, "wm_gcolsum: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    const int ns = colsum_nsplit(npix);
     WM_DISPATCH_DTYPE(dtype, "wm_gcolsum",
-        hipLaunchKernelGGL(gcolsum_kernel<T>, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, (const T*)x, npix, C, out, Creal, accumulate));
+        hipLaunchKernelGGL(gcolsum_kernel<T>, dim3((unsigned)((C + 63) / 64), (unsigned)ns), dim3(256), 0, s, (const T*)x, npix, C, scratch));
+    hipLaunchKernelGGL(gcolsum_reduce_kernel, dim3((unsigned)((Creal + 255) / 256)), dim3(256), 0, s, scratch, ns, C, out, Creal, accumulate);
     WM_LAUNCH_CHECK("wm_gcolsum");
     return WM_OK;
 }

@@ -63,16 +63,17 @@ __global__ __launch_bounds__(256) void qfatt_fwd_kernel(const T* __restrict__ x,
         out[i] = from_f32<T>(to_f32(x[i]) + gamma[b * ldv + c] * to_f32(res[i]) + beta[b * ldv + c]);
     }
 }
-// backward: gres = gamma * g (elementwise), ggamma[b,c] = sum_p g * res, gbeta[b,c] = sum_p g; grid = (C/64 blocks, B), 4 pixel lanes
+// backward: gres = gamma * g (elementwise), ggamma[b,c] = sum_p g * res, gbeta[b,c] = sum_p g; grid = (C/64 blocks, B, pixel splits), 4 pixel
+// lanes; part [nsplit][B][2][ldv], summed in a fixed order by qfatt_bwd_reduce_kernel
 template <typename T>
 __global__ __launch_bounds__(256) void qfatt_bwd_kernel(const T* __restrict__ g, const T* __restrict__ res, const float* __restrict__ gamma,
-                                                        T* __restrict__ gres, float* __restrict__ ggamma, float* __restrict__ gbeta, size_t hw, int C,
-                                                        int ldv) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6, b = blockIdx.y;
+                                                        T* __restrict__ gres, float* __restrict__ part, size_t hw, int C, int ldv) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, b = blockIdx.y;
+    const size_t per = (hw + gridDim.z - 1) / gridDim.z, p0 = (size_t)blockIdx.z * per, p1 = p0 + per < hw ? p0 + per : hw;
     float s1 = 0.f, s2 = 0.f;
     if (c < C) {
         const float gm = gamma[(size_t)b * ldv + c];
-        for (size_t p = part; p < hw; p += 4) {
+        for (size_t p = p0 + sub; p < p1; p += 4) {
             const size_t i = ((size_t)b * hw + p) * C + c;
             const float gv = to_f32(g[i]), rv = to_f32(res[i]);
             gres[i] = from_f32<T>(gm * gv);
@@ -81,12 +82,29 @@ __global__ __launch_bounds__(256) void qfatt_bwd_kernel(const T* __restrict__ g,
         }
     }
     __shared__ float sh[2][4][64];
-    sh[0][part][threadIdx.x & 63] = s1; sh[1][part][threadIdx.x & 63] = s2;
+    sh[0][sub][threadIdx.x & 63] = s1; sh[1][sub][threadIdx.x & 63] = s2;
     __syncthreads();
-    if (part == 0 && c < C) {
-        ggamma[(size_t)b * ldv + c] = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
-        gbeta[(size_t)b * ldv + c] = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
+    if (sub == 0 && c < C) {
+        float* o = part + (((size_t)blockIdx.z * gridDim.y + b) * 2) * ldv;
+        o[c] = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
+        o[ldv + c] = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
     }
+}
+__global__ __launch_bounds__(256) void qfatt_bwd_reduce_kernel(const float* __restrict__ part, int nsplit, int B, int C, int ldv, float* __restrict__ ggamma,
+                                                               float* __restrict__ gbeta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nsplit; ++k) {
+        const float* o = part + (((size_t)k * B + b) * 2) * ldv;
+        s1 += o[c]; s2 += o[ldv + c];
+    }
+    ggamma[(size_t)b * ldv + c] = s1; gbeta[(size_t)b * ldv + c] = s2;
+}
+inline int qfatt_nsplit(size_t hw) {
+    const size_t n = (hw + 1023) / 1024;
+    return (int)(n < 1 ? 1 : (n > 64 ? 64 : n));
 }
 // global average pool x [B,hw,C] -> out f32 [B,C]; backward: gx[b,p,c] = g[b,c] / hw
 template <typename T>
@@ -313,13 +331,16 @@ extern "C" int wm_qfatt_fwd(const void* x, const void* res, const float* gamma, 
     WM_LAUNCH_CHECK("wm_qfatt_fwd");
     return WM_OK;
 }
-extern "C" int wm_qfatt_bwd(const void* g, const void* res, const float* gamma, void* gres, float* ggamma, float* gbeta, int B, size_t hw, int C, int ldv,
-                            int dtype, void* stream) {
-    WM_REQUIRE(g && res && gamma && gres && ggamma && gbeta && B > 0 && hw > 0 && C > 0 && ldv >= C, WM_E_BADARG, "wm_qfatt_bwd: bad arguments");
+extern "C" size_t wm_qfatt_bwd_scratch_floats(int B, size_t hw, int ldv) { return (size_t)qfatt_nsplit(hw) * B * 2 * ldv; }
+extern "C" int wm_qfatt_bwd(const void* g, const void* res, const float* gamma, void* gres, float* ggamma, float* gbeta, float* scratch, int B, size_t hw,
+                            int C, int ldv, int dtype, void* stream) {
+    WM_REQUIRE(g && res && gamma && gres && ggamma && gbeta && scratch && B > 0 && hw > 0 && C > 0 && ldv >= C, WM_E_BADARG, "wm_qfatt_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    const int ns = qfatt_nsplit(hw);
     WM_DISPATCH_DTYPE(dtype, "wm_qfatt_bwd",
-        hipLaunchKernelGGL(qfatt_bwd_kernel<T>, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0, s, (const T*)g, (const T*)res, gamma, (T*)gres, ggamma,
-                           gbeta, hw, C, ldv));
+        hipLaunchKernelGGL(qfatt_bwd_kernel<T>, dim3((unsigned)((C + 63) / 64), (unsigned)B, (unsigned)ns), dim3(256), 0, s, (const T*)g, (const T*)res, gamma,
+                           (T*)gres, scratch, hw, C, ldv));
+    hipLaunchKernelGGL(qfatt_bwd_reduce_kernel, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, s, scratch, ns, B, C, ldv, ggamma, gbeta);
     WM_LAUNCH_CHECK("wm_qfatt_bwd");
     return WM_OK;
 }

@@ -1163,8 +1163,10 @@ def gconv_wgrad(dout, x, Cout, Cin, KH, KW, stride, pad, want_bias=True):
     _, IH, IW, KC = x.shape
     if x.shape[0] != B or x.dtype != dout.dtype:
         raise ValueError("gconv_wgrad: operands disagree")
-    ns = _lib.lib().wm_gconv_wgrad_nsplit(c_int(B), c_int(OH), c_int(OW), c_int(KC), c_int(NC), c_int(KH), c_int(KW))
-    partial = torch.empty(ns * KH * KW * NC * KC, device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    L.wm_gconv_wgrad_scratch_floats.restype = c_size_t
+    partial = torch.empty(L.wm_gconv_wgrad_scratch_floats(c_int(B), c_int(OH), c_int(OW), c_int(KC), c_int(NC), c_int(KH), c_int(KW)), device=x.device,
+                          dtype=torch.float32)
     dw = torch.empty(Cout, Cin, KH, KW, device=x.device, dtype=torch.float32)
     db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_bias else None
     rc = _lib.lib().wm_gconv_wgrad(_p(dout), _p(x), _p(partial), _p(dw), _p(db), c_int(0), c_int(B), c_int(IH), c_int(IW), c_int(KC), c_int(OH),
@@ -1178,7 +1180,10 @@ def gcolsum(x, creal):
     x = _nhwc(x)
     C = x.shape[3]
     out = torch.empty(creal, device=x.device, dtype=torch.float32)
-    rc = _lib.lib().wm_gcolsum(_p(x), c_size_t(x.numel() // C), c_int(C), _p(out), c_int(creal), c_int(0), c_int(dt_id(x.dtype)), _stream())
+    L = _lib.lib()
+    L.wm_gcolsum_scratch_floats.restype = c_size_t
+    scratch = torch.empty(L.wm_gcolsum_scratch_floats(c_size_t(x.numel() // C), c_int(C)), device=x.device, dtype=torch.float32)
+    rc = L.wm_gcolsum(_p(x), c_size_t(x.numel() // C), c_int(C), _p(out), c_int(creal), c_int(0), _p(scratch), c_int(dt_id(x.dtype)), _stream())
     _lib.check(rc, "wm_gcolsum")
     return out
 
@@ -1232,8 +1237,11 @@ def qfatt_bwd(g, res, gamma):
     gres = torch.empty_like(g)
     gg = torch.zeros_like(gamma)
     gb = torch.zeros_like(gamma)
-    rc = _lib.lib().wm_qfatt_bwd(_p(g), _p(res), _p(gamma), _p(gres), _p(gg), _p(gb), c_int(B), c_size_t(H * W), c_int(C), c_int(gamma.shape[1]),
-                                 c_int(dt_id(g.dtype)), _stream())
+    L = _lib.lib()
+    L.wm_qfatt_bwd_scratch_floats.restype = c_size_t
+    scratch = torch.empty(L.wm_qfatt_bwd_scratch_floats(c_int(B), c_size_t(H * W), c_int(gamma.shape[1])), device=g.device, dtype=torch.float32)
+    rc = L.wm_qfatt_bwd(_p(g), _p(res), _p(gamma), _p(gres), _p(gg), _p(gb), _p(scratch), c_int(B), c_size_t(H * W), c_int(C), c_int(gamma.shape[1]),
+                        c_int(dt_id(g.dtype)), _stream())
     _lib.check(rc, "wm_qfatt_bwd")
     return gres, gg, gb
 
