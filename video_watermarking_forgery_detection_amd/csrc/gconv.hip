@@ -337,15 +337,29 @@ __global__ void gconv_pack_kernel(const float* __restrict__ w, T* __restrict__ w
 // out[c] (+)= sum over the splits in a fixed order
 template <typename T>
 __global__ __launch_bounds__(256) void gcolsum_kernel(const T* __restrict__ x, size_t npix, int C, float* __restrict__ part) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    // a thread owns one 16-byte vector (VE channels) of the 64-channel block and every (256 / vectors)-th pixel of the split
+    constexpr int VE = 16 / sizeof(T), NV = 64 / VE, PL = 256 / NV;   // bf16: 8 channels, 8 vectors, 32 pixel lanes
+    const int v = threadIdx.x % NV, pl = threadIdx.x / NV;
+    const int c0 = blockIdx.x * 64 + v * VE;
     const size_t per = (npix + gridDim.y - 1) / gridDim.y, p0 = (size_t)blockIdx.y * per, p1 = p0 + per < npix ? p0 + per : npix;
-    float acc = 0.f;
-    if (c < C)
-        for (size_t p = p0 + sub; p < p1; p += 4) acc += to_f32(x[p * C + c]);
-    __shared__ float s[4][64];
-    s[sub][threadIdx.x & 63] = acc;
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    if (c0 < C)
+        for (size_t p = p0 + pl; p < p1; p += PL) {
+            const vec16<T> t = *reinterpret_cast<const vec16<T>*>(x + p * C + c0);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) acc[e] += t.get(e);
+        }
+    __shared__ float s[PL][65];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s[pl][v * VE + e] = acc[e];
     __syncthreads();
-    if (sub == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+    if (threadIdx.x < 64 && blockIdx.x * 64 + (int)threadIdx.x < C) {
+        float t = 0.f;
+        for (int k = 0; k < PL; ++k) t += s[k][threadIdx.x];
+        part[(size_t)blockIdx.y * C + blockIdx.x * 64 + threadIdx.x] = t;
+    }
 }
 __global__ __launch_bounds__(256) void gcolsum_reduce_kernel(const float* __restrict__ part, int nsplit, int C, float* __restrict__ out, int Creal, int accumulate) {
     const int c = blockIdx.x * 256 + threadIdx.x;

@@ -27,6 +27,12 @@ def _pad_bias(bias, n):
     return out
 
 
+def _fast3x3(weight, stride, pad, dtype, out_stride):
+    """3x3 stride-1 pad-1 convolutions on 16-bit activations whose output stride is a multiple of 32 run on the hot path's
+    wave-specialised / streamed-filter kernels (csrc/conv3x3*.hip, wgrad_ws.hip) instead of the general direct kernel"""
+    return (dtype in (torch.bfloat16, torch.float16) and tuple(weight.shape[2:]) == (3, 3) and stride == 1 and pad == 1 and out_stride % 32 == 0)
+
+
 class _ConvFn(Function):
     """nn.Conv2d on NHWC: weight [Cout,Cin,KH,KW] f32"""
 
@@ -38,8 +44,12 @@ class _ConvFn(Function):
             raise ValueError(f"conv expects {Cin} input channels (stride {cpad(Cin)}), the activation has stride {KC}")
         NC = cpad(Cout)
         OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
-        wp = ops.gconv_pack(weight.detach(), NC, KC, False, x.dtype)
-        out = ops.gconv_fwd(x, wp, _pad_bias(bias, NC), (OH, OW), KH, KW, stride, pad)
+        if _fast3x3(weight, stride, pad, x.dtype, NC):
+            wp = ops.pack_w3x3(weight.detach(), NC, KC, x.dtype)
+            out, _ = ops.conv3x3_fwd(x, wp, _pad_bias(bias, NC), None, None, want_stats=False)
+        else:
+            wp = ops.gconv_pack(weight.detach(), NC, KC, False, x.dtype)
+            out = ops.gconv_fwd(x, wp, _pad_bias(bias, NC), (OH, OW), KH, KW, stride, pad)
         ctx.save_for_backward(x, weight)
         ctx.geo = (stride, pad, bias is not None)
         return out
@@ -52,10 +62,19 @@ class _ConvFn(Function):
         g = g.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wt = ops.gconv_pack(weight.detach(), x.shape[3], g.shape[3], True, g.dtype)
-            gx = ops.gconv_fwd(g, wt, None, (x.shape[1], x.shape[2]), KH, KW, stride, pad, dgrad=True)
+            if _fast3x3(weight, stride, pad, g.dtype, x.shape[3]):
+                wt = ops.pack_w3x3(weight.detach(), g.shape[3], x.shape[3], g.dtype, transpose=True)
+                gx, _ = ops.conv3x3_fwd(g, wt, None, None, None, want_stats=False)
+            else:
+                wt = ops.gconv_pack(weight.detach(), x.shape[3], g.shape[3], True, g.dtype)
+                gx = ops.gconv_fwd(g, wt, None, (x.shape[1], x.shape[2]), KH, KW, stride, pad, dgrad=True)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            gw, gb = ops.gconv_wgrad(g, x, Cout, Cin, KH, KW, stride, pad, want_bias=has_bias)
+            if _fast3x3(weight, stride, pad, g.dtype, 32):      # (the weight-gradient kernels take any 8-multiple of channels)
+                gw = torch.empty(Cout, Cin, 3, 3, device=g.device, dtype=torch.float32)
+                ops.conv3x3_wgrad(x, x.shape[3], None, None, g, gw, False)
+                gb = ops.gcolsum(g, Cout) if has_bias else None
+            else:
+                gw, gb = ops.gconv_wgrad(g, x, Cout, Cin, KH, KW, stride, pad, want_bias=has_bias)
         return gx, gw, gb, None, None
 
 
