@@ -470,7 +470,8 @@ int wm_scale_dev(float* x, size_t n, const float* scale_dev, void* stream);
  *                 be 0: a plain layout change); the backward sums every padded position back onto its source pixel.
  * wm_gunpack_nchw(_bwd): the top-left H x W window and first C channels of x [B,PH,PW,CP] -> [B,C,H,W] f32, and its adjoint.
  * wm_spectral_norm_fwd: W [M][N] = weight_orig.view(Cout,-1); do_iter != 0 (training): v = normalize(W^T u), u = normalize(W v)
- *                 in place (eps 1e-12); sigma = u.(W v); Wsn = W / sigma.   wm_spectral_norm_bwd: gW (+)= (G - <G,Wsn> u v^T)/sigma
+ *                 in place (eps 1e-12); sigma = u.(W v); Wsn = W / sigma; scratch: wm_spectral_norm_scratch_floats(M, N) floats.
+ *                 wm_spectral_norm_bwd: gW (+)= (G - <G,Wsn> u v^T)/sigma
  *                 (u, v detached, as torch computes them under no_grad); partial = f32[256] scratch.
  * wm_bayar_constrain: every 5x5 filter of w [nfilters][25] in place: centre := 0, filter /= its sum, centre := -1. */
 int wm_gconv_pack(const float* w, void* wp, int Cout, int Cin, int KH, int KW, int RP, int CP, int transpose, int dtype, void* stream);
@@ -498,7 +499,8 @@ int wm_pad_nchw_to_nhwc_bwd(const void* gp, float* gx, int B, int C, int H, int 
                             int CP, int dtype, void* stream);
 int wm_gunpack_nchw(const void* x, float* out, int B, int C, int H, int W, int PH, int PW, int CP, int dtype, void* stream);
 int wm_gunpack_nchw_bwd(const float* g, void* gx, int B, int C, int H, int W, int PH, int PW, int CP, int dtype, void* stream);
-int wm_spectral_norm_fwd(const float* W, float* u, float* v, float* sigma, float* Wsn, int M, int N, int do_iter, void* stream);
+size_t wm_spectral_norm_scratch_floats(int M, int N);
+int wm_spectral_norm_fwd(const float* W, float* u, float* v, float* sigma, float* Wsn, float* scratch, int M, int N, int do_iter, void* stream);
 int wm_spectral_norm_bwd(const float* G, const float* Wsn, const float* u, const float* v, const float* sigma, float* partial,
                          float* gW, int M, int N, int accumulate, void* stream);
 int wm_bayar_constrain(float* w, int nfilters, void* stream);

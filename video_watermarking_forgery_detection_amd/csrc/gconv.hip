@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void gcolsum_reduce_kernel(const float* __rest
 }
 inline int colsum_nsplit(size_t npix) {
     const size_t n = (npix + 1023) / 1024;
-    return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
+    return (int)(n < 1 ? 1 : (n > 64 ? 64 : n));
 }
 
 inline int grid1(size_t n, int cap = 4096) {

@@ -196,12 +196,45 @@ __global__ __launch_bounds__(256) void unpack_bwd_kernel(const float* __restrict
 }
 
 // ---- spectral norm (torch.nn.utils.spectral_norm, one power iteration): W [M][N] f32 = weight_orig.view(Cout, -1)
-//   v = normalize(W^T u), u = normalize(W v), sigma = u . (W v); eps = 1e-12.  One workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void sn_power_iter_kernel(const float* __restrict__ W, float* __restrict__ u, float* __restrict__ v, float* __restrict__ sigma,
-                                                             int M, int N, int do_iter, float eps) {
-    extern __shared__ float sm[];   // su[M] | red[1024]
-    float* su = sm;
-    float* red = sm + M;
+//   v = normalize(W^T u), u = normalize(W v), sigma = u . (W v); eps = 1e-12.  Four small launches (the matrix is read twice, by many
+//   workgroups): column pass, its norm, row pass, its norm + sigma.  scratch: f32 [N + M + 2 * 256 + 4]
+__global__ __launch_bounds__(256) void sn_cols_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ vraw, float* __restrict__ part,
+                                                      int M, int N) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    if (j < N)
+        for (int i = 0; i < M; ++i) s += W[(size_t)i * N + j] * u[i];
+    if (j < N) vraw[j] = s;
+    float q = wave_sum(s * s);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+// v = vraw / max(||vraw||, eps)   (one workgroup)
+__global__ __launch_bounds__(256) void sn_vnorm_kernel(const float* __restrict__ vraw, const float* __restrict__ part, int nparts, float* __restrict__ v, int N,
+                                                       float eps) {
+    __shared__ float sn;
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < nparts; ++k) t += part[k];
+        sn = fmaxf(sqrtf(t), eps);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < N; j += 256) v[j] = vraw[j] / sn;
+}
+// wv[i] = W[i,:] . v  (a wave per row)
+__global__ __launch_bounds__(256) void sn_rows_kernel(const float* __restrict__ W, const float* __restrict__ v, float* __restrict__ wv, int M, int N) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= M) return;
+    float s = 0.f;
+    for (int j = threadIdx.x & 63; j < N; j += 64) s += W[(size_t)i * N + j] * v[j];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) wv[i] = s;
+}
+// do_iter: u = wv / max(||wv||, eps); sigma = u . wv   (one workgroup of 1024 threads)
+__global__ __launch_bounds__(1024) void sn_sigma_kernel(const float* __restrict__ wv, float* __restrict__ u, float* __restrict__ sigma, int M, int do_iter, float eps) {
+    __shared__ float red[1024];
     const int tid = threadIdx.x;
     auto block_sum = [&](float x) {
         red[tid] = x;
@@ -214,35 +247,9 @@ __global__ __launch_bounds__(1024) void sn_power_iter_kernel(const float* __rest
         __syncthreads();
         return r;
     };
-    for (int i = tid; i < M; i += 1024) su[i] = u[i];
-    __syncthreads();
-    if (do_iter) {
-        // v = W^T u (thread per column), normalise
-        float nv = 0.f;
-        for (int j = tid; j < N; j += 1024) {
-            float s = 0.f;
-            for (int i = 0; i < M; ++i) s += W[(size_t)i * N + j] * su[i];
-            v[j] = s;
-            nv += s * s;
-        }
-        const float vn = fmaxf(sqrtf(block_sum(nv)), eps);
-        for (int j = tid; j < N; j += 1024) v[j] /= vn;
-        __syncthreads();
-    }
-    // Wv: a wave per row (lanes across the columns), then u = normalize(Wv), sigma = u . Wv
-    float* wv = su;     // su is not needed after v
-    __syncthreads();
-    for (int i = tid >> 6; i < M; i += 16) {
-        float s = 0.f;
-        for (int j = tid & 63; j < N; j += 64) s += W[(size_t)i * N + j] * v[j];
-        s = wave_sum(s);
-        if ((tid & 63) == 0) wv[i] = s;
-    }
-    __syncthreads();
     float nu = 0.f;
     for (int i = tid; i < M; i += 1024) nu += wv[i] * wv[i];
-    const float un2 = block_sum(nu);
-    const float un = fmaxf(sqrtf(un2), eps);
+    const float un = fmaxf(sqrtf(block_sum(nu)), eps);
     float dot = 0.f;
     for (int i = tid; i < M; i += 1024) {
         const float ui = do_iter ? wv[i] / un : u[i];
@@ -407,12 +414,21 @@ extern "C" int wm_gunpack_nchw_bwd(const float* g, void* gx, int B, int C, int H
     return WM_OK;
 }
 
-// u [M], v [N] updated in place when do_iter != 0 (training); sigma [1]; then Wsn = W / sigma
-extern "C" int wm_spectral_norm_fwd(const float* W, float* u, float* v, float* sigma, float* Wsn, int M, int N, int do_iter, void* stream) {
-    WM_REQUIRE(W && u && v && sigma && Wsn && M > 0 && N > 0, WM_E_BADARG, "wm_spectral_norm_fwd: bad arguments");
-    WM_REQUIRE(M <= 8192, WM_E_SHAPE, "wm_spectral_norm_fwd: M=%d too large for the one-workgroup power iteration", M);
+// u [M], v [N] updated in place when do_iter != 0 (training); sigma [1]; then Wsn = W / sigma.  scratch: wm_spectral_norm_scratch_floats(M, N)
+extern "C" size_t wm_spectral_norm_scratch_floats(int M, int N) { return (size_t)N + M + (size_t)((N + 255) / 256) + 8; }
+extern "C" int wm_spectral_norm_fwd(const float* W, float* u, float* v, float* sigma, float* Wsn, float* scratch, int M, int N, int do_iter, void* stream) {
+    WM_REQUIRE(W && u && v && sigma && Wsn && scratch && M > 0 && N > 0, WM_E_BADARG, "wm_spectral_norm_fwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sn_power_iter_kernel, dim3(1), dim3(1024), (size_t)(M + 1024) * sizeof(float), s, W, u, v, sigma, M, N, do_iter, 1e-12f);
+    float* vraw = scratch;
+    float* wv = scratch + N;
+    float* part = scratch + N + M;
+    const int nb = (N + 255) / 256;
+    if (do_iter) {
+        hipLaunchKernelGGL(sn_cols_kernel, dim3(nb), dim3(256), 0, s, W, u, vraw, part, M, N);
+        hipLaunchKernelGGL(sn_vnorm_kernel, dim3(1), dim3(256), 0, s, vraw, part, nb, v, N, 1e-12f);
+    }
+    hipLaunchKernelGGL(sn_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, W, v, wv, M, N);
+    hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(1024), 0, s, wv, u, sigma, M, do_iter, 1e-12f);
     WM_LAUNCH_CHECK("wm_spectral_norm_fwd(power iteration)");
     const size_t n = (size_t)M * N;
     hipLaunchKernelGGL(sn_apply_kernel, dim3(grid1(n)), dim3(256), 0, s, W, sigma, Wsn, n);

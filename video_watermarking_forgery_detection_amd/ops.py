@@ -1322,7 +1322,10 @@ def spectral_norm_fwd(w, u, v, do_iter):
     assert u.numel() == M and v.numel() == N and u.is_contiguous() and v.is_contiguous() and u.dtype == torch.float32 and v.dtype == torch.float32
     sigma = torch.empty(1, device=w.device, dtype=torch.float32)
     wsn = torch.empty_like(w)
-    rc = _lib.lib().wm_spectral_norm_fwd(_p(w), _p(u), _p(v), _p(sigma), _p(wsn), c_int(M), c_int(N), c_int(1 if do_iter else 0), _stream())
+    L = _lib.lib()
+    L.wm_spectral_norm_scratch_floats.restype = c_size_t
+    scratch = torch.empty(L.wm_spectral_norm_scratch_floats(c_int(M), c_int(N)), device=w.device, dtype=torch.float32)
+    rc = L.wm_spectral_norm_fwd(_p(w), _p(u), _p(v), _p(sigma), _p(wsn), _p(scratch), c_int(M), c_int(N), c_int(1 if do_iter else 0), _stream())
     _lib.check(rc, "wm_spectral_norm_fwd")
     return wsn, sigma
 
