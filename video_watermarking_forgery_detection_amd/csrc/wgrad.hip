@@ -357,9 +357,19 @@ static int launch_wgrad_reduce(float* ws, int nslabs, int CinP, int CoutP, float
     return WM_OK;
 }
 
+// wide layers run (input blocks x output blocks) workgroups per slab: fewer slabs fill the chip as well, and the slab traffic (9 x CinP x
+// CoutP floats each, written once and read once by the reduction) shrinks with them -- 151 MB per 128 x 128 layer at 256 slabs
+inline int nslabs_ch(int B, int H, int W, int CinX, int CoutY);
 inline int nslabs_for(int B, int H, int W) {
     const long n = (long)B * wm_cdiv(H, 16) * wm_cdiv(W, 16);
     return (int)(n < 256 ? n : 256);
+}
+
+inline int nslabs_ch(int B, int H, int W, int CinX, int CoutY) {
+    const int n = nslabs_for(B, H, W), cb = wm_cdiv(CinX, CB) * wm_cdiv(CoutY, CB);
+    if (cb <= 1) return n;
+    const int want = wm_cdiv(512, cb);
+    return n < want ? n : (want < 1 ? 1 : want);
 }
 
 template <typename T>
@@ -370,7 +380,7 @@ void launch_wgrad(const void* x, int ldx, int CinX, const float* in_scale, const
     a.dy = (const T*)dy; a.lddy = lddy; a.CoutY = CoutY; a.ws = ws; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, WCfg<T>::TH); a.ntiles = B * a.tilesX * a.tilesY;
     a.ciBlocks = wm_cdiv(CinX, CB); a.coBlocks = wm_cdiv(CoutY, CB);
-    dim3 grid((unsigned)nslabs_for(B, H, W), (unsigned)(a.ciBlocks * a.coBlocks)), block(256);
+    dim3 grid((unsigned)nslabs_ch(B, H, W, CinX, CoutY), (unsigned)(a.ciBlocks * a.coBlocks)), block(256);
     if (in_scale) hipLaunchKernelGGL((wgrad_kernel<T, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((wgrad_kernel<T, false>), grid, block, 0, s, a);
 }
@@ -459,13 +469,14 @@ extern "C" int wm_conv3x3_wgrad_fin(const void* x, int ldx, int CinX, const floa
     WM_REQUIRE(perm_dev || CinX >= Cin, WM_E_BADARG, "wm_conv3x3_wgrad: x has fewer channels than the weight");
     hipStream_t s = (hipStream_t)stream;
     static const bool v1 = WM_ENV_FLAG("WM_WGRAD_V1");  // diagnostic knob (debug build): single-role kernel
-    if (is16(dtype) && !v1) wm_launch_wgrad_ws(dtype, x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, nslabs_for(B, H, W), s, sweep_reverse ? 1 : 0);
+    const int nsl = nslabs_ch(B, H, W, CinX, CoutY);
+    if (is16(dtype) && !v1) wm_launch_wgrad_ws(dtype, x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, nsl, s, sweep_reverse ? 1 : 0);
     else if (dtype == WM_BF16) launch_wgrad<bf16_t>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
     else if (dtype == WM_F16) launch_wgrad<f16_t>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
     else launch_wgrad<float>(x, ldx, CinX, in_scale, in_shift, dy, lddy, CoutY, ws, B, H, W, s);
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad");
     const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
-    WM_REQUIRE(launch_wgrad_reduce(ws, nslabs_for(B, H, W), CinP, CoutP, dw, Cin, Cout, perm_dev, accumulate, fin, s) == WM_OK, WM_E_BADARG,
+    WM_REQUIRE(launch_wgrad_reduce(ws, nsl, CinP, CoutP, dw, Cin, Cout, perm_dev, accumulate, fin, s) == WM_OK, WM_E_BADARG,
                "wm_conv3x3_wgrad: bad finalisation rider");
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad(reduce)");
     return WM_OK;
