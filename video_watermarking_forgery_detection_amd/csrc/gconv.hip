@@ -361,16 +361,20 @@ __global__ __launch_bounds__(256) void gcolsum_kernel(const T* __restrict__ x, s
         part[(size_t)blockIdx.y * C + blockIdx.x * 64 + threadIdx.x] = t;
     }
 }
+// out[c] (+)= sum over the splits: 64 channels x 4 split lanes per workgroup, fixed order
 __global__ __launch_bounds__(256) void gcolsum_reduce_kernel(const float* __restrict__ part, int nsplit, int C, float* __restrict__ out, int Creal, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= Creal) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * C + c];
-    out[c] = (accumulate ? out[c] : 0.f) + s;
+    if (c < Creal)
+        for (int k = sub; k < nsplit; k += 4) s += part[(size_t)k * C + c];
+    __shared__ float sh[4][64];
+    sh[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && c < Creal) out[c] = (accumulate ? out[c] : 0.f) + ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]));
 }
 inline int colsum_nsplit(size_t npix) {
     const size_t n = (npix + 1023) / 1024;
-    return (int)(n < 1 ? 1 : (n > 64 ? 64 : n));
+    return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
 }
 
 inline int grid1(size_t n, int cap = 4096) {
@@ -480,7 +484,7 @@ extern "C" int wm_gconv_wgrad(const void* dout, const void* in, float* partial, 
         const int ns = colsum_nsplit(npix);
         WM_DISPATCH_DTYPE(dtype, "wm_gconv_wgrad(bias)",
             hipLaunchKernelGGL(gcolsum_kernel<T>, dim3((unsigned)((NC + 63) / 64), (unsigned)ns), dim3(256), 0, s, (const T*)dout, npix, NC, partial));
-        hipLaunchKernelGGL(gcolsum_reduce_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, s, partial, ns, NC, dbias, Cout, accumulate);
+        hipLaunchKernelGGL(gcolsum_reduce_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(256), 0, s, partial, ns, NC, dbias, Cout, accumulate);
         WM_LAUNCH_CHECK("wm_gconv_wgrad(bias)");
     }
     return WM_OK;
@@ -494,7 +498,7 @@ extern "C" int wm_gcolsum(const void* x, size_t npix, int C, float* out, int Cre
     const int ns = colsum_nsplit(npix);
     WM_DISPATCH_DTYPE(dtype, "wm_gcolsum",
         hipLaunchKernelGGL(gcolsum_kernel<T>, dim3((unsigned)((C + 63) / 64), (unsigned)ns), dim3(256), 0, s, (const T*)x, npix, C, scratch));
-    hipLaunchKernelGGL(gcolsum_reduce_kernel, dim3((unsigned)((Creal + 255) / 256)), dim3(256), 0, s, scratch, ns, C, out, Creal, accumulate);
+    hipLaunchKernelGGL(gcolsum_reduce_kernel, dim3((unsigned)((Creal + 63) / 64)), dim3(256), 0, s, scratch, ns, C, out, Creal, accumulate);
     WM_LAUNCH_CHECK("wm_gcolsum");
     return WM_OK;
 }
