@@ -1,3 +1,6 @@
+"""Debugging aid for csrc/bwd_ws.hip: the one-kernel backward against the two-kernel form on small ragged shapes -- where the two differ,
+which side is off against an f64 evaluation, and (with an identity filter, so that dx == dy) the staged dy itself.
+usage: python tools/dbg_bwd.py   (on the GPU box)"""
 import sys, torch
 sys.path.insert(0, "."); sys.path.insert(0, "tests"); sys.path.insert(0, "tests/golden")
 import detgen
