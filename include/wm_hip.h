@@ -234,6 +234,7 @@ int wm_conv3x3_dgrad_applyfused(const void* g, const void* y, const float* stats
  * formed from y alone, as in wm_conv3x3_dgrad_gvfused).  nwg = wm_conv3x3_bwd_fused_nwg(B,H,W).
  * wm_conv3x3_bwd_fused_reduce: dw [Cout][Cin][3][3] (+)= the sum of the slabs (wm_conv3x3_wgrad_fin's reduction, incl. `fin`). */
 int wm_conv3x3_bwd_fused_supported(int dtype);
+int wm_conv3x3_bwd_fused_supported_shape(int B, int H, int W, int dtype);   /* ... and B*H*W*64 < 2^31 (32-bit element offsets) */
 int wm_conv3x3_bwd_fused_nwg(int B, int H, int W);
 int wm_conv3x3_bwd_fused_gvec_max_batch(void);
 int wm_conv3x3_bwd_fused(const void* g, const float* gvec, const void* y, const float* stats4, const float* coef, const void* wpt,

@@ -495,6 +495,11 @@ WM_KNOB_SETTER(wm_debug_bwd_fuse, g_bwdfuse)   // A/B knob (tools/ab_step.py, de
 WM_KNOB_INT(g_bwd_dbg, "WM_BWD_DBG", 0);
 WM_KNOB_SETTER(wm_debug_bwd_variant, g_bwd_dbg)   // phase ablations of bwd_ws.hip (debug build only; results are then meaningless)
 extern "C" int wm_conv3x3_bwd_fused_supported(int dtype) { return (g_bwdfuse && is16(dtype)) ? 1 : 0; }
+// ... and the tensor fits the kernel's 32-bit element offsets / 24-bit row and column counts
+extern "C" int wm_conv3x3_bwd_fused_supported_shape(int B, int H, int W, int dtype) {
+    return (wm_conv3x3_bwd_fused_supported(dtype) && B > 0 && H > 0 && W > 0 && (long long)B * H * W * 64 < (1LL << 31) && (long long)B * H < (1 << 23) &&
+            W < (1 << 23)) ? 1 : 0;
+}
 extern "C" int wm_conv3x3_bwd_fused_nwg(int B, int H, int W) {
     const long n = (long)B * wm_cdiv(H, 8) * wm_cdiv(W, 16);
     return (int)(n < 256 ? n : 256);

@@ -201,7 +201,7 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
             and x.t.shape[-1] == 64 and ctx.stats.is_contiguous() and ops.conv3x3_gvfused_supported(64, y.shape[-1], dtype)):
         coef = coef_of()
         wpt = _packed(conv, y.shape[-1], rows, dtype, None, True)
-        if (feed_stats and y.shape[-1] == 64 and ops.conv3x3_bwd_fused_supported(dtype) and gvec.shape[-1] == 64
+        if (feed_stats and y.shape[-1] == 64 and ops.conv3x3_bwd_fused_supported(dtype, y.shape) and gvec.shape[-1] == 64
                 and y.shape[0] <= ops.conv3x3_bwd_fused_gvec_max_batch()):
             # one kernel for both gradients (csrc/bwd_ws.hip, gvec form): y and the feeding layer's raw output are read once
             gx, part, pcoef = ops.conv3x3_bwd_fused(None, y, ctx.stats, coef, wpt, x.t, x.scale, x.shift, grads[conv.weight], accumulate,
@@ -223,7 +223,7 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
             and ops.conv3x3_dgrad_applyfused_supported(64, rows, dtype)):
         coef = coef_of()
         wpt = _packed(conv, 64, rows, dtype, None, True)
-        if feed_stats and rows == 64 and ops.conv3x3_bwd_fused_supported(dtype):
+        if feed_stats and rows == 64 and ops.conv3x3_bwd_fused_supported(dtype, y.shape):
             # one kernel: dy is formed in the LDS and feeds BOTH gradients; the feeding layer's raw output is read once (csrc/bwd_ws.hip)
             # (g itself may come from such a kernel, which writes its gradient already multiplied by this layer's ReLU mask: the staging
             # then skips the mask arithmetic -- trusted only for exactly that tensor, unmodified: the check in coef_of())

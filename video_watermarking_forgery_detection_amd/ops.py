@@ -487,8 +487,11 @@ def conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry=None, r_scale=None, r_sh
     return dy, dx, part
 
 
-def conv3x3_bwd_fused_supported(dtype):
-    return bool(_lib.lib().wm_conv3x3_bwd_fused_supported(c_int(dt_id(dtype))))
+def conv3x3_bwd_fused_supported(dtype, shape=None):
+    """the one-kernel backward exists for this dtype (and, given y's shape [B,H,W,64], the tensor fits its 32-bit offsets)"""
+    if shape is None:
+        return bool(_lib.lib().wm_conv3x3_bwd_fused_supported(c_int(dt_id(dtype))))
+    return bool(_lib.lib().wm_conv3x3_bwd_fused_supported_shape(c_int(shape[0]), c_int(shape[1]), c_int(shape[2]), c_int(dt_id(dtype))))
 
 
 def conv3x3_bwd_fused_gvec_max_batch():
