@@ -566,6 +566,7 @@ void WM_HSYM(wm_launch_bwd_ws)(const void* g, const void* y, const float* stats4
     a.B = B; a.H = H; a.W = W; a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
     a.reverse = wm_sweep_dir(reverse);
 #ifdef WM_DEBUG
+    if (!gvec)   // (the ablation variants exist for the tensor-gradient form only; a gvec launch has no g to read)
     switch (dbg) {
         case 1: hipLaunchKernelGGL((bwd_ws_kernel<1, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         case 2: hipLaunchKernelGGL((bwd_ws_kernel<2, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
