@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                 s2[2 * j] = __builtin_fmaf(gz0, y0, s2[2 * j]);
                 s2[2 * j + 1] = __builtin_fmaf(gz1, y1, s2[2 * j + 1]);
             }
-            if (inb[ml]) {
+            if (inb[ml] && !(DBG & 512)) {   // DBG 512: no dx stores
                 *reinterpret_cast<u32x4*>(outp[ml]) = u32x4{pk[0], pk[1], pk[2], pk[3]};
                 *reinterpret_cast<u32x4*>(outp[ml] + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
             }
@@ -578,6 +578,7 @@ void WM_HSYM(wm_launch_bwd_ws)(const void* g, const void* y, const float* stats4
         case 32: hipLaunchKernelGGL((bwd_ws_kernel<32, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         case 64: hipLaunchKernelGGL((bwd_ws_kernel<64, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         case 96: hipLaunchKernelGGL((bwd_ws_kernel<96, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 512: hipLaunchKernelGGL((bwd_ws_kernel<512, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         case 256: hipLaunchKernelGGL((bwd_ws_kernel<256, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         case 128: hipLaunchKernelGGL((bwd_ws_kernel<128, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         case 16: hipLaunchKernelGGL((bwd_ws_kernel<16, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
