@@ -56,6 +56,7 @@ struct BwdArgs {
     float* stat;                                           // [gridDim.x][2][64]
     float* ws;                                             // [gridDim.x][9][64][64]
     int B, H, W, tilesX, tilesY, ntiles, reverse;
+    unsigned mX, mY, m2X;                                  // ceil(2^32 / d) of tilesX, tilesY, 2 tilesX (0 for d = 1): tile index / d = mulhi
 };
 
 __device__ __forceinline__ int fsw(int px) { return ((px >> 2) & 1) | (((px >> 1) & 1) << 1) | (((px >> 3) & 1) << 2); }
@@ -73,7 +74,8 @@ __device__ __forceinline__ hx8 tr_frag(const char* p0, const char* p1) {
 
 // DBG (debug build only, tools/ab_step.py wm_debug_bwd_variant): phase ablations -- 1 skip the input-gradient MFMAs, 2 the weight-gradient
 // MFMAs, 4 the epilogue, 8 the staging of the next tile, 16 stage the same tile again and again (results are then meaningless; compile-
-// time so the real kernel is untouched)
+// time so the real kernel is untouched), 512 no dx stores, 1024 / 2048 half the filter / dy fragment reads of the input- / weight-gradient loop,
+// 4096 phase stamps (with 512: the sums land where dx would)
 // PREMASKED: g arrives already multiplied by its layer's ReLU mask (this kernel's own dx is written that way, see the epilogue), so the
 // staging's compare + select + the z fma disappear; masking twice is the identity, so results do not depend on the flag
 // GVEC: the layer's output was globally pooled, so its gradient is one value per (sample, channel): the staging reads y only and takes
@@ -114,17 +116,20 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
     // tile order: pairs of tile rows walked column by column (upper tile, lower tile, next column ...), so the two halo rows a tile
     // shares with the one below it and the two halo columns it shares with its right neighbour are re-read within 1 and 2 tiles -- from
     // this XCD's L2, not from the Infinity Cache 16 tiles later (tilesY odd: plain row-major order)
+    // (the divisions are mulhi by the host's ceil(2^32 / d): exact while tile * d < 2^32, and 3 scalar instructions instead of ~40 --
+    // one wave per SIMD pays the issue slot of every instruction, scalar ones included)
+    auto fdiv = [](int t, int d, unsigned m) { return d == 1 ? t : (int)__umulhi((unsigned)t, m); };
     auto geo = [&](int tile) {
         TileGeo g;
         int t = a.reverse ? t_begin + (t_end - 1 - tile) : tile;
         if (a.tilesY & 1) {
-            const int txi = t % a.tilesX; t /= a.tilesX;
-            const int tyi = t % a.tilesY; t /= a.tilesY;
-            g.b = t; g.ty0 = tyi * TH; g.tx0 = txi * TW;
+            const int q1 = fdiv(t, a.tilesX, a.mX), txi = t - q1 * a.tilesX;
+            const int q2 = fdiv(q1, a.tilesY, a.mY), tyi = q1 - q2 * a.tilesY;
+            g.b = q2; g.ty0 = tyi * TH; g.tx0 = txi * TW;
         } else {
-            const int rem = t % (2 * a.tilesX), pr = t / (2 * a.tilesX);     // pr: pair of tile rows, over all images
+            const int pr = fdiv(t, 2 * a.tilesX, a.m2X), rem = t - pr * 2 * a.tilesX;     // pr: pair of tile rows, over all images
             const int row = 2 * pr + (rem & 1);
-            g.b = row / a.tilesY; g.ty0 = (row - g.b * a.tilesY) * TH; g.tx0 = (rem >> 1) * TW;
+            g.b = fdiv(row, a.tilesY, a.mY); g.ty0 = (row - g.b * a.tilesY) * TH; g.tx0 = (rem >> 1) * TW;
         }
         return g;
     };
@@ -303,10 +308,12 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         pkb = *reinterpret_cast<const f32x4*>(kp + 8); pkb2 = *reinterpret_cast<const f32x4*>(kp + 12);
     };
     // half-step h of the input-gradient loop (36 of them, 4 MFMAs each) carries the units [hs_first(h), hs_first(h) + hs_count(h)): a channel
-    // pair's 5 transform units together in the first of 4 half-steps (ten independent dependency chains side by side), a group's 5 publish units 3-2 over the next two; the pair's constants are
-    // requested at the top of its first half-step, AHEAD of that half-step's fragment reads in the in-order LDS queue
-    auto hs_first = [](int h) { const int g = h / 18, r = h - 18 * g; return 25 * g + (r < 16 ? (r / 4) * 5 + ((r & 3) ? 5 : 0) : 20 + (r == 16 ? 0 : 3)); };
-    auto hs_count = [](int h) { const int r = h % 18; return r < 16 ? ((r & 3) ? 0 : 5) : (r == 16 ? 3 : 2); };
+    // pair owns 4 half-steps -- its constants are requested at the top of the first (no unit there: the read has 4 MFMAs to arrive), its 5
+    // transform units run 2-2-1 in the other three --, a group's 5 publish units 3-2 in the last two.  ONE wave per SIMD issues in order:
+    // a unit's VALU instructions hide behind the MFMAs only when they sit BETWEEN them (the matrix pipe is busy 16 cycles per MFMA, the
+    // issue port 4), hence the sched_group_barrier pipelines in the loop (tools/phase_bwd.py: 6.8k -> cycles per tile for this loop)
+    auto hs_first = [](int h) { const int g = h / 18, r = h - 18 * g, m = r & 3; return 25 * g + (r < 16 ? (r / 4) * 5 + (m == 0 ? 0 : m == 1 ? 0 : m == 2 ? 2 : 4) : 20 + (r == 16 ? 0 : 3)); };
+    auto hs_count = [](int h) { const int r = h % 18, m = r & 3; return r < 16 ? (m == 0 ? 0 : m == 3 ? 1 : 2) : (r == 16 ? 3 : 2); };
     auto pub_unit = [&](int u, unsigned char* buf, bool refill, const TileGeo& g2) {
         const int grp = u / 25, v = u - grp * 25;
         const int j = v < 20 ? v % 5 : v - 20;
@@ -364,7 +371,12 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
 
     // one tile; STAGE: tile + 1 exists (its operands are in the registers: publish them); REFILL: tile + 2 exists (request it).  Compile-
     // time, so the body is straight-line code the scheduler can interleave; the last two tiles of a run use the reduced bodies
+    // DBG 4096: s_memtime stamps at the phase boundaries, summed per workgroup and written over the start of dx (tools/phase_bwd.py)
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, t_run0 = 0, r_run0 = 0;
+    if constexpr ((DBG & 4096) != 0) { t_run0 = __builtin_amdgcn_s_memtime(); r_run0 = __builtin_amdgcn_s_memrealtime(); }
     auto tile_body = [&](int tile, auto stage_c, auto refill_c) {
+        unsigned long long ts[7];
+        if constexpr ((DBG & 4096) != 0) ts[0] = __builtin_amdgcn_s_memtime();
         constexpr bool stage = decltype(stage_c)::value && !(DBG & 8);
         constexpr bool refill = decltype(refill_c)::value && !(DBG & 8);
         const TileGeo g = geo(tile);
@@ -387,31 +399,38 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
             ryv[ml][4] = t1[0]; ryv[ml][5] = t1[1]; ryv[ml][6] = t1[2]; ryv[ml][7] = t1[3];
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((DBG & 4096) != 0) { ts[1] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         // ---------------- weight gradient: 4 K-steps x 9 taps x (2 x 2 fragments); the dy fragments of the next tap are requested while
         // this tap's four MFMAs run (fenced: an unfenced schedule hoists dozens of fragment reads and spills)
         if constexpr (!(DBG & 2)) {
             const char* curc = reinterpret_cast<const char*>(cur);
-            hx8 afrag[2][2], bfrag[2];
+            // one wave per SIMD has nobody to hide its LDS latency behind: the dy fragments are requested WR - 1 taps ahead (a ring of WR),
+            // the a fragments of the next K-step half a K-step ahead
+            constexpr int WR = 4;
+            hx8 afrag[WR][2], bfrag[2][2];
             auto load_a = [&](int st, int buf) {   // st = ks * 9 + tap
                 const int ks = st / 9, tap = st - ks * 9, kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
                 for (int fi = 0; fi < 2; ++fi)
                     afrag[buf][fi] = tr_frag(curc + (2 * ks + kh) * (HW * 128) + xo[kw][0][fi], curc + (2 * ks + kh) * (HW * 128) + xo[kw][1][fi]);
             };
-            load_a(0, 0);
+            auto load_b = [&](int ks, int buf) {
+#pragma unroll
+                for (int fj = 0; fj < 2; ++fj) bfrag[buf][fj] = tr_frag(curc + 2 * ks * TW * 128 + dof[0][fj], curc + 2 * ks * TW * 128 + dof[1][fj]);
+            };
+            load_b(0, 0);
+#pragma unroll
+            for (int i = 0; i < WR - 1; ++i) load_a(i, i);
 #pragma unroll
             for (int st = 0; st < 36; ++st) {
-                const int ks = st / 9, tap = st - ks * 9, cb = st & 1;
-                if (tap == 0) {
-#pragma unroll
-                    for (int fj = 0; fj < 2; ++fj) bfrag[fj] = tr_frag(curc + 2 * ks * TW * 128 + dof[0][fj], curc + 2 * ks * TW * 128 + dof[1][fj]);
-                }
-                if (st + 1 < 36) load_a(st + 1, cb ^ 1);
+                const int ks = st / 9, tap = st - ks * 9;
+                if (st + WR - 1 < 36 && !((DBG & 2048) && ((st + WR - 1) & 1))) load_a(st + WR - 1, (st + WR - 1) % WR);   // DBG 2048: half the dy fragment reads
+                if (tap == 4 && ks + 1 < TH / 2) load_b(ks + 1, (ks + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
-                    for (int fj = 0; fj < 2; ++fj) wacc[tap][fi][fj] = HX::mfma16(afrag[cb][fi], bfrag[fj], wacc[tap][fi][fj]);
+                    for (int fj = 0; fj < 2; ++fj) wacc[tap][fi][fj] = HX::mfma16(afrag[st % WR][fi], bfrag[ks & 1][fj], wacc[tap][fi][fj]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -419,8 +438,10 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         // gfx9 counts loads and stores in ONE counter and only loads return in order: with the previous tile's dx stores possibly pending,
         // every wait on a staged slot would become vmcnt(0) -- also for the slots just re-requested.  So ONE full wait here, where it is
         // free (everything outstanding was issued at least a weight-gradient phase ago and is needed now), and none after the refills
+        if constexpr ((DBG & 4096) != 0) { ts[2] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((DBG & 4096) != 0) { ts[3] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         // ---------------- input gradient: 18 K-steps x (2 pixel + 4 filter fragments, 8 MFMAs), the next tile's staging in their shadow
         f32x4 acc[2][4];
 #pragma unroll
@@ -428,9 +449,9 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) acc[ml][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (!(DBG & 1)) {
-            // fragment schedule: the pixel fragments one K-step ahead; the filter fragments in two halves (channel fragments 0-1 / 2-3),
-            // each requested while the other half's four MFMAs run -- 32 registers of operands instead of 48
-            hx8 pix[2][2], filA[2], filB[2];
+            // fragment schedule: every fragment of K-step sidx + 1 is requested at the top of K-step sidx (8 MFMAs + the staging units ahead
+            // of its use: one wave per SIMD has to cover the LDS latency itself); 48 registers of operands
+            hx8 pix[2][2], filA[2][2], filB[2][2];
             auto load_pix = [&](int sidx, int buf) {
                 const int tap = sidx >> 1, ks = sidx & 1;
                 const int kh = tap / 3, kw = tap - kh * 3;
@@ -444,34 +465,45 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                 for (int n = 0; n < 2; ++n)
                     f[n] = *reinterpret_cast<const hx8*>(reinterpret_cast<const char*>(sW) + boff[ks] + (tap * C + (2 * half + n) * 16) * (C * 2));
             };
+            // the region's schedule: MFMA, up to IV VALU instructions, MFMA, ... (whatever is left follows the fourth group)
+            auto interleave4 = [] {
+                constexpr int IV = (DBG & 8192) ? 3 : 5;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, IV, 0); }
+            };
             load_pix(0, 0);
-            load_fil(0, 0, filA);
+            load_fil(0, 0, filA[0]);
+            load_fil(0, 1, filB[0]);
 #pragma unroll
             for (int sidx = 0; sidx < 18; ++sidx) {
                 const int cb = sidx & 1;
                 constexpr bool inter = stage && !(DBG & 128);
                 if constexpr (inter) { if ((2 * sidx) % 18 < 16 && ((2 * sidx) % 18) % 4 == 0) pub_consts(((2 * sidx) % 18) / 4); }
-                load_fil(sidx, 1, filB);
+                if (sidx + 1 < 18) {
+                    load_pix(sidx + 1, cb ^ 1);
+                    if (!((DBG & 1024) && (sidx & 1))) { load_fil(sidx + 1, 0, filA[cb ^ 1]); load_fil(sidx + 1, 1, filB[cb ^ 1]); }   // DBG 1024: half the filter fragment reads
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[ml][n] = HX::mfma16(filA[n], pix[cb][ml], acc[ml][n]);
+                    for (int n = 0; n < 2; ++n) acc[ml][n] = HX::mfma16(filA[cb][n], pix[cb][ml], acc[ml][n]);
                 if constexpr (inter) {
 #pragma unroll
                     for (int u = hs_first(2 * sidx); u < hs_first(2 * sidx) + hs_count(2 * sidx); ++u) pub_unit(u, nxt, refill, g2);
+                    interleave4();
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (inter) { if ((2 * sidx + 1) % 18 < 16 && ((2 * sidx + 1) % 18) % 4 == 0) pub_consts(((2 * sidx + 1) % 18) / 4); }
-                if (sidx + 1 < 18) { load_pix(sidx + 1, cb ^ 1); load_fil(sidx + 1, 0, filA); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[ml][2 + n] = HX::mfma16(filB[n], pix[cb][ml], acc[ml][2 + n]);
+                    for (int n = 0; n < 2; ++n) acc[ml][2 + n] = HX::mfma16(filB[cb][n], pix[cb][ml], acc[ml][2 + n]);
                 if constexpr (inter) {
 #pragma unroll
                     for (int u = hs_first(2 * sidx + 1); u < hs_first(2 * sidx + 1) + hs_count(2 * sidx + 1); ++u) pub_unit(u, nxt, refill, g2);
+                    interleave4();
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -483,33 +515,45 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
 #pragma unroll
             for (int u = 0; u < NUNIT; ++u) { if (u % 25 < 20 && u % 5 == 0) pub_consts((u % 25) / 5); pub_unit(u, nxt, refill, g2); }
         }
+        if constexpr ((DBG & 4096) != 0) { __builtin_amdgcn_sched_barrier(0); ts[4] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         // ---------------- input-gradient epilogue: layer L-1's BatchNorm-backward sums (gz = dx * [z > 0], dx rounded as stored), pack, store
+        // (one wave per SIMD pays an issue slot for every instruction: lanes outside the image skip the lot under exec, the masked dx is
+        // built by two selects per pair and the sums take THEIR operands from it -- 17 VALU instructions per channel pair)
         if constexpr (!(DBG & 4))
 #pragma unroll
         for (int ml = 0; ml < 2; ++ml) {
+            if (!inb[ml]) continue;
             unsigned pk[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int nf = j >> 1, i0 = 2 * (j & 1);
-                const hx2 p2v = {(hx_t)acc[ml][nf][i0], (hx_t)acc[ml][nf][i0 + 1]};
-                pk[j] = __builtin_bit_cast(unsigned, p2v);
-                const unsigned gm = inb[ml] ? pk[j] : 0u;
-                const float g0 = HX::lo(gm), g1 = HX::hi(gm);
-                const float y0 = HX::lo(ryv[ml][j]), y1 = HX::hi(ryv[ml][j]);
-                const f32x2 rs = *reinterpret_cast<const f32x2*>(sTab + 16 * q + 2 * j), rh = *reinterpret_cast<const f32x2*>(sTab + C + 16 * q + 2 * j);
-                const float z0 = __builtin_fmaf(rs[0], y0, rh[0]), z1 = __builtin_fmaf(rs[1], y1, rh[1]);
-                const float gz0 = z0 > 0.f ? g0 : 0.f, gz1 = z1 > 0.f ? g1 : 0.f;
-                pk[j] = (z0 > 0.f ? pk[j] & 0xffffu : 0u) | (z1 > 0.f ? pk[j] & 0xffff0000u : 0u);   // dx leaves masked: gz, not g
-                s1[2 * j] += gz0; s1[2 * j + 1] += gz1;
-                s2[2 * j] = __builtin_fmaf(gz0, y0, s2[2 * j]);
-                s2[2 * j + 1] = __builtin_fmaf(gz1, y1, s2[2 * j + 1]);
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x4 rs = *reinterpret_cast<const f32x4*>(sTab + 16 * q + 4 * jj), rh = *reinterpret_cast<const f32x4*>(sTab + C + 16 * q + 4 * jj);
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    const int j = 2 * jj + jh, nf = j >> 1, i0 = 2 * (j & 1);
+                    const hx2 p2v = {(hx_t)acc[ml][nf][i0], (hx_t)acc[ml][nf][i0 + 1]};
+                    const unsigned raw = __builtin_bit_cast(unsigned, p2v);
+                    const float y0 = HX::lo(ryv[ml][j]), y1 = HX::hi(ryv[ml][j]);
+                    const float z0 = __builtin_fmaf(rs[2 * jh], y0, rh[2 * jh]), z1 = __builtin_fmaf(rs[2 * jh + 1], y1, rh[2 * jh + 1]);
+                    const unsigned t = z0 > 0.f ? raw : (raw & 0xffff0000u);
+                    pk[j] = z1 > 0.f ? t : (t & 0xffffu);   // dx leaves masked: gz, not g
+                    const float gz0 = HX::lo(pk[j]), gz1 = HX::hi(pk[j]);
+                    s1[2 * j] += gz0; s1[2 * j + 1] += gz1;
+                    s2[2 * j] = __builtin_fmaf(gz0, y0, s2[2 * j]);
+                    s2[2 * j + 1] = __builtin_fmaf(gz1, y1, s2[2 * j + 1]);
+                }
             }
-            if (inb[ml] && !(DBG & 512)) {   // DBG 512: no dx stores
+            if constexpr (!(DBG & 512)) {   // DBG 512: no dx stores
                 *reinterpret_cast<u32x4*>(outp[ml]) = u32x4{pk[0], pk[1], pk[2], pk[3]};
                 *reinterpret_cast<u32x4*>(outp[ml] + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
             }
         }
+        if constexpr ((DBG & 4096) != 0) { __builtin_amdgcn_sched_barrier(0); ts[5] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         __syncthreads();
+        if constexpr ((DBG & 4096) != 0) {
+            ts[6] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ph[i] += ts[i + 1] - ts[i];
+        }
     };
     {
         typedef std::integral_constant<bool, true> yes;
@@ -520,6 +564,15 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         if (tile < t_end) tile_body(tile, no{}, no{});
     }
 
+    if constexpr ((DBG & 4096) != 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(a.dx) + (size_t)blockIdx.x * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o[i] = ph[i];
+            o[6] = t1 - t_run0; o[7] = r1 - r_run0;
+        }
+    }
     // ---- weight-gradient slab: wacc[tap][fi][fj][i] = sum_q dy[q + (kh-1, kw-1)][co] * a[q][ci], co = 32mi + 16fi + 4kq + i,
     // ci = 32ni + 16fj + r: that is dW of filter tap 8 - tap; slab layout [tap][ci][co] (wgrad.hip's reduction)
     float* slab = a.ws + (size_t)blockIdx.x * 9 * C * C;
@@ -564,6 +617,8 @@ void WM_HSYM(wm_launch_bwd_ws)(const void* g, const void* y, const float* stats4
     a.gvec = gvec; a.gv_ld = gv_ld;
     a.xr = (const hx_t*)xr; a.in_scale = in_scale; a.in_shift = in_shift; a.dx = (hx_t*)dx; a.stat = stat; a.ws = ws;
     a.B = B; a.H = H; a.W = W; a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
+    auto magic = [](int d) { return d == 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
+    a.mX = magic(a.tilesX); a.mY = magic(a.tilesY); a.m2X = magic(2 * a.tilesX);
     a.reverse = wm_sweep_dir(reverse);
 #ifdef WM_DEBUG
     if (!gvec)   // (the ablation variants exist for the tensor-gradient form only; a gvec launch has no g to read)
@@ -573,15 +628,17 @@ void WM_HSYM(wm_launch_bwd_ws)(const void* g, const void* y, const float* stats4
         case 3: hipLaunchKernelGGL((bwd_ws_kernel<3, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         case 4: hipLaunchKernelGGL((bwd_ws_kernel<4, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         case 8: hipLaunchKernelGGL((bwd_ws_kernel<8, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 7: hipLaunchKernelGGL((bwd_ws_kernel<7, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 12: hipLaunchKernelGGL((bwd_ws_kernel<12, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         case 32: hipLaunchKernelGGL((bwd_ws_kernel<32, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         case 64: hipLaunchKernelGGL((bwd_ws_kernel<64, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 96: hipLaunchKernelGGL((bwd_ws_kernel<96, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         case 512: hipLaunchKernelGGL((bwd_ws_kernel<512, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 256: hipLaunchKernelGGL((bwd_ws_kernel<256, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 128: hipLaunchKernelGGL((bwd_ws_kernel<128, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
-        case 16: hipLaunchKernelGGL((bwd_ws_kernel<16, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 1024: hipLaunchKernelGGL((bwd_ws_kernel<1024, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 2048: hipLaunchKernelGGL((bwd_ws_kernel<2048, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 3072: hipLaunchKernelGGL((bwd_ws_kernel<3072, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 4608: hipLaunchKernelGGL((bwd_ws_kernel<4608, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 4616: hipLaunchKernelGGL((bwd_ws_kernel<4616, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 4640: hipLaunchKernelGGL((bwd_ws_kernel<4640, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 4672: hipLaunchKernelGGL((bwd_ws_kernel<4672, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 4864: hipLaunchKernelGGL((bwd_ws_kernel<4864, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         case 15: hipLaunchKernelGGL((bwd_ws_kernel<15, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         default: break;
     }

@@ -497,8 +497,12 @@ WM_KNOB_SETTER(wm_debug_bwd_variant, g_bwd_dbg)   // phase ablations of bwd_ws.h
 extern "C" int wm_conv3x3_bwd_fused_supported(int dtype) { return (g_bwdfuse && is16(dtype)) ? 1 : 0; }
 // ... and the tensor fits the kernel's 32-bit element offsets / 24-bit row and column counts
 extern "C" int wm_conv3x3_bwd_fused_supported_shape(int B, int H, int W, int dtype) {
-    return (wm_conv3x3_bwd_fused_supported(dtype) && B > 0 && H > 0 && W > 0 && (long long)B * H * W * 64 < (1LL << 31) && (long long)B * H < (1 << 23) &&
-            W < (1 << 23)) ? 1 : 0;
+    if (!(wm_conv3x3_bwd_fused_supported(dtype) && B > 0 && H > 0 && W > 0 && (long long)B * H * W * 64 < (1LL << 31) && (long long)B * H < (1 << 23) &&
+          W < (1 << 23)))
+        return 0;
+    // the tile index is divided by mulhi with ceil(2^32 / d): exact while index * d < 2^32
+    const long long tx = wm_cdiv(W, 16), ty = wm_cdiv(H, 8);
+    return ((long long)B * tx * ty * 2 * tx < (1LL << 32) && (long long)B * ty * ty < (1LL << 32)) ? 1 : 0;
 }
 extern "C" int wm_conv3x3_bwd_fused_nwg(int B, int H, int W) {
     const long n = (long)B * wm_cdiv(H, 8) * wm_cdiv(W, 16);
