@@ -54,6 +54,7 @@ GEOS = [  # (Cin, Cout, k, stride, pad, H, W)   -- every geometry of the three n
     (3, 32, 4, 2, 1, 32, 32), (32, 32, 3, 1, 1, 16, 16), (64, 128, 4, 2, 1, 16, 16), (512, 1, 1, 1, 0, 2, 2),
     (3, 16, 3, 1, 1, 20, 24), (16, 32, 2, 2, 0, 20, 24), (48, 48, 3, 1, 1, 5, 6), (3, 3, 5, 1, 0, 36, 36),
     (48, 192, 2, 2, 0, 8, 8), (192, 192, 3, 1, 1, 4, 4), (5, 7, 5, 2, 2, 13, 11), (20, 40, 3, 2, 1, 9, 9), (1, 512, 1, 1, 0, 1, 1),
+    (3, 16, 5, 1, 2, 6, 150), (3, 32, 4, 2, 1, 8, 260), (64, 32, 4, 2, 1, 6, 10),   # rows wider than a 64-pixel chunk (thin-layer weight gradient)
 ]
 
 

@@ -71,10 +71,22 @@ __global__ __launch_bounds__(256) void gconv_kernel(GArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 15, q = lane >> 4;
     const size_t npix = (size_t)a.B * a.OH * a.OW;
-    const size_t pix = ((size_t)blockIdx.x * 4 + wave) * 16 + p;
-    const bool pok = pix < npix;
-    const size_t pc = pok ? pix : npix - 1;
-    const int ox = (int)(pc % a.OW), oy = (int)((pc / a.OW) % a.OH), b = (int)(pc / ((size_t)a.OW * a.OH));
+    const size_t lin = ((size_t)blockIdx.x * 4 + wave) * 16 + p;
+    const bool pok = lin < npix;
+    const size_t pc = pok ? lin : npix - 1;
+    int ox, oy, b;
+    if (a.dgrad && a.stride == 2 && !((a.OH | a.OW) & 1)) {
+        // stride-2 input gradient: an output pixel's parity class (oy & 1, ox & 1) decides which taps reach it (4 of 16 for a 4x4 filter,
+        // 1 of 4 for 2x2).  Pixels are walked class by class, so a wave's 16 pixels share the class and the other taps are skipped whole
+        const int hw = a.OW >> 1, hh = a.OH >> 1;
+        const size_t per = npix >> 2, cls = pc / per, idx = pc - cls * per;
+        const int j = (int)(idx % hw), i = (int)((idx / hw) % hh);
+        b = (int)(idx / ((size_t)hw * hh));
+        oy = 2 * i + (int)(cls >> 1); ox = 2 * j + (int)(cls & 1);
+    } else {
+        ox = (int)(pc % a.OW); oy = (int)((pc / a.OW) % a.OH); b = (int)(pc / ((size_t)a.OW * a.OH));
+    }
+    const size_t pix = ((size_t)b * a.OH + oy) * a.OW + ox;
     const int n0 = blockIdx.y * 64;
     const T* in = (const T*)a.in;
     const T* w = (const T*)a.w;
@@ -94,6 +106,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GArgs a) {
         const int ky = tap / a.KW, kx = tap - ky * a.KW;
         int sy = 0, sx = 0;
         const bool ok = src_of(a, oy, ox, ky, kx, sy, sx) && pok;
+        if (__ballot(ok) == 0) continue;   // no lane of the wave has a source pixel under this tap (wave-uniform)
         const T* px = in + (((size_t)b * a.IH + (ok ? sy : 0)) * a.IW + (ok ? sx : 0)) * a.KC;
         const T* wt = w + (size_t)tap * a.NC * a.KC;
         for (int c0 = 0; c0 < a.KC; c0 += Op::KSTEP) {
@@ -309,15 +322,103 @@ __global__ __launch_bounds__(256) void gconv_wgrad16_kernel(GWArgs a, int tapgro
         }
 }
 
+// ---- weight gradient of a THIN layer (input channel stride 16: the 3-channel image planes of the 5x5 Bayar layer and of the first 4x4
+// stride-2 discriminator layer), 16-bit dtypes.  A 64 x 64 block per tap as above wastes 15/16 of every staged row and stages the input once
+// per tap.  Here a workgroup owns one 16-channel block of dout and a split of the chunks (64 consecutive output pixels of one output row);
+// per chunk it stages dout [64 px][16 n] and ONCE the input window [KH rows][63 stride + KW px][16 k] (32 bytes per pixel), and every tap's
+// B fragment is a shifted (stride-2: strided) transposing read of that window.  Wave w accumulates the taps w, w + 4, ... in registers.
+constexpr int THIN_MAXT = 7;   // taps per wave: 25 / 4 rounded up
+template <typename H>
+__global__ __launch_bounds__(256) void gconv_wgrad_thin_kernel(GWArgs a, int chunks_x, int winw) {
+    typedef typename h16<H>::x8 frag;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];   // dout chunk 2 KB | input window KH * winw * 32 B
+    unsigned char* sd = tsm;
+    unsigned char* sx = tsm + 64 * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int taps = a.KH * a.KW, nblk = blockIdx.y;
+    const size_t chunks = (size_t)a.B * a.OH * chunks_x, cper = (chunks + a.nsplit - 1) / a.nsplit;
+    const size_t c0 = (size_t)blockIdx.x * cper, c1 = c0 + cper < chunks ? c0 + cper : chunks;
+    const H* dout = (const H*)a.dout;
+    const H* in = (const H*)a.in;
+    const int r = lane & 15, kq = lane >> 4, q2 = (lane >> 2) & 3, p2 = lane & 3;
+    f32x4 acc[THIN_MAXT];
+#pragma unroll
+    for (int t = 0; t < THIN_MAXT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    const int nwin = a.KH * winw * 2;   // 16-byte vectors of the window
+    for (size_t ch = c0; ch < c1; ++ch) {
+        const int xs = (int)(ch % chunks_x), oy = (int)((ch / chunks_x) % a.OH), b = (int)(ch / ((size_t)chunks_x * a.OH));
+        const int ox0 = xs * 64;
+        if (tid < 128) {
+            const int px = tid >> 1, h = tid & 1;
+            u32x4v v = {0u, 0u, 0u, 0u};
+            if (ox0 + px < a.OW) v = *reinterpret_cast<const u32x4v*>(dout + (((size_t)b * a.OH + oy) * a.OW + ox0 + px) * a.NC + nblk * 16 + 8 * h);
+            *reinterpret_cast<u32x4v*>(sd + px * 32 + 16 * h) = v;
+        }
+        const int iy0 = oy * a.stride - a.pad, ix0 = ox0 * a.stride - a.pad;
+        for (int i = tid; i < nwin; i += 256) {
+            const int h = i & 1, wp = (i >> 1) % winw, wr = (i >> 1) / winw;
+            const int sy = iy0 + wr, sxx = ix0 + wp;
+            u32x4v v = {0u, 0u, 0u, 0u};
+            if (sy >= 0 && sy < a.IH && sxx >= 0 && sxx < a.IW) v = *reinterpret_cast<const u32x4v*>(in + (((size_t)b * a.IH + sy) * a.IW + sxx) * 16 + 8 * h);
+            *reinterpret_cast<u32x4v*>(sx + (wr * winw + wp) * 32 + 16 * h) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pxl = 32 * ks + 8 * kq + q2;   // this lane's pixel of the K-step (and pxl + 4)
+            const char* ap = reinterpret_cast<const char*>(sd) + pxl * 32 + 8 * p2;
+            const frag af = g_tr_frag<H>(ap, ap + 4 * 32);
+#pragma unroll
+            for (int t = 0; t < THIN_MAXT; ++t) {
+                const int tap = wave + 4 * t;
+                if (tap < taps) {
+                    const int ky = tap / a.KW, kx = tap - ky * a.KW;
+                    const char* bp = reinterpret_cast<const char*>(sx) + ((ky * winw + pxl * a.stride + kx) * 32) + 8 * p2;
+                    const frag bf = g_tr_frag<H>(bp, bp + 4 * a.stride * 32);
+                    acc[t] = h16<H>::mfma16(af, bf, acc[t]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < THIN_MAXT; ++t) {
+        const int tap = wave + 4 * t;
+        if (tap < taps) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a.partial[(((size_t)blockIdx.x * taps + tap) * a.NC + nblk * 16 + 4 * kq + i) * 16 + r] = acc[t][i];
+        }
+    }
+}
+
 // dw[co][ci][ky][kx] (+)= sum over splits of partial[split][tap][co][ci]   (co < Cout, ci < Cin: the real extents)
+// SL split lanes per output (1, 4 or 16, the host's choice by nsplit): thread (o, sl) sums the splits sl, sl + SL, ... of output o, the SL
+// partial sums meet in the LDS in a fixed order
 __global__ __launch_bounds__(256) void gconv_wreduce_kernel(const float* __restrict__ partial, int nsplit, int taps, int NC, int KC, float* __restrict__ dw,
-                                                            int Cout, int Cin, int accumulate) {
+                                                            int Cout, int Cin, int accumulate, int SL) {
+    __shared__ float red[256];
     const size_t total = (size_t)Cout * Cin * taps;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int tap = (int)(i % taps), ci = (int)((i / taps) % Cin), co = (int)(i / ((size_t)taps * Cin));
+    const int per = 256 / SL, o = threadIdx.x % per, sl = threadIdx.x / per;
+    for (size_t base = (size_t)blockIdx.x * per; base < total; base += (size_t)gridDim.x * per) {   // (uniform trip count: barriers inside)
+        const size_t i = base + o;
         float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += partial[(((size_t)sp * taps + tap) * NC + co) * KC + ci];
-        dw[i] = (accumulate ? dw[i] : 0.f) + s;
+        if (i < total) {
+            const int tap = (int)(i % taps), ci = (int)((i / taps) % Cin), co = (int)(i / ((size_t)taps * Cin));
+            const float* pp = partial + ((size_t)tap * NC + co) * KC + ci;
+            const size_t step = (size_t)taps * NC * KC;
+            for (int sp = sl; sp < nsplit; sp += SL) s += pp[(size_t)sp * step];
+        }
+        if (SL > 1) {
+            red[threadIdx.x] = s;
+            __syncthreads();
+            if (sl == 0) {
+                for (int k = 1; k < SL; ++k) s += red[k * per + o];
+            }
+            __syncthreads();
+        }
+        if (sl == 0 && i < total) dw[i] = (accumulate ? dw[i] : 0.f) + s;
     }
 }
 
@@ -427,11 +528,22 @@ extern "C" int wm_gconv_fwd(const void* in, const void* w, const float* bias, vo
 
 // pixel splits of the 16-bit kernel: enough workgroups to fill the chip, at most 64 slabs
 static int wgrad16_nsplit(int B, int OH, int OW, int KC, int NC, int KH, int KW) {
+    // >= 2048 workgroups in flight (24 KB of LDS each: 6 per CU hide the per-tap load -> LDS -> barrier latency), at least 4 chunks each;
+    // the 5x5 3 -> 3 Bayar layer has 4 jobs and 24,576 chunks: at the former cap of 64 splits its weight gradient took 2.5 ms
     const size_t chunks = ((size_t)B * OH * OW + 63) / 64;
     const long jobs = (long)((NC + 63) / 64) * ((KC + 63) / 64) * ((KH * KW + WG_TAPS - 1) / WG_TAPS);
-    long ns = (1024 + jobs - 1) / jobs;
-    if (ns > 64) ns = 64;
-    if ((size_t)ns > chunks) ns = (long)chunks;
+    const long target = jobs < 16 ? 2048 : 1024;   // (layers with many jobs keep the slab traffic of the splits down)
+    long ns = (target + jobs - 1) / jobs;
+    if (ns > 1024) ns = 1024;
+    if ((size_t)ns > (chunks + 3) / 4) ns = (long)((chunks + 3) / 4);
+    return (int)(ns < 1 ? 1 : ns);
+}
+static bool thin_ok(int KC, int NC, int KH, int KW, int stride) { return KC == 16 && NC % 16 == 0 && KH * KW <= 4 * THIN_MAXT && (stride == 1 || stride == 2); }
+static int thin_chunks_x(int OW) { return (OW + 63) / 64; }
+static int thin_nsplit(int B, int OH, int OW) {
+    const size_t chunks = (size_t)B * OH * thin_chunks_x(OW);
+    size_t ns = (chunks + 7) / 8;   // >= 8 chunks per workgroup
+    if (ns > 1024) ns = 1024;
     return (int)(ns < 1 ? 1 : ns);
 }
 extern "C" int wm_gconv_wgrad_nsplit(int B, int OH, int OW, int KC, int NC, int KH, int KW) {
@@ -446,7 +558,7 @@ extern "C" int wm_gconv_wgrad_nsplit(int B, int OH, int OW, int KC, int NC, int 
 }
 
 extern "C" size_t wm_gconv_wgrad_scratch_floats(int B, int OH, int OW, int KC, int NC, int KH, int KW) {
-    const int ns = std::max(wm_gconv_wgrad_nsplit(B, OH, OW, KC, NC, KH, KW), wgrad16_nsplit(B, OH, OW, KC, NC, KH, KW));   // either kernel
+    const int ns = std::max(std::max(wm_gconv_wgrad_nsplit(B, OH, OW, KC, NC, KH, KW), wgrad16_nsplit(B, OH, OW, KC, NC, KH, KW)), thin_nsplit(B, OH, OW));   // any kernel
     const size_t a = (size_t)ns * KH * KW * NC * KC, b = (size_t)colsum_nsplit((size_t)B * OH * OW) * NC;
     return a > b ? a : b;
 }
@@ -468,6 +580,13 @@ extern "C" int wm_gconv_wgrad(const void* dout, const void* in, float* partial, 
         a.nsplit = wm_gconv_wgrad_nsplit(B, OH, OW, KC, NC, KH, KW);
         const int jobs = KH * KW * (NC / 16) * ((KC + 15) / 16);
         hipLaunchKernelGGL(gconv_wgrad_kernel<float>, dim3((unsigned)jobs, (unsigned)a.nsplit), dim3(256), 0, s, a);
+    } else if (thin_ok(KC, NC, KH, KW, stride)) {
+        a.nsplit = thin_nsplit(B, OH, OW);
+        const int winw = 63 * stride + KW;
+        const size_t lds = 64 * 32 + (size_t)KH * winw * 32;
+        const dim3 grid((unsigned)a.nsplit, (unsigned)(NC / 16));
+        if (dtype == WM_BF16) hipLaunchKernelGGL(gconv_wgrad_thin_kernel<bf16_t>, grid, dim3(256), lds, s, a, thin_chunks_x(OW), winw);
+        else hipLaunchKernelGGL(gconv_wgrad_thin_kernel<f16_t>, grid, dim3(256), lds, s, a, thin_chunks_x(OW), winw);
     } else {
         a.nsplit = wgrad16_nsplit(B, OH, OW, KC, NC, KH, KW);
         const int tapgroups = (KH * KW + WG_TAPS - 1) / WG_TAPS;
@@ -476,8 +595,13 @@ extern "C" int wm_gconv_wgrad(const void* dout, const void* in, float* partial, 
         else hipLaunchKernelGGL(gconv_wgrad16_kernel<f16_t>, grid, dim3(256), 0, s, a, tapgroups);
     }
     WM_LAUNCH_CHECK("wm_gconv_wgrad");
-    hipLaunchKernelGGL(gconv_wreduce_kernel, dim3(grid1((size_t)Cout * Cin * KH * KW)), dim3(256), 0, s, partial, a.nsplit, KH * KW, NC, KC, dw, Cout, Cin,
-                       accumulate);
+    {
+        const int SL = a.nsplit >= 64 ? 16 : a.nsplit >= 8 ? 4 : 1;
+        const size_t outs = (size_t)Cout * Cin * KH * KW, per = 256 / SL;
+        const size_t g = (outs + per - 1) / per;
+        hipLaunchKernelGGL(gconv_wreduce_kernel, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, s, partial, a.nsplit, KH * KW, NC, KC, dw, Cout, Cin,
+                           accumulate, SL);
+    }
     WM_LAUNCH_CHECK("wm_gconv_wgrad(reduce)");
     if (dbias) {   // (the slab partials have been consumed by the reduce above: the scratch is free again)
         const size_t npix = (size_t)B * OH * OW;
