@@ -438,25 +438,42 @@ __global__ void gconv_pack_kernel(const float* __restrict__ w, T* __restrict__ w
 // out[c] (+)= sum over the splits in a fixed order
 template <typename T>
 __global__ __launch_bounds__(256) void gcolsum_kernel(const T* __restrict__ x, size_t npix, int C, float* __restrict__ part) {
-    // a thread owns one 16-byte vector (VE channels) of the 64-channel block and every (256 / vectors)-th pixel of the split
-    constexpr int VE = 16 / sizeof(T), NV = 64 / VE, PL = 256 / NV;   // bf16: 8 channels, 8 vectors, 32 pixel lanes
-    const int v = threadIdx.x % NV, pl = threadIdx.x / NV;
+    // a thread owns one 16-byte vector (VE channels) of the block's cw <= 64 channels and every PL-th pixel of the split; a narrow block
+    // (C = 32: 4 vectors) spreads its threads over more pixel lanes instead of idling; four loads in flight per thread
+    constexpr int VE = 16 / sizeof(T), MAXPL = 256 / (16 / VE);
+    const int cw = min(64, C - (int)blockIdx.x * 64), nv = cw / VE, PL = 256 / nv;
+    const int v = threadIdx.x % nv, pl = threadIdx.x / nv;
     const int c0 = blockIdx.x * 64 + v * VE;
     const size_t per = (npix + gridDim.y - 1) / gridDim.y, p0 = (size_t)blockIdx.y * per, p1 = p0 + per < npix ? p0 + per : npix;
-    float acc[VE];
+    float acc[4][VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
-    if (c0 < C)
-        for (size_t p = p0 + pl; p < p1; p += PL) {
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[u][e] = 0.f;
+    if (pl < PL) {
+        size_t p = p0 + pl;
+        for (; p + 3 * (size_t)PL < p1; p += 4 * (size_t)PL) {
+            vec16<T> t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const vec16<T>*>(x + (p + (size_t)u * PL) * C + c0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VE; ++e) acc[u][e] += t[u].get(e);
+        }
+        for (; p < p1; p += PL) {
             const vec16<T> t = *reinterpret_cast<const vec16<T>*>(x + p * C + c0);
 #pragma unroll
-            for (int e = 0; e < VE; ++e) acc[e] += t.get(e);
+            for (int e = 0; e < VE; ++e) acc[0][e] += t.get(e);
         }
-    __shared__ float s[PL][65];
+    }
+    __shared__ float s[MAXPL][65];
+    if (pl < PL) {
 #pragma unroll
-    for (int e = 0; e < VE; ++e) s[pl][v * VE + e] = acc[e];
+        for (int e = 0; e < VE; ++e) s[pl][v * VE + e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+    }
     __syncthreads();
-    if (threadIdx.x < 64 && blockIdx.x * 64 + (int)threadIdx.x < C) {
+    if ((int)threadIdx.x < cw) {
         float t = 0.f;
         for (int k = 0; k < PL; ++k) t += s[k][threadIdx.x];
         part[(size_t)blockIdx.y * C + blockIdx.x * 64 + threadIdx.x] = t;
@@ -475,7 +492,7 @@ __global__ __launch_bounds__(256) void gcolsum_reduce_kernel(const float* __rest
 }
 inline int colsum_nsplit(size_t npix) {
     const size_t n = (npix + 1023) / 1024;
-    return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
+    return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
 }
 
 inline int grid1(size_t n, int cap = 4096) {
