@@ -944,7 +944,8 @@ def test_after_concat_layer_without_the_concat(case, dtype):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, torch.bfloat16, False), (3, 40, 56, torch.bfloat16, True), (1, 21, 37, torch.float16, False),
-                                  (16, 128, 128, torch.bfloat16, True)])
+                                  (16, 128, 128, torch.bfloat16, True),
+                                  (2, 16, 16, torch.bfloat16, False), (5, 8, 200, torch.bfloat16, True)])   # one tile column / one tile row (the mulhi geometry's d = 1)
 def test_fused_backward_kernel_against_the_two_kernel_form(case):
     """csrc/bwd_ws.hip (input gradient + the feeding layer's BatchNorm sums + weight gradient from one staged dy / a tile) against
     wm_conv3x3_dgrad_applyfused + wm_conv3x3_wgrad on the same operands: dx bit-identical (same dy, same MFMA order over K), the

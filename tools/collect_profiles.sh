@@ -26,4 +26,15 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/att_fetch -o af -- python
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/att_write -o aw -- python3 $ROOT/tools/attack_bench.py 5 > $OUT/att_write.log 2>&1
 python3 $ROOT/tools/attack_bench.py 50 > $OUT/attack_bench.json 2> $OUT/attack_bench.err
 echo "attacks done"
+# the widened configurations through the model surface, the literal IRNrhi step, the one-pass backward kernel's phases, the co-issue micro
+cd $ROOT
+(python3 tools/bench_c5.py train_hidden_c3.yml bf16 72 && python3 tools/bench_c5.py train_hidden_c3.yml f16 72 && python3 tools/bench_c5.py train_hidden_c5.yml bf16 72 &&
+ python3 tools/bench_c5.py train_hidden_c5_fp16.yml f16 72) 2> $OUT/c3_c5.err | grep '^{' > $OUT/c3_c5_steps.jsonl
+(python3 tools/bench_literal.py 4 bf16 12 && python3 tools/bench_literal.py 4 f16 12) 2> $OUT/literal.err | grep '^{' > $OUT/literal_steps.jsonl
+(python3 tools/phase_bwd.py 0 && python3 tools/phase_bwd.py 256 && python3 tools/phase_bwd.py 8) 2>&1 | grep -v amdgpu.ids > $OUT/bwd_phase_cycles.txt
+if [ -x tools/micro/mfma_rate ]; then tools/micro/mfma_rate > $OUT/mfma_coissue_micro.txt 2>&1; fi
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lit_stats -o l -- python3 $ROOT/tools/bench_literal.py 4 bf16 6 > $OUT/lit_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_stats -o c -- python3 $ROOT/tools/bench_c5.py train_hidden_c5_fp16.yml f16 44 > $OUT/c5_stats.log 2>&1
+echo "widened done"
 ls -R $OUT | head -40

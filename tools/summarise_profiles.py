@@ -124,4 +124,19 @@ try:
     shutil.copy(os.path.join(src, "attack_bench.json"), os.path.join(dst, f"{tag}_attack_bench.json"))
 except (IndexError, OSError) as e:
     print("attack profiles missing:", e)
+# ---- widened configurations, the literal step, the one-pass backward kernel's phases, the co-issue microbenchmark
+for name, out in (("c3_c5_steps.jsonl", f"{tag}_c3_c5_steps.jsonl"), ("literal_steps.jsonl", f"{tag}_literal_steps.jsonl"),
+                  ("bwd_phase_cycles.txt", f"{tag}_bwd_phase_cycles.txt"), ("mfma_coissue_micro.txt", f"{tag}_mfma_coissue_micro.txt")):
+    f = os.path.join(src, name)
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        shutil.copy(f, os.path.join(dst, out))
+    else:
+        print("missing:", name)
+for sub, base, steps, cmd in (("lit_stats", f"{tag}_literal_step_kernel_stats", 8.0, "python3 tools/bench_literal.py 4 bf16 6   (8 steps: the reference's literal IRNrhi step, 24 frames 256x256, bf16)"),
+                              ("c5_stats", f"{tag}_c5_fp16_kernel_stats", 42.0, "python3 tools/bench_c5.py train_hidden_c5_fp16.yml f16 44   (42 steps with work, 16 frames 256x256 each, UNet head, f16 + device GradScaler)")):
+    try:
+        stats_summary(sub, base, steps, cmd)
+        os.remove(os.path.join(dst, base + ".csv"))   # (the summary is what is cited; the full CSVs of the benchmarked step are kept above)
+    except (IndexError, OSError) as e:
+        print("missing:", sub, e)
 print(json.dumps(res, indent=1)[:1500])

@@ -448,6 +448,17 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) acc[ml][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the epilogue's per-channel constants (the feeding layer's scale | shift of this lane's 16 channels): the first half is requested at the
+        // top of the LAST K-step, whose fragment ring has a free half, so that the epilogue does not open with an exposed LDS round trip
+        f32x4 rsv[4], rhv[4];
+        auto load_rsrh = [&](int j0, int j1) {
+#pragma unroll
+            for (int jj = j0; jj < j1; ++jj) {
+                rsv[jj] = *reinterpret_cast<const f32x4*>(sTab + 16 * q + 4 * jj);
+                rhv[jj] = *reinterpret_cast<const f32x4*>(sTab + C + 16 * q + 4 * jj);
+            }
+        };
+        if constexpr ((DBG & 1) != 0) load_rsrh(0, 2);
         if constexpr (!(DBG & 1)) {
             // fragment schedule: every fragment of K-step sidx + 1 is requested at the top of K-step sidx (8 MFMAs + the staging units ahead
             // of its use: one wave per SIMD has to cover the LDS latency itself); 48 registers of operands
@@ -479,6 +490,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                 const int cb = sidx & 1;
                 constexpr bool inter = stage && !(DBG & 128);
                 if constexpr (inter) { if ((2 * sidx) % 18 < 16 && ((2 * sidx) % 18) % 4 == 0) pub_consts(((2 * sidx) % 18) / 4); }
+                if (sidx == 17) load_rsrh(0, 2);   // (all four vectors here cost the unmasked-g variant 2 spilled registers)
                 if (sidx + 1 < 18) {
                     load_pix(sidx + 1, cb ^ 1);
                     if (!((DBG & 1024) && (sidx & 1))) { load_fil(sidx + 1, 0, filA[cb ^ 1]); load_fil(sidx + 1, 1, filB[cb ^ 1]); }   // DBG 1024: half the filter fragment reads
@@ -517,32 +529,28 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         }
         if constexpr ((DBG & 4096) != 0) { __builtin_amdgcn_sched_barrier(0); ts[4] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         // ---------------- input-gradient epilogue: layer L-1's BatchNorm-backward sums (gz = dx * [z > 0], dx rounded as stored), pack, store
-        // (one wave per SIMD pays an issue slot for every instruction: lanes outside the image skip the lot under exec, the masked dx is
-        // built by two selects per pair and the sums take THEIR operands from it -- 17 VALU instructions per channel pair)
+        // (one wave per SIMD pays an issue slot for every instruction: the masked dx is built by two selects per pair and the sums take
+        // THEIR operands from it -- 18 VALU instructions per channel pair; branch-free, so both pixel rows schedule as one block)
+        load_rsrh(2, 4);
         if constexpr (!(DBG & 4))
 #pragma unroll
         for (int ml = 0; ml < 2; ++ml) {
-            if (!inb[ml]) continue;
             unsigned pk[8];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const f32x4 rs = *reinterpret_cast<const f32x4*>(sTab + 16 * q + 4 * jj), rh = *reinterpret_cast<const f32x4*>(sTab + C + 16 * q + 4 * jj);
-#pragma unroll
-                for (int jh = 0; jh < 2; ++jh) {
-                    const int j = 2 * jj + jh, nf = j >> 1, i0 = 2 * (j & 1);
-                    const hx2 p2v = {(hx_t)acc[ml][nf][i0], (hx_t)acc[ml][nf][i0 + 1]};
-                    const unsigned raw = __builtin_bit_cast(unsigned, p2v);
-                    const float y0 = HX::lo(ryv[ml][j]), y1 = HX::hi(ryv[ml][j]);
-                    const float z0 = __builtin_fmaf(rs[2 * jh], y0, rh[2 * jh]), z1 = __builtin_fmaf(rs[2 * jh + 1], y1, rh[2 * jh + 1]);
-                    const unsigned t = z0 > 0.f ? raw : (raw & 0xffff0000u);
-                    pk[j] = z1 > 0.f ? t : (t & 0xffffu);   // dx leaves masked: gz, not g
-                    const float gz0 = HX::lo(pk[j]), gz1 = HX::hi(pk[j]);
-                    s1[2 * j] += gz0; s1[2 * j + 1] += gz1;
-                    s2[2 * j] = __builtin_fmaf(gz0, y0, s2[2 * j]);
-                    s2[2 * j + 1] = __builtin_fmaf(gz1, y1, s2[2 * j + 1]);
-                }
+            for (int j = 0; j < 8; ++j) {
+                const int nf = j >> 1, i0 = 2 * (j & 1), jj = j >> 1, jh = j & 1;
+                const hx2 p2v = {(hx_t)acc[ml][nf][i0], (hx_t)acc[ml][nf][i0 + 1]};
+                const unsigned raw = inb[ml] ? __builtin_bit_cast(unsigned, p2v) : 0u;
+                const float y0 = HX::lo(ryv[ml][j]), y1 = HX::hi(ryv[ml][j]);
+                const float z0 = __builtin_fmaf(rsv[jj][2 * jh], y0, rhv[jj][2 * jh]), z1 = __builtin_fmaf(rsv[jj][2 * jh + 1], y1, rhv[jj][2 * jh + 1]);
+                const unsigned t = z0 > 0.f ? raw : (raw & 0xffff0000u);
+                pk[j] = z1 > 0.f ? t : (t & 0xffffu);   // dx leaves masked: gz, not g
+                const float gz0 = HX::lo(pk[j]), gz1 = HX::hi(pk[j]);
+                s1[2 * j] += gz0; s1[2 * j + 1] += gz1;
+                s2[2 * j] = __builtin_fmaf(gz0, y0, s2[2 * j]);
+                s2[2 * j + 1] = __builtin_fmaf(gz1, y1, s2[2 * j + 1]);
             }
-            if constexpr (!(DBG & 512)) {   // DBG 512: no dx stores
+            if (inb[ml] && !(DBG & 512)) {   // DBG 512: no dx stores
                 *reinterpret_cast<u32x4*>(outp[ml]) = u32x4{pk[0], pk[1], pk[2], pk[3]};
                 *reinterpret_cast<u32x4*>(outp[ml] + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
             }
