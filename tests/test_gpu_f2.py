@@ -139,3 +139,38 @@ def test_embedder_properties_at_full_frame_size():
         net(torch.zeros(1, 4, 100, 100, device=DEV))
     with pytest.raises(RuntimeError, match="GPU only"):
         net(torch.zeros(1, 4, 64, 64))
+
+
+def test_captured_step_replays_the_eager_step():
+    """glayers.CapturedStep: forward + reverse + backward of the embedder captured into a hipGraph; a replay on new input (copied into
+    the static tensor) leaves the same outputs and the same flat gradient as the eager step on that input."""
+    from video_watermarking_forgery_detection_amd import glayers as G
+    PAMI, ResBlock, _ = _mods()
+    net = detgen.fill_f2(PAMI(dims_in=[[4, 32, 32]], block_num=[1, 1, 1], subnet_constructor=ResBlock, dtype=torch.bfloat16)).to(DEV)
+    opt = G.FlatAdamW(net, lr=1e-4)
+    xs = torch.zeros(2, 4, 32, 32, device=DEV)
+
+    def fwd_bwd():
+        y = net(xs)
+        back, mid = net(y, rev=True)
+        loss = ((y - xs) ** 2).mean() + (back ** 2).mean() + (mid ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        return y, loss
+
+    x1, x2 = detgen.uniform((2, 4, 32, 32), 5).to(DEV), detgen.uniform((2, 4, 32, 32), 6).to(DEV)
+    xs.copy_(x1)
+    step = G.CapturedStep(fwd_bwd)
+    xs.copy_(x2)
+    y_s, loss_s = step.replay()
+    torch.cuda.synchronize()
+    y2, g2, l2 = y_s.clone(), opt.grad.clone(), loss_s.clone()
+    assert float(g2.abs().max()) > 0
+    xs.copy_(x1)
+    step.replay()                              # overwrites the static outputs and the flat gradient
+    torch.cuda.synchronize()
+    assert not torch.equal(opt.grad, g2)
+    xs.copy_(x2)
+    y_e, loss_e = fwd_bwd()                    # the eager step on x2
+    torch.cuda.synchronize()
+    assert torch.equal(y_e, y2) and torch.equal(opt.grad, g2) and torch.equal(loss_e.detach(), l2.detach())

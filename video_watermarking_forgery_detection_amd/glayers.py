@@ -22,6 +22,8 @@ cpad = ops.cpad
 def _pad_bias(bias, n):
     if bias is None:
         return None
+    if bias.numel() == n and bias.dtype == torch.float32 and bias.is_contiguous():
+        return bias.detach()            # (no padding channels: two launches fewer per call -- the embedder makes ~1,600 such calls a step)
     out = torch.zeros(n, device=bias.device, dtype=torch.float32)
     out[: bias.numel()] = bias.detach()
     return out
@@ -550,3 +552,34 @@ class FlatAdamW:
     def step(self):
         self.t += 1
         ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t, decoupled=True)
+
+
+class CapturedStep:
+    """A launch-bound step (the invertible embedder issues ~20,000 kernels of 3-20 us per forward + reverse + backward) captured ONCE into a
+    hipGraph and replayed: `fn()` must be shape-static, read its inputs from tensors that are updated in place (copy_), and not synchronise
+    with the host (no .item() / float()).  Gradients land in the parameters' existing .grad tensors (FlatAdamW's flat buffer), so
+    zero_grad belongs INSIDE fn and the optimiser step -- whose bias correction depends on the host's step count -- outside:
+
+        step = CapturedStep(lambda: fwd_bwd(x_static))      # two eager warm-up calls on a side stream, then the capture
+        for batch in data: x_static.copy_(batch); step.replay(); opt.step()
+
+    step.result holds what fn returned at capture (tensors that every replay overwrites).  Hand results out through that return value:
+    an fn that rebinds outer variables to its tensors, after an eager call on the default stream had bound them, ended the capture in a
+    segmentation fault inside hipStreamEndCapture on ROCm 7.2 (tools/dbg_capture.py 1 0 0 1)."""
+
+    def __init__(self, fn, warmup=2):
+        if not torch.cuda.is_available():
+            raise RuntimeError("CapturedStep: GPU only")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.result = fn()
+
+    def replay(self):
+        self.graph.replay()
+        return self.result
