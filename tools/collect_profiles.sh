@@ -31,6 +31,7 @@ cd $ROOT
 (python3 tools/bench_c5.py train_hidden_c3.yml bf16 72 && python3 tools/bench_c5.py train_hidden_c3.yml f16 72 && python3 tools/bench_c5.py train_hidden_c5.yml bf16 72 &&
  python3 tools/bench_c5.py train_hidden_c5_fp16.yml f16 72) 2> $OUT/c3_c5.err | grep '^{' > $OUT/c3_c5_steps.jsonl
 (python3 tools/bench_literal.py 4 bf16 12 && python3 tools/bench_literal.py 4 f16 12) 2> $OUT/literal.err | grep '^{' > $OUT/literal_steps.jsonl
+(python3 tools/bench_inn.py 8 bf16 6 && python3 tools/bench_inn.py 8 bf16 6 graph && python3 tools/bench_inn.py 8 f16 6 graph) 2> $OUT/inn.err | grep '^{' > $OUT/inn_steps.jsonl
 (python3 tools/phase_bwd.py 0 && python3 tools/phase_bwd.py 256 && python3 tools/phase_bwd.py 8) 2>&1 | grep -v amdgpu.ids > $OUT/bwd_phase_cycles.txt
 if [ -x tools/micro/mfma_rate ]; then tools/micro/mfma_rate > $OUT/mfma_coissue_micro.txt 2>&1; fi
 cd /tmp

@@ -14,7 +14,8 @@ NXCD, NCU, NSIMD = 8, 256, 4
 
 
 def find(sub, pat):
-    return glob.glob(os.path.join(src, sub, "**", pat), recursive=True)[0]
+    # (gpurun MERGES the box's gpurun_out into the local one: files of earlier collections with other -o prefixes survive; take the newest)
+    return max(glob.glob(os.path.join(src, sub, "**", pat), recursive=True), key=os.path.getmtime)
 
 
 def stats_summary(sub, out_base, steps, cmd):
@@ -125,7 +126,7 @@ try:
 except (IndexError, OSError) as e:
     print("attack profiles missing:", e)
 # ---- widened configurations, the literal step, the one-pass backward kernel's phases, the co-issue microbenchmark
-for name, out in (("c3_c5_steps.jsonl", f"{tag}_c3_c5_steps.jsonl"), ("literal_steps.jsonl", f"{tag}_literal_steps.jsonl"),
+for name, out in (("c3_c5_steps.jsonl", f"{tag}_c3_c5_steps.jsonl"), ("literal_steps.jsonl", f"{tag}_literal_steps.jsonl"), ("inn_steps.jsonl", f"{tag}_inn_steps.jsonl"),
                   ("bwd_phase_cycles.txt", f"{tag}_bwd_phase_cycles.txt"), ("mfma_coissue_micro.txt", f"{tag}_mfma_coissue_micro.txt")):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 0:
