@@ -486,6 +486,12 @@ size_t wm_gcolsum_scratch_floats(size_t npix, int C);
 int wm_gcolsum(const void* x, size_t npix, int C, float* out, int Creal, int accumulate, float* scratch, int dtype, void* stream);
 int wm_unary_fwd(const void* x, void* y, size_t n, int kind, int dtype, void* stream);
 int wm_unary_bwd(const void* x, const void* gy, void* gx, size_t n, int kind, int dtype, void* stream);
+/* gx = gy * act'(x) over x [npix][C] AND out [Creal] (+)= the column sums of gx as stored -- the bias gradient of the nn.Conv2d whose
+ * output the activation took (conditional_jpeg_generator.py / invertible_net.py:326-366's conv -> ELU / ReLU pairs): one pass over the
+ * data + a reduce of the split partials.  part: wm_unary_bwd_colsum_scratch_floats(npix, C) floats. */
+size_t wm_unary_bwd_colsum_scratch_floats(size_t npix, int C);
+int wm_unary_bwd_colsum(const void* x, const void* gy, void* gx, size_t npix, int C, int kind, float* part, float* out, int Creal,
+                        int accumulate, int dtype, void* stream);
 int wm_add_scaled(const void* a, const void* b, void* out, size_t n, float alpha, int dtype, void* stream);
 int wm_qfatt_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* out, int B, size_t hw, int C, int ldv,
                  int dtype, void* stream);

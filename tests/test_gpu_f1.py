@@ -144,6 +144,41 @@ def test_activations_combines_pool():
     assert rel(ops.gpool_bwd(gam.to(DEV), (2, 5, 6, 32), torch.float32), (gam / 30.0)[:, None, None, :].expand(2, 5, 6, 32)) < 1e-6
 
 
+def test_activation_backward_with_the_bias_gradient():
+    """ops.unary_bwd_colsum (the activation's backward and the split partials of the bias gradient in one pass) against unary_bwd + gcolsum, and a
+    FusedSequential against the same children run one by one"""
+    from video_watermarking_forgery_detection_amd import ops, glayers as G
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
+        for (B, H, W, C, creal, kind) in ((2, 9, 7, 16, 3, "elu"), (3, 33, 40, 64, 64, "relu"), (2, 64, 64, 192, 180, "gelu"), (8, 128, 128, 32, 32, "lrelu")):
+            x = detgen.normal((B, H, W, C), 7 + C).to(DEV).to(dtype)
+            g = detgen.normal((B, H, W, C), 8 + C).to(DEV).to(dtype)
+            gx0 = ops.unary_bwd(x, g, kind)
+            db0 = ops.gcolsum(gx0, creal)
+            for _ in range(2):
+                gx, db = ops.unary_bwd_colsum(x, g, kind, creal)
+                assert rel(gx, gx0) <= {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype], (dtype, C, kind)   # (gelu's FMA contraction may differ by an ulp between the two kernels)
+                assert rel(db, db0) < 1e-5, (dtype, C)
+    torch.manual_seed(0)
+    seq = G.FusedSequential(G.Conv2d(5, 24, 3, 1, 1), G.Act("elu"), G.Conv2d(24, 24, 4, 2, 1), G.Act("relu"), G.Conv2d(24, 7, 1, 1, 0)).to(DEV)
+    x = detgen.normal((2, 5, 12, 12), 3).to(DEV)
+    for dtype in (torch.float32, torch.bfloat16):
+        outs = []
+        for fused in (True, False):
+            seq.zero_grad()
+            xd = x.clone().requires_grad_(True)
+            h = G.to_nhwc(xd, dtype)
+            if fused:
+                h = seq(h)
+            else:
+                for m in seq:
+                    h = m(h)
+            y = G.to_nchw(h, 7)
+            (y * y).sum().backward()
+            outs.append([y.detach().clone(), xd.grad.clone()] + [p.grad.clone() for p in seq.parameters()])
+        for a, b in zip(*outs):
+            assert rel(a, b) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
 def test_padding_layout_changes():
     from video_watermarking_forgery_detection_amd import glayers as G, ops
     from video_watermarking_forgery_detection_amd.models.conditional_jpeg_generator import symm_pad

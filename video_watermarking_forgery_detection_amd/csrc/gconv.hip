@@ -479,19 +479,24 @@ __global__ __launch_bounds__(256) void gcolsum_kernel(const T* __restrict__ x, s
         part[(size_t)blockIdx.y * C + blockIdx.x * 64 + threadIdx.x] = t;
     }
 }
-// out[c] (+)= sum over the splits: 64 channels x 4 split lanes per workgroup, fixed order
-__global__ __launch_bounds__(256) void gcolsum_reduce_kernel(const float* __restrict__ part, int nsplit, int C, float* __restrict__ out, int Creal, int accumulate) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+// out[c] (+)= sum over the splits: 64 channels x 16 split lanes per workgroup, fixed order
+__global__ __launch_bounds__(1024) void gcolsum_reduce_kernel(const float* __restrict__ part, int nsplit, int C, float* __restrict__ out, int Creal, int accumulate) {
+    const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, sub = threadIdx.x >> 6;
     float s = 0.f;
     if (c < Creal)
-        for (int k = sub; k < nsplit; k += 4) s += part[(size_t)k * C + c];
-    __shared__ float sh[4][64];
-    sh[sub][threadIdx.x & 63] = s;
+        for (int k = sub; k < nsplit; k += 16) s += part[(size_t)k * C + c];
+    __shared__ float sh[16][64];
+    sh[sub][cl] = s;
     __syncthreads();
-    if (sub == 0 && c < Creal) out[c] = (accumulate ? out[c] : 0.f) + ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]));
+    if (sub == 0 && c < Creal) {
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r += sh[k][cl];
+        out[c] = (accumulate ? out[c] : 0.f) + r;
+    }
 }
-inline int colsum_nsplit(size_t npix) {
-    const size_t n = (npix + 1023) / 1024;
+inline int colsum_nsplit(size_t npix) {   // >= 256 pixels per split, at most 1024 splits (streaming kernels want ~4 workgroups per CU in flight)
+    const size_t n = (npix + 255) / 256;
     return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
 }
 
@@ -625,7 +630,7 @@ extern "C" int wm_gconv_wgrad(const void* dout, const void* in, float* partial, 
         const int ns = colsum_nsplit(npix);
         WM_DISPATCH_DTYPE(dtype, "wm_gconv_wgrad(bias)",
             hipLaunchKernelGGL(gcolsum_kernel<T>, dim3((unsigned)((NC + 63) / 64), (unsigned)ns), dim3(256), 0, s, (const T*)dout, npix, NC, partial));
-        hipLaunchKernelGGL(gcolsum_reduce_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(256), 0, s, partial, ns, NC, dbias, Cout, accumulate);
+        hipLaunchKernelGGL(gcolsum_reduce_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(1024), 0, s, partial, ns, NC, dbias, Cout, accumulate);
         WM_LAUNCH_CHECK("wm_gconv_wgrad(bias)");
     }
     return WM_OK;
@@ -639,7 +644,7 @@ extern "C" int wm_gcolsum(const void* x, size_t npix, int C, float* out, int Cre
     const int ns = colsum_nsplit(npix);
     WM_DISPATCH_DTYPE(dtype, "wm_gcolsum",
         hipLaunchKernelGGL(gcolsum_kernel<T>, dim3((unsigned)((C + 63) / 64), (unsigned)ns), dim3(256), 0, s, (const T*)x, npix, C, scratch));
-    hipLaunchKernelGGL(gcolsum_reduce_kernel, dim3((unsigned)((Creal + 63) / 64)), dim3(256), 0, s, scratch, ns, C, out, Creal, accumulate);
+    hipLaunchKernelGGL(gcolsum_reduce_kernel, dim3((unsigned)((Creal + 63) / 64)), dim3(1024), 0, s, scratch, ns, C, out, Creal, accumulate);
     WM_LAUNCH_CHECK("wm_gcolsum");
     return WM_OK;
 }

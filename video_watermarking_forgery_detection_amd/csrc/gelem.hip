@@ -47,6 +47,77 @@ __global__ __launch_bounds__(256) void unary_bwd_kernel(const T* __restrict__ x,
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         gx[i] = from_f32<T>(to_f32(gy[i]) * act_d(kind, to_f32(x[i])));
 }
+// gx = gy * act'(x) AND the split partials of its column sums as stored (the bias gradient of the convolution that fed the activation) in
+// one pass -- two launches (this + the reduce) instead of three, and gx is not read back: grid (64-channel blocks, pixel splits), thread
+// layout of gconv.hip's gcolsum; part [nsplit][C].  (A one-launch form, the last workgroup to arrive summing the partials, was measured
+// and dropped: on this chip an agent-scope release is a write-back of the XCD's L2 -- 256 workgroups fencing after 17 MB of stores each
+// made the kernel slower than the three launches it replaced: 160 -> 184 ms on the embedder's step.)
+template <typename T>
+__global__ __launch_bounds__(256) void unary_bwd_colsum_kernel(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ gx, size_t npix, int C, int kind,
+                                                               float* __restrict__ part) {
+    constexpr int VE = 16 / sizeof(T), MAXPL = 256 / (16 / VE);
+    const int cw = min(64, C - (int)blockIdx.x * 64), nv = cw / VE, PL = 256 / nv;
+    const int v = threadIdx.x % nv, pl = threadIdx.x / nv;
+    const int c0 = blockIdx.x * 64 + v * VE;
+    const size_t per = (npix + gridDim.y - 1) / gridDim.y, p0 = (size_t)blockIdx.y * per, p1 = p0 + per < npix ? p0 + per : npix;
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    auto one = [&](const vec16<T>& tx, const vec16<T>& tg, size_t p) {
+        vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            o.set(e, tg.get(e) * act_d(kind, tx.get(e)));
+            acc[e] += o.get(e);
+        }
+        *reinterpret_cast<vec16<T>*>(gx + p * C + c0) = o;
+    };
+    if (pl < PL) {
+        size_t p = p0 + pl;
+        for (; p + 3 * (size_t)PL < p1; p += 4 * (size_t)PL) {   // eight loads in flight per thread
+            vec16<T> tx[4], tg[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                tx[u] = *reinterpret_cast<const vec16<T>*>(x + (p + (size_t)u * PL) * C + c0);
+                tg[u] = *reinterpret_cast<const vec16<T>*>(gy + (p + (size_t)u * PL) * C + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) one(tx[u], tg[u], p + (size_t)u * PL);
+        }
+        for (; p < p1; p += PL) one(*reinterpret_cast<const vec16<T>*>(x + p * C + c0), *reinterpret_cast<const vec16<T>*>(gy + p * C + c0), p);
+    }
+    __shared__ float s[MAXPL][65];
+    if (pl < PL) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s[pl][v * VE + e] = acc[e];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cw) {
+        float t = 0.f;
+        for (int k = 0; k < PL; ++k) t += s[k][threadIdx.x];
+        part[(size_t)blockIdx.y * C + blockIdx.x * 64 + threadIdx.x] = t;
+    }
+}
+// out[c] (+)= the split partials in a fixed order: 64 channels x 16 split lanes per workgroup
+__global__ __launch_bounds__(1024) void ubc_reduce_kernel(const float* __restrict__ part, int nsplit, int C, float* __restrict__ out, int Creal, int accumulate) {
+    const int cl = threadIdx.x & 63, sub = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    float t = 0.f;
+    if (c < Creal)
+        for (int k = sub; k < nsplit; k += 16) t += part[(size_t)k * C + c];
+    __shared__ float sh[16][64];
+    sh[sub][cl] = t;
+    __syncthreads();
+    if (sub == 0 && c < Creal) {
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r += sh[k][cl];
+        out[c] = (accumulate ? out[c] : 0.f) + r;
+    }
+}
+inline int ubc_nsplit(size_t npix) {   // >= 128 pixels per split, at most 1024 splits: 4 workgroups per CU keep enough loads in flight
+    const size_t n = (npix + 127) / 128;
+    return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
+}
 // out = a + alpha * b
 template <typename T>
 __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, size_t n, float alpha) {
@@ -319,6 +390,21 @@ extern "C" int wm_unary_bwd(const void* x, const void* gy, void* gx, size_t n, i
     hipStream_t s = (hipStream_t)stream;
     WM_DISPATCH_DTYPE(dtype, "wm_unary_bwd", hipLaunchKernelGGL(unary_bwd_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, (const T*)x, (const T*)gy, (T*)gx, n, kind));
     WM_LAUNCH_CHECK("wm_unary_bwd");
+    return WM_OK;
+}
+extern "C" size_t wm_unary_bwd_colsum_scratch_floats(size_t npix, int C) { return (size_t)ubc_nsplit(npix) * C; }
+// gx = gy * act'(x) over x [npix][C]; out [Creal] f32 (+)= column sums of gx.  part: wm_unary_bwd_colsum_scratch_floats(npix, C) floats.
+extern "C" int wm_unary_bwd_colsum(const void* x, const void* gy, void* gx, size_t npix, int C, int kind, float* part, float* out, int Creal, int accumulate,
+                                   int dtype, void* stream) {
+    WM_REQUIRE(x && gy && gx && part && out && npix > 0 && C > 0 && C % 16 == 0 && Creal > 0 && Creal <= C && kind >= 0 && kind <= 5, WM_E_BADARG,
+               "wm_unary_bwd_colsum: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int ns = ubc_nsplit(npix);
+    const dim3 grid((unsigned)((C + 63) / 64), (unsigned)ns);
+    WM_DISPATCH_DTYPE(dtype, "wm_unary_bwd_colsum",
+        hipLaunchKernelGGL(unary_bwd_colsum_kernel<T>, grid, dim3(256), 0, s, (const T*)x, (const T*)gy, (T*)gx, npix, C, kind, part));
+    hipLaunchKernelGGL(ubc_reduce_kernel, dim3((unsigned)((Creal + 63) / 64)), dim3(1024), 0, s, part, ns, C, out, Creal, accumulate);
+    WM_LAUNCH_CHECK("wm_unary_bwd_colsum");
     return WM_OK;
 }
 extern "C" int wm_add_scaled(const void* a, const void* b, void* out, size_t n, float alpha, int dtype, void* stream) {

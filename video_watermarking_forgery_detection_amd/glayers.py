@@ -60,24 +60,51 @@ class _ConvFn(Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         stride, pad, has_bias = ctx.geo
-        Cout, Cin, KH, KW = weight.shape
-        g = g.contiguous()
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            if _fast3x3(weight, stride, pad, g.dtype, x.shape[3]):
-                wt = ops.pack_w3x3(weight.detach(), g.shape[3], x.shape[3], g.dtype, transpose=True)
-                gx, _ = ops.conv3x3_fwd(g, wt, None, None, None, want_stats=False)
-            else:
-                wt = ops.gconv_pack(weight.detach(), x.shape[3], g.shape[3], True, g.dtype)
-                gx = ops.gconv_fwd(g, wt, None, (x.shape[1], x.shape[2]), KH, KW, stride, pad, dgrad=True)
-        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            if _fast3x3(weight, stride, pad, g.dtype, 32):      # (the weight-gradient kernels take any 8-multiple of channels)
-                gw = torch.empty(Cout, Cin, 3, 3, device=g.device, dtype=torch.float32)
-                ops.conv3x3_wgrad(x, x.shape[3], None, None, g, gw, False)
-                gb = ops.gcolsum(g, Cout) if has_bias else None
-            else:
-                gw, gb = ops.gconv_wgrad(g, x, Cout, Cin, KH, KW, stride, pad, want_bias=has_bias)
+        gx, gw, gb = _conv_backward(x, weight, g.contiguous(), stride, pad, ctx.needs_input_grad[0],
+                                    ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]), has_bias)
         return gx, gw, gb, None, None
+
+
+def _conv_backward(x, weight, g, stride, pad, need_gx, need_gw, want_bias):
+    """(gx, gw, gb) of nn.Conv2d for the output gradient g (NHWC, contiguous); gb only if want_bias"""
+    Cout, Cin, KH, KW = weight.shape
+    gx = gw = gb = None
+    if need_gx:
+        if _fast3x3(weight, stride, pad, g.dtype, x.shape[3]):
+            wt = ops.pack_w3x3(weight.detach(), g.shape[3], x.shape[3], g.dtype, transpose=True)
+            gx, _ = ops.conv3x3_fwd(g, wt, None, None, None, want_stats=False)
+        else:
+            wt = ops.gconv_pack(weight.detach(), x.shape[3], g.shape[3], True, g.dtype)
+            gx = ops.gconv_fwd(g, wt, None, (x.shape[1], x.shape[2]), KH, KW, stride, pad, dgrad=True)
+    if need_gw:
+        if _fast3x3(weight, stride, pad, g.dtype, 32):      # (the weight-gradient kernels take any 8-multiple of channels)
+            gw = torch.empty(Cout, Cin, 3, 3, device=g.device, dtype=torch.float32)
+            ops.conv3x3_wgrad(x, x.shape[3], None, None, g, gw, False)
+            gb = ops.gcolsum(g, Cout) if want_bias else None
+        else:
+            gw, gb = ops.gconv_wgrad(g, x, Cout, Cin, KH, KW, stride, pad, want_bias=want_bias)
+    return gx, gw, gb
+
+
+class _ConvActFn(Function):
+    """act(nn.Conv2d(x)) as ONE autograd node: the backward forms gz = g * act'(z) and the bias gradient (its column sums) in one pass
+    over the data (ops.unary_bwd_colsum: two launches instead of three, gz not read back), then the convolution's two gradients from gz"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, kind):
+        with torch.no_grad():
+            z = _ConvFn.forward(ctx, x, weight, bias, stride, pad)
+        ctx.save_for_backward(x, weight, z)
+        ctx.kind = kind
+        return ops.unary_fwd(z, kind)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, z = ctx.saved_tensors
+        stride, pad, has_bias = ctx.geo
+        gz, gb = ops.unary_bwd_colsum(z, g, ctx.kind, weight.shape[0])
+        gx, gw, _ = _conv_backward(x, weight, gz, stride, pad, ctx.needs_input_grad[0], ctx.needs_input_grad[1], False)
+        return gx, gw, (gb if has_bias and ctx.needs_input_grad[2] else None), None, None, None
 
 
 class _ConvTFn(Function):
@@ -271,6 +298,48 @@ class SpectralNormConv2d(Conv2d):
 
     def effective_weight(self):
         return _SpectralNormFn.apply(self.weight_orig, self.weight_u, self.weight_v, self.training)
+
+
+class ConvAct(nn.Module):
+    """nn.Sequential(conv, activation) with the state_dict keys of that Sequential (`0.weight`, `0.bias`) and one autograd node for the
+    pair (_ConvActFn); `conv` is a Conv2d / SpectralNormConv2d of this module"""
+
+    def __init__(self, conv, kind):
+        super().__init__()
+        if kind not in ops.ACT_KINDS:
+            raise ValueError(f"unknown activation {kind}")
+        self.add_module("0", conv)
+        self.kind = kind
+
+    def __getitem__(self, i):
+        if i != 0:
+            raise IndexError(i)
+        return self._modules["0"]
+
+    def forward(self, x):
+        c = self._modules["0"]
+        return _ConvActFn.apply(x, c.effective_weight(), c.bias, c.stride, c.padding, self.kind)
+
+    def extra_repr(self):
+        return self.kind
+
+
+class FusedSequential(nn.Sequential):
+    """nn.Sequential with the same children and state_dict keys whose forward runs every (Conv2d, Act) neighbour pair as one autograd
+    node (_ConvActFn): the activation's backward and the convolution's bias gradient become one pass over the data"""
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], Act):
+                x = _ConvActFn.apply(x, m.effective_weight(), m.bias, m.stride, m.padding, mods[i + 1].kind)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
 
 
 class ConvTranspose2d(nn.Module):

@@ -20,7 +20,7 @@ def sequential(*args):
             modules.extend(m.children())
         elif isinstance(m, nn.Module):
             modules.append(m)
-    return nn.Sequential(*modules)
+    return G.FusedSequential(*modules)      # (same children and keys; conv + activation pairs run as one autograd node)
 
 
 _ACT = {"R": "relu", "r": "relu", "L": "lrelu", "l": "lrelu"}

@@ -80,10 +80,10 @@ class ResBlock(nn.Module):
         feature = 64
         cls = G.SpectralNormConv2d if use_spectral_norm else G.Conv2d
         self.channel_in, self.channel_out, self.feature = channel_in, channel_out, feature
-        self.conv1 = nn.Sequential(cls(channel_in, feature, 3, 1, 1), G.Act("elu"))
-        self.conv2 = nn.Sequential(cls(feature, feature, 3, 1, 1), G.Act("elu"))
-        self.conv3 = nn.Sequential(cls(feature, feature, 3, 1, 1), G.Act("elu"))
-        self.conv4 = nn.Sequential(cls(feature, feature, 3, 1, 1), G.Act("elu"))
+        self.conv1 = G.ConvAct(cls(channel_in, feature, 3, 1, 1), "elu")
+        self.conv2 = G.ConvAct(cls(feature, feature, 3, 1, 1), "elu")
+        self.conv3 = G.ConvAct(cls(feature, feature, 3, 1, 1), "elu")
+        self.conv4 = G.ConvAct(cls(feature, feature, 3, 1, 1), "elu")
         self.conv5 = G.Conv2d(feature + channel_in, channel_out, 3, 1, 1)
         if not use_spectral_norm:
             (_xavier_ if init == "xavier" else _kaiming_)([self.conv1[0], self.conv2[0], self.conv3[0], self.conv4[0]], 0.1)

@@ -51,7 +51,7 @@ class Discriminator(BaseNetwork):
         sn = use_spectral_norm
 
         def stage(cin, cout):
-            return nn.Sequential(spectral_norm_conv(cin, cout, 4, 2, 1, sn), G.Act("gelu"), spectral_norm_conv(cout, cout, 3, 1, 1, sn), G.Act("gelu"))
+            return G.FusedSequential(spectral_norm_conv(cin, cout, 4, 2, 1, sn), G.Act("gelu"), spectral_norm_conv(cout, cout, 3, 1, 1, sn), G.Act("gelu"))
 
         self.init_conv = stage(3, dim)
         self.conv1 = stage(dim, dim * 2)

@@ -1209,6 +1209,24 @@ def unary_bwd(x, gy, kind):
     return gx
 
 
+def unary_bwd_colsum(x, gy, kind, creal):
+    """(gx, db): gx = gy * act'(x) and db [creal] = the column sums of gx (the bias gradient of the convolution under the activation)
+    in one pass over the data (csrc/gelem.hip); NHWC, channel stride a multiple of 16"""
+    _need_cuda(x, gy)
+    x, gy = _nhwc(x), gy.contiguous()
+    C = x.shape[3]
+    npix = x.numel() // C
+    gx = torch.empty_like(x)
+    db = torch.empty(creal, device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    L.wm_unary_bwd_colsum_scratch_floats.restype = c_size_t
+    part = torch.empty(L.wm_unary_bwd_colsum_scratch_floats(c_size_t(npix), c_int(C)), device=x.device, dtype=torch.float32)
+    rc = L.wm_unary_bwd_colsum(_p(x), _p(gy), _p(gx), c_size_t(npix), c_int(C), c_int(ACT_KINDS[kind]), _p(part), _p(db), c_int(creal), c_int(0),
+                               c_int(dt_id(x.dtype)), _stream())
+    _lib.check(rc, "wm_unary_bwd_colsum")
+    return gx, db
+
+
 def add_scaled(a, b, alpha=1.0):
     _need_cuda(a, b)
     if a.shape != b.shape or a.dtype != b.dtype:
