@@ -174,3 +174,34 @@ def test_captured_step_replays_the_eager_step():
     y_e, loss_e = fwd_bwd()                    # the eager step on x2
     torch.cuda.synchronize()
     assert torch.equal(y_e, y2) and torch.equal(opt.grad, g2) and torch.equal(loss_e.detach(), l2.detach())
+
+
+def test_pack_plan_trains_the_same_parameters():
+    """glayers.set_pack_plan: persistent packed 3x3 weights re-packed by one launch after FlatAdamW.step give bit-identical training to
+    packing per call; an in-place torch write to a weight is noticed (autograd version) and not served from the stale pack."""
+    from video_watermarking_forgery_detection_amd import glayers as G, ops
+    PAMI, ResBlock, _ = _mods()
+    x = detgen.uniform((2, 4, 32, 32), 9).to(DEV)
+    finals = []
+    for use_plan in (False, True):
+        net = detgen.fill_f2(PAMI(dims_in=[[4, 32, 32]], block_num=[1, 1, 1], subnet_constructor=ResBlock, dtype=torch.bfloat16)).to(DEV)
+        opt = G.FlatAdamW(net, lr=1e-3)
+        plan = ops.PackPlan() if use_plan else None
+        G.set_pack_plan(plan)
+        try:
+            for step in range(4):
+                y = net(x)
+                back, mid = net(y, rev=True)
+                loss = ((y - x) ** 2).mean() + (back ** 2).mean()
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                if step == 1:                  # an in-place write the plan did not make: the next forward must see it
+                    with torch.no_grad():
+                        net.operations_down[1].s1.conv2[0].weight.mul_(0.5)
+            if use_plan:
+                assert plan.valid and len(plan.packed) > 20
+        finally:
+            G.set_pack_plan(None)
+        finals.append(opt.flat.clone())
+    assert torch.equal(finals[0], finals[1])

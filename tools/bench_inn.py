@@ -16,6 +16,9 @@ SIZE = int(os.environ.get("INN_SIZE", "256"))
 BLOCKS = [int(v) for v in os.environ.get("INN_BLOCKS", "8,8,8").split(",")]
 net = Inveritible_Decolorization_PAMI(dims_in=[[4, SIZE, SIZE]], block_num=BLOCKS, subnet_constructor=ResBlock, dtype=dt).cuda()   # the reference's init: every subnet ends in a zero conv
 opt = G.FlatAdamW(net, lr=1e-5)
+if os.environ.get("INN_PLAN", "1") == "1":
+    from video_watermarking_forgery_detection_amd import ops
+    G.set_pack_plan(ops.PackPlan())     # packed 3x3 weights: one re-pack launch per optimiser step instead of 2,800 small ones
 x = torch.rand(bs, 4, SIZE, SIZE, device="cuda")
 GRAPH = len(sys.argv) > 4 and sys.argv[4] == "graph"
 def fwd_bwd():
@@ -25,6 +28,7 @@ def fwd_bwd():
     opt.zero_grad()
     loss.backward()
     return loss
+fwd_bwd(); opt.step()                      # (one eager step: registers the packed weights, the optimiser's refresh validates the plan)
 graph = G.CapturedStep(fwd_bwd) if GRAPH else None
 if GRAPH:
     loss = graph.result

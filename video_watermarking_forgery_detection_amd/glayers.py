@@ -29,6 +29,26 @@ def _pad_bias(bias, n):
     return out
 
 
+_PLAN = None
+
+
+def set_pack_plan(plan):
+    """Route the packed 3x3 weights of plain Conv2d layers through `plan` (ops.PackPlan; None switches it off): a layer's packed
+    weight -- forward and transposed orientation -- is then a persistent tensor that ONE launch refreshes for every layer after an
+    optimiser step (FlatAdamW.step does it; with another optimiser call plan.refresh() yourself) instead of one small launch per
+    layer, call and orientation (2,800 a step in the invertible embedder).  In-place torch writes to a weight (load_state_dict, init)
+    are noticed through its autograd version and fall back to a one-off pack until the next refresh."""
+    global _PLAN
+    _PLAN = plan
+
+
+def _pack3(weight, rows, cols, dtype, transpose, plan_ok):
+    w = weight.detach()
+    if _PLAN is not None and plan_ok:
+        return _PLAN.get(w, rows, cols, dtype, transpose=transpose)
+    return ops.pack_w3x3(w, rows, cols, dtype, transpose=transpose)
+
+
 def _fast3x3(weight, stride, pad, dtype, out_stride):
     """3x3 stride-1 pad-1 convolutions on 16-bit activations whose output stride is a multiple of 32 run on the hot path's
     wave-specialised / streamed-filter kernels (csrc/conv3x3*.hip, wgrad_ws.hip) instead of the general direct kernel"""
@@ -47,13 +67,14 @@ class _ConvFn(Function):
         NC = cpad(Cout)
         OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
         if _fast3x3(weight, stride, pad, x.dtype, NC):
-            wp = ops.pack_w3x3(weight.detach(), NC, KC, x.dtype)
+            wp = _pack3(weight, NC, KC, x.dtype, False, isinstance(weight, nn.Parameter))
             out, _ = ops.conv3x3_fwd(x, wp, _pad_bias(bias, NC), None, None, want_stats=False)
         else:
             wp = ops.gconv_pack(weight.detach(), NC, KC, False, x.dtype)
             out = ops.gconv_fwd(x, wp, _pad_bias(bias, NC), (OH, OW), KH, KW, stride, pad)
         ctx.save_for_backward(x, weight)
         ctx.geo = (stride, pad, bias is not None)
+        ctx.plan_ok = isinstance(weight, nn.Parameter)       # (a computed weight -- spectral norm -- is a new tensor every call: never planned)
         return out
 
     @staticmethod
@@ -61,17 +82,17 @@ class _ConvFn(Function):
         x, weight = ctx.saved_tensors
         stride, pad, has_bias = ctx.geo
         gx, gw, gb = _conv_backward(x, weight, g.contiguous(), stride, pad, ctx.needs_input_grad[0],
-                                    ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]), has_bias)
+                                    ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]), has_bias, ctx.plan_ok)
         return gx, gw, gb, None, None
 
 
-def _conv_backward(x, weight, g, stride, pad, need_gx, need_gw, want_bias):
+def _conv_backward(x, weight, g, stride, pad, need_gx, need_gw, want_bias, plan_ok=False):
     """(gx, gw, gb) of nn.Conv2d for the output gradient g (NHWC, contiguous); gb only if want_bias"""
     Cout, Cin, KH, KW = weight.shape
     gx = gw = gb = None
     if need_gx:
         if _fast3x3(weight, stride, pad, g.dtype, x.shape[3]):
-            wt = ops.pack_w3x3(weight.detach(), g.shape[3], x.shape[3], g.dtype, transpose=True)
+            wt = _pack3(weight, g.shape[3], x.shape[3], g.dtype, True, plan_ok)
             gx, _ = ops.conv3x3_fwd(g, wt, None, None, None, want_stats=False)
         else:
             wt = ops.gconv_pack(weight.detach(), x.shape[3], g.shape[3], True, g.dtype)
@@ -103,7 +124,7 @@ class _ConvActFn(Function):
         x, weight, z = ctx.saved_tensors
         stride, pad, has_bias = ctx.geo
         gz, gb = ops.unary_bwd_colsum(z, g, ctx.kind, weight.shape[0])
-        gx, gw, _ = _conv_backward(x, weight, gz, stride, pad, ctx.needs_input_grad[0], ctx.needs_input_grad[1], False)
+        gx, gw, _ = _conv_backward(x, weight, gz, stride, pad, ctx.needs_input_grad[0], ctx.needs_input_grad[1], False, ctx.plan_ok)
         return gx, gw, (gb if has_bias and ctx.needs_input_grad[2] else None), None, None, None
 
 
@@ -621,6 +642,8 @@ class FlatAdamW:
     def step(self):
         self.t += 1
         ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t, decoupled=True)
+        if _PLAN is not None:
+            _PLAN.refresh()        # every registered packed weight from the new values, one launch
 
 
 class CapturedStep:

@@ -51,6 +51,7 @@ class IRNrhiLiteralModel(BaseModel):
         betas = (_get(train_opt, 'beta1', default=0.9), _get(train_opt, 'beta2', default=0.999))
         lr_d = _get(train_opt, 'lr_D', default=1e-4)
         # :281-335 -- torch.optim.AdamW(lr=lr_D, weight_decay=wd_G, betas) for each of the three networks
+        self._pack_plan = ops.PackPlan()
         self.optimizer_generator = G.FlatAdamW(self.generator, lr_d, betas, weight_decay=wd)
         self.optimizer_discriminator = G.FlatAdamW(self.discriminator, lr_d, betas, weight_decay=wd)
         self.optimizer_localizer = G.FlatAdamW(self.localizer, lr_d, betas, weight_decay=wd)
@@ -76,6 +77,14 @@ class IRNrhiLiteralModel(BaseModel):
 
     # ------------------------------------------------------------------ the step
     def optimize_parameters(self, step, latest_values=None, train=True, eval_dir=None):
+        prev = G._PLAN
+        G.set_pack_plan(self._pack_plan)       # the 3x3 layers' packed weights: persistent, re-packed by one launch per optimiser step
+        try:
+            return self._optimize_parameters(step, latest_values, train, eval_dir)
+        finally:
+            G.set_pack_plan(prev)
+
+    def _optimize_parameters(self, step, latest_values=None, train=True, eval_dir=None):
         self.global_step += 1
         if self.real_H is None:
             return [], []

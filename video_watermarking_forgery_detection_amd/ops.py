@@ -172,6 +172,7 @@ class PackPlan:
         self.valid = False
         self.max_elems = 0
         self._perm_dev = {}
+        self.ver = {}        # key -> the weight's autograd version at the last refresh (an in-place torch write since then = stale)
 
     @staticmethod
     def key(w, CoutP, CinP, dtype, perm, transpose):
@@ -179,7 +180,7 @@ class PackPlan:
 
     def get(self, w, CoutP, CinP, dtype, perm=None, transpose=False):
         k = self.key(w, CoutP, CinP, dtype, perm, transpose)
-        if self.valid and k in self.packed and self.jobs is not None:
+        if self.valid and k in self.packed and self.jobs is not None and self.ver.get(k) == w._version:
             return self.packed[k]
         if k not in self.req:
             self.req[k] = (w, CoutP, CinP, dtype, perm, transpose)
@@ -223,6 +224,8 @@ class PackPlan:
         rc = _lib.lib().wm_pack_w3x3_batch(_p(self.jobs), c_int(self.njobs), c_size_t(self.max_elems),
                                            c_int(dt_id(self.dtype)), _stream())
         _lib.check(rc, "wm_pack_w3x3_batch")
+        for k, req in self.req.items():
+            self.ver[k] = req[0]._version
         self.valid = True
 
 
