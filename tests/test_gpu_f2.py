@@ -205,3 +205,33 @@ def test_pack_plan_trains_the_same_parameters():
             G.set_pack_plan(None)
         finals.append(opt.flat.clone())
     assert torch.equal(finals[0], finals[1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gradients_added_into_the_flat_buffer_match_autograd(dtype):
+    """with a FlatAdamW the conv backward kernels add weight / bias gradients straight into the optimiser's flat gradient (and return
+    None to autograd); without one autograd accumulates the returned tensors -- same sums (the embedder uses every weight twice)"""
+    from video_watermarking_forgery_detection_amd import glayers as G
+    PAMI, ResBlock, _ = _mods()
+    x = detgen.uniform((2, 4, 32, 32), 11).to(DEV)
+
+    def run(net):
+        y = net(x)
+        back, mid = net(y, rev=True)
+        return ((y - x) ** 2).mean() + (back ** 2).mean() + (mid ** 2).mean()
+
+    plain = detgen.fill_f2(PAMI(dims_in=[[4, 32, 32]], block_num=[1, 1, 1], subnet_constructor=ResBlock, dtype=dtype)).to(DEV)
+    run(plain).backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in plain.parameters() if p.requires_grad])      # (the Haar filters are frozen parameters)
+    flat = detgen.fill_f2(PAMI(dims_in=[[4, 32, 32]], block_num=[1, 1, 1], subnet_constructor=ResBlock, dtype=dtype)).to(DEV)
+    opt = G.FlatAdamW(flat, lr=1e-3)
+    for _ in range(2):                      # twice: zero_grad really restarts the sums
+        opt.zero_grad()
+        run(flat).backward()
+        assert rel(opt.grad, ref) < 1e-6
+    del opt, flat                           # a collected optimiser must not leave live accumulation targets behind
+    import gc
+    gc.collect()
+    again = detgen.fill_f2(PAMI(dims_in=[[4, 32, 32]], block_num=[1, 1, 1], subnet_constructor=ResBlock, dtype=dtype)).to(DEV)
+    run(again).backward()
+    assert rel(torch.cat([p.grad.reshape(-1) for p in again.parameters() if p.requires_grad]), ref) < 1e-6

@@ -10,6 +10,8 @@ through `to_nhwc` / `to_nchw`.  There is no CPU or PyTorch fallback: every Funct
 """
 import math
 
+import weakref
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -30,6 +32,21 @@ def _pad_bias(bias, n):
 
 
 _PLAN = None
+_FLAT_GRADS = {}      # parameter data_ptr -> (weakref flat parameters, weakref flat gradients, offset, numel) of a live FlatAdamW
+
+
+def _flat_grad(ptr, numel):
+    """the slice of a live FlatAdamW's gradient buffer that belongs to the parameter at address `ptr` (None if there is none: the
+    optimiser was collected -- its addresses may have been reused -- or the tensor is not a parameter of one)"""
+    e = _FLAT_GRADS.get(ptr)
+    if e is None:
+        return None
+    flat, grad = e[0](), e[1]()
+    if flat is None or grad is None or e[3] != numel or flat.data_ptr() + 4 * e[2] != ptr:
+        if flat is None or grad is None:
+            del _FLAT_GRADS[ptr]
+        return None
+    return grad[e[2]:e[2] + e[3]]
 
 
 def set_pack_plan(plan):
@@ -75,6 +92,7 @@ class _ConvFn(Function):
         ctx.save_for_backward(x, weight)
         ctx.geo = (stride, pad, bias is not None)
         ctx.plan_ok = isinstance(weight, nn.Parameter)       # (a computed weight -- spectral norm -- is a new tensor every call: never planned)
+        ctx.bias_ptr = bias.data_ptr() if bias is not None else 0
         return out
 
     @staticmethod
@@ -82,12 +100,14 @@ class _ConvFn(Function):
         x, weight = ctx.saved_tensors
         stride, pad, has_bias = ctx.geo
         gx, gw, gb = _conv_backward(x, weight, g.contiguous(), stride, pad, ctx.needs_input_grad[0],
-                                    ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]), has_bias, ctx.plan_ok)
+                                    ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]), has_bias, ctx.plan_ok, ctx.bias_ptr)
         return gx, gw, gb, None, None
 
 
-def _conv_backward(x, weight, g, stride, pad, need_gx, need_gw, want_bias, plan_ok=False):
-    """(gx, gw, gb) of nn.Conv2d for the output gradient g (NHWC, contiguous); gb only if want_bias"""
+def _conv_backward(x, weight, g, stride, pad, need_gx, need_gw, want_bias, plan_ok=False, bias_ptr=0):
+    """(gx, gw, gb) of nn.Conv2d for the output gradient g (NHWC, contiguous); gb only if want_bias.  A parameter whose .grad is a view
+    of a FlatAdamW buffer gets its gradient ADDED there by the kernel and None returned for it (autograd would otherwise launch one
+    add per parameter and contribution: 3,200 a step in the invertible embedder, whose weights all serve twice)."""
     Cout, Cin, KH, KW = weight.shape
     gx = gw = gb = None
     if need_gx:
@@ -98,12 +118,18 @@ def _conv_backward(x, weight, g, stride, pad, need_gx, need_gw, want_bias, plan_
             wt = ops.gconv_pack(weight.detach(), x.shape[3], g.shape[3], True, g.dtype)
             gx = ops.gconv_fwd(g, wt, None, (x.shape[1], x.shape[2]), KH, KW, stride, pad, dgrad=True)
     if need_gw:
+        wacc = _flat_grad(weight.data_ptr(), weight.numel())
+        bacc = _flat_grad(bias_ptr, Cout) if want_bias else None
+        if wacc is None or (want_bias and bacc is None):
+            wacc = bacc = None
         if _fast3x3(weight, stride, pad, g.dtype, 32):      # (the weight-gradient kernels take any 8-multiple of channels)
-            gw = torch.empty(Cout, Cin, 3, 3, device=g.device, dtype=torch.float32)
-            ops.conv3x3_wgrad(x, x.shape[3], None, None, g, gw, False)
-            gb = ops.gcolsum(g, Cout) if want_bias else None
+            gw = wacc.view(Cout, Cin, 3, 3) if wacc is not None else torch.empty(Cout, Cin, 3, 3, device=g.device, dtype=torch.float32)
+            ops.conv3x3_wgrad(x, x.shape[3], None, None, g, gw, wacc is not None)
+            gb = ops.gcolsum(g, Cout, out_acc=bacc) if want_bias else None
         else:
-            gw, gb = ops.gconv_wgrad(g, x, Cout, Cin, KH, KW, stride, pad, want_bias=want_bias)
+            gw, gb = ops.gconv_wgrad(g, x, Cout, Cin, KH, KW, stride, pad, want_bias=want_bias, dw_acc=wacc, db_acc=bacc)
+        if wacc is not None:
+            gw = gb = None
     return gx, gw, gb
 
 
@@ -123,9 +149,10 @@ class _ConvActFn(Function):
     def backward(ctx, g):
         x, weight, z = ctx.saved_tensors
         stride, pad, has_bias = ctx.geo
-        gz, gb = ops.unary_bwd_colsum(z, g, ctx.kind, weight.shape[0])
+        bacc = _flat_grad(ctx.bias_ptr, weight.shape[0]) if (has_bias and ctx.needs_input_grad[2]) else None
+        gz, gb = ops.unary_bwd_colsum(z, g, ctx.kind, weight.shape[0], db_acc=bacc)
         gx, gw, _ = _conv_backward(x, weight, gz, stride, pad, ctx.needs_input_grad[0], ctx.needs_input_grad[1], False, ctx.plan_ok)
-        return gx, gw, (gb if has_bias and ctx.needs_input_grad[2] else None), None, None, None
+        return gx, gw, (gb if has_bias and ctx.needs_input_grad[2] and bacc is None else None), None, None, None
 
 
 class _ConvTFn(Function):
@@ -626,6 +653,7 @@ class FlatAdamW:
                 self.flat[o:o + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat[o:o + k].view(p.shape)
                 p.grad = self.grad[o:o + k].view(p.shape)
+                _FLAT_GRADS[p.data_ptr()] = (weakref.ref(self.flat), weakref.ref(self.grad), o, k)
                 o += k
         self.lr, self.betas, self.eps, self.weight_decay, self.t = lr, betas, eps, weight_decay, 0
 

@@ -1162,8 +1162,9 @@ def gconv_fwd(x, wp, bias, out_hw, KH, KW, stride, pad, dgrad=False):
     return out
 
 
-def gconv_wgrad(dout, x, Cout, Cin, KH, KW, stride, pad, want_bias=True):
-    """dw [Cout,Cin,KH,KW] f32, dbias [Cout] f32 (or None) of the conv x [B,IH,IW,KC] -> dout [B,OH,OW,NC]"""
+def gconv_wgrad(dout, x, Cout, Cin, KH, KW, stride, pad, want_bias=True, dw_acc=None, db_acc=None):
+    """dw [Cout,Cin,KH,KW] f32, dbias [Cout] f32 (or None) of the conv x [B,IH,IW,KC] -> dout [B,OH,OW,NC].
+    dw_acc (and db_acc when a bias gradient is wanted): contiguous f32 tensors of those shapes the results are ADDED to instead"""
     dout, x = _nhwc(dout), _nhwc(x)
     B, OH, OW, NC = dout.shape
     _, IH, IW, KC = x.shape
@@ -1173,23 +1174,31 @@ def gconv_wgrad(dout, x, Cout, Cin, KH, KW, stride, pad, want_bias=True):
     L.wm_gconv_wgrad_scratch_floats.restype = c_size_t
     partial = torch.empty(L.wm_gconv_wgrad_scratch_floats(c_int(B), c_int(OH), c_int(OW), c_int(KC), c_int(NC), c_int(KH), c_int(KW)), device=x.device,
                           dtype=torch.float32)
-    dw = torch.empty(Cout, Cin, KH, KW, device=x.device, dtype=torch.float32)
-    db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_bias else None
-    rc = _lib.lib().wm_gconv_wgrad(_p(dout), _p(x), _p(partial), _p(dw), _p(db), c_int(0), c_int(B), c_int(IH), c_int(IW), c_int(KC), c_int(OH),
+    acc = dw_acc is not None
+    if acc and (not dw_acc.is_contiguous() or dw_acc.numel() != Cout * Cin * KH * KW or dw_acc.dtype != torch.float32 or
+                (want_bias and (db_acc is None or not db_acc.is_contiguous() or db_acc.numel() != Cout or db_acc.dtype != torch.float32))):
+        raise ValueError("gconv_wgrad: accumulation targets do not match the gradients")
+    dw = dw_acc if acc else torch.empty(Cout, Cin, KH, KW, device=x.device, dtype=torch.float32)
+    db = (db_acc if acc else torch.empty(Cout, device=x.device, dtype=torch.float32)) if want_bias else None
+    rc = _lib.lib().wm_gconv_wgrad(_p(dout), _p(x), _p(partial), _p(dw), _p(db), c_int(1 if acc else 0), c_int(B), c_int(IH), c_int(IW), c_int(KC), c_int(OH),
                                    c_int(OW), c_int(NC), c_int(KH), c_int(KW), c_int(stride), c_int(pad), c_int(Cout), c_int(Cin),
                                    c_int(dt_id(x.dtype)), _stream())
     _lib.check(rc, "wm_gconv_wgrad")
     return dw, db
 
 
-def gcolsum(x, creal):
+def gcolsum(x, creal, out_acc=None):
+    """column sums [creal] f32 of x [.., C]; out_acc: a contiguous f32 [creal] tensor they are ADDED to instead"""
     x = _nhwc(x)
     C = x.shape[3]
-    out = torch.empty(creal, device=x.device, dtype=torch.float32)
+    if out_acc is not None and (not out_acc.is_contiguous() or out_acc.numel() != creal or out_acc.dtype != torch.float32):
+        raise ValueError("gcolsum: accumulation target does not match")
+    out = out_acc if out_acc is not None else torch.empty(creal, device=x.device, dtype=torch.float32)
     L = _lib.lib()
     L.wm_gcolsum_scratch_floats.restype = c_size_t
     scratch = torch.empty(L.wm_gcolsum_scratch_floats(c_size_t(x.numel() // C), c_int(C)), device=x.device, dtype=torch.float32)
-    rc = L.wm_gcolsum(_p(x), c_size_t(x.numel() // C), c_int(C), _p(out), c_int(creal), c_int(0), _p(scratch), c_int(dt_id(x.dtype)), _stream())
+    rc = L.wm_gcolsum(_p(x), c_size_t(x.numel() // C), c_int(C), _p(out), c_int(creal), c_int(0 if out_acc is None else 1), _p(scratch), c_int(dt_id(x.dtype)),
+                      _stream())
     _lib.check(rc, "wm_gcolsum")
     return out
 
@@ -1212,19 +1221,22 @@ def unary_bwd(x, gy, kind):
     return gx
 
 
-def unary_bwd_colsum(x, gy, kind, creal):
+def unary_bwd_colsum(x, gy, kind, creal, db_acc=None):
     """(gx, db): gx = gy * act'(x) and db [creal] = the column sums of gx (the bias gradient of the convolution under the activation)
-    in one pass over the data (csrc/gelem.hip); NHWC, channel stride a multiple of 16"""
+    in one pass over the data (csrc/gelem.hip); NHWC, channel stride a multiple of 16.  db_acc: added to instead (contiguous f32 [creal])"""
     _need_cuda(x, gy)
     x, gy = _nhwc(x), gy.contiguous()
     C = x.shape[3]
     npix = x.numel() // C
     gx = torch.empty_like(x)
-    db = torch.empty(creal, device=x.device, dtype=torch.float32)
+    if db_acc is not None and (not db_acc.is_contiguous() or db_acc.numel() != creal or db_acc.dtype != torch.float32):
+        raise ValueError("unary_bwd_colsum: accumulation target does not match")
+    db = db_acc if db_acc is not None else torch.empty(creal, device=x.device, dtype=torch.float32)
     L = _lib.lib()
     L.wm_unary_bwd_colsum_scratch_floats.restype = c_size_t
     part = torch.empty(L.wm_unary_bwd_colsum_scratch_floats(c_size_t(npix), c_int(C)), device=x.device, dtype=torch.float32)
-    rc = L.wm_unary_bwd_colsum(_p(x), _p(gy), _p(gx), c_size_t(npix), c_int(C), c_int(ACT_KINDS[kind]), _p(part), _p(db), c_int(creal), c_int(0),
+    rc = L.wm_unary_bwd_colsum(_p(x), _p(gy), _p(gx), c_size_t(npix), c_int(C), c_int(ACT_KINDS[kind]), _p(part), _p(db), c_int(creal),
+                               c_int(0 if db_acc is None else 1),
                                c_int(dt_id(x.dtype)), _stream())
     _lib.check(rc, "wm_unary_bwd_colsum")
     return gx, db
