@@ -525,6 +525,10 @@ int wm_bayar_constrain(float* w, int nfilters, void* stream);
  * wm_coupling_bwd: gradients wrt x, s, t from g = dL/dy; v = x for rev 0, v = the forward's OUTPUT y for rev 1. */
 int wm_haar(const void* in, void* out, int B, int H, int W, int C, int CPin, int CPout, float fac, int up, int dtype, void* stream);
 int wm_chan_copy(const void* src, void* dst, size_t npix, int sstride, int soff, int dstride, int doff, int n, int dtype, void* stream);
+/* dst [npix][dstride] written WHOLE in one launch: a's channel window [aoff, aoff + na) lands at channel adst, b's (b may be NULL) at bdst,
+ * zero elsewhere: x.narrow / torch.cat on the channel dimension (invertible_net.py:135-145, :358) and their adjoints on stride-padded NHWC. */
+int wm_chan_place(const void* a, int astride, int aoff, int adst, int na, const void* b, int bstride, int boff, int bdst, int nb, void* dst,
+                  int dstride, size_t npix, int dtype, void* stream);
 int wm_coupling_fwd(const void* x, const void* s, const void* t, void* y, size_t n, float clamp, float eps, int rev, int dtype, void* stream);
 int wm_coupling_bwd(const void* g, const void* v, const void* s, void* gx, void* gs, void* gt, size_t n, float clamp, float eps, int rev,
                     int dtype, void* stream);

@@ -81,6 +81,40 @@ __global__ __launch_bounds__(256) void chan_copy_kernel(const T* __restrict__ sr
     }
 }
 
+// dst[p][c], every c < dstride, in one launch: a[p][aoff + c - adst] for c in [adst, adst + na), b[p][boff + c - bdst] for c in [bdst, bdst + nb)
+// (b may be null), zero elsewhere -- a channel slice, its adjoint, a cat and the cat's two adjoints each as ONE fully written tensor instead
+// of a zero fill plus one or two strided copies.  VEC: every offset / count / stride is a multiple of the 16-byte vector.
+struct PlaceArgs {
+    const void* a; const void* b; void* dst;
+    size_t npix;
+    int astride, aoff, adst, na, bstride, boff, bdst, nb, dstride;
+};
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void chan_place_kernel(PlaceArgs g) {
+    constexpr int VE = VEC ? 16 / (int)sizeof(T) : 1;
+    const T* a = (const T*)g.a;
+    const T* b = (const T*)g.b;
+    T* dst = (T*)g.dst;
+    const int per = g.dstride / VE;
+    const size_t total = g.npix * per;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % per) * VE;
+        const size_t p = i / per;
+        if constexpr (VEC) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            u4 v = {0u, 0u, 0u, 0u};
+            if (c >= g.adst && c < g.adst + g.na) v = *reinterpret_cast<const u4*>(a + p * g.astride + g.aoff + (c - g.adst));
+            else if (b && c >= g.bdst && c < g.bdst + g.nb) v = *reinterpret_cast<const u4*>(b + p * g.bstride + g.boff + (c - g.bdst));
+            *reinterpret_cast<u4*>(dst + p * g.dstride + c) = v;
+        } else {
+            T v = from_f32<T>(0.f);
+            if (c >= g.adst && c < g.adst + g.na) v = a[p * g.astride + g.aoff + (c - g.adst)];
+            else if (b && c >= g.bdst && c < g.bdst + g.nb) v = b[p * g.bstride + g.boff + (c - g.bdst)];
+            dst[p * g.dstride + c] = v;
+        }
+    }
+}
+
 __device__ __forceinline__ float coupling_e(float s, float clamp, float eps) { return expf(clamp * (2.f / (1.f + expf(-s)) - 1.f)) + eps; }
 
 template <typename T>
@@ -140,6 +174,28 @@ extern "C" int wm_chan_copy(const void* src, void* dst, size_t npix, int sstride
     WM_DISPATCH_DTYPE(dtype, "wm_chan_copy",
         hipLaunchKernelGGL(chan_copy_kernel<T>, dim3(grid1(npix * n)), dim3(256), 0, s, (const T*)src, (T*)dst, npix, sstride, soff, dstride, doff, n));
     WM_LAUNCH_CHECK("wm_chan_copy");
+    return WM_OK;
+}
+
+// dst [npix][dstride], written whole: a's window [aoff, aoff + na) lands at channel adst, b's (b may be NULL) at bdst, zero elsewhere
+extern "C" int wm_chan_place(const void* a, int astride, int aoff, int adst, int na, const void* b, int bstride, int boff, int bdst, int nb, void* dst,
+                             int dstride, size_t npix, int dtype, void* stream) {
+    WM_REQUIRE(a && dst && npix > 0 && na > 0 && aoff >= 0 && adst >= 0 && aoff + na <= astride && adst + na <= dstride, WM_E_BADARG,
+               "wm_chan_place: window a [%d,%d) -> [%d,%d) outside strides %d / %d", aoff, aoff + na, adst, adst + na, astride, dstride);
+    WM_REQUIRE(!b || (nb > 0 && boff >= 0 && bdst >= 0 && boff + nb <= bstride && bdst + nb <= dstride && (bdst >= adst + na || bdst + nb <= adst)), WM_E_BADARG,
+               "wm_chan_place: window b [%d,%d) -> [%d,%d) outside strides %d / %d or over window a", boff, boff + nb, bdst, bdst + nb, bstride, dstride);
+    PlaceArgs g;
+    g.a = a; g.b = b; g.dst = dst; g.npix = npix; g.astride = astride; g.aoff = aoff; g.adst = adst; g.na = na;
+    g.bstride = b ? bstride : 0; g.boff = b ? boff : 0; g.bdst = b ? bdst : 0; g.nb = b ? nb : 0; g.dstride = dstride;
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_chan_place", {
+        const int ve = 16 / (int)sizeof(T);
+        const bool vec = !((astride | aoff | adst | na | g.bstride | g.boff | g.bdst | g.nb | dstride) % ve);
+        const size_t total = npix * (size_t)(vec ? dstride / ve : dstride);
+        if (vec) hipLaunchKernelGGL((chan_place_kernel<T, true>), dim3(grid1(total)), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((chan_place_kernel<T, false>), dim3(grid1(total)), dim3(256), 0, s, g);
+    });
+    WM_LAUNCH_CHECK("wm_chan_place");
     return WM_OK;
 }
 

@@ -481,19 +481,17 @@ class _HaarFn(Function):
 
 
 class _ChanSliceFn(Function):
-    """x[..., off:off+n] as its own NHWC tensor (stride cpad(n), padding zero)"""
+    """x[..., off:off+n] as its own NHWC tensor (stride cpad(n), padding zero); one launch each way (ops.chan_place)"""
 
     @staticmethod
     def forward(ctx, x, off, n):
-        ctx.meta = (tuple(x.shape), off, n)
-        out = torch.zeros(*x.shape[:3], cpad(n), device=x.device, dtype=x.dtype)
-        return ops.chan_copy_(out, 0, x, off, n)
+        ctx.meta = (x.shape[3], off, n)
+        return ops.chan_place(cpad(n), x, off, 0, n)
 
     @staticmethod
     def backward(ctx, g):
-        shape, off, n = ctx.meta
-        gx = torch.zeros(shape, device=g.device, dtype=g.dtype)
-        return ops.chan_copy_(gx, off, g.contiguous(), 0, n), None, None
+        stride, off, n = ctx.meta
+        return ops.chan_place(stride, g.contiguous(), 0, off, n), None, None
 
 
 class _ChanCatFn(Function):
@@ -502,17 +500,13 @@ class _ChanCatFn(Function):
     @staticmethod
     def forward(ctx, a, na, b, nb):
         ctx.meta = (na, nb)
-        out = torch.zeros(*a.shape[:3], cpad(na + nb), device=a.device, dtype=a.dtype)
-        ops.chan_copy_(out, 0, a, 0, na)
-        return ops.chan_copy_(out, na, b, 0, nb)
+        return ops.chan_place(cpad(na + nb), a, 0, 0, na, b, 0, na, nb)
 
     @staticmethod
     def backward(ctx, g):
         na, nb = ctx.meta
         g = g.contiguous()
-        ga = torch.zeros(*g.shape[:3], cpad(na), device=g.device, dtype=g.dtype)
-        gb = torch.zeros(*g.shape[:3], cpad(nb), device=g.device, dtype=g.dtype)
-        return ops.chan_copy_(ga, 0, g, 0, na), None, ops.chan_copy_(gb, 0, g, na, nb), None
+        return ops.chan_place(cpad(na), g, 0, 0, na), None, ops.chan_place(cpad(nb), g, na, 0, nb), None
 
 
 class _CouplingFn(Function):

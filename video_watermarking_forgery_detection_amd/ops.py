@@ -1419,6 +1419,24 @@ def chan_copy_(dst, doff, src, soff, n):
     return dst
 
 
+def chan_place(dstride, a, aoff, adst, na, b=None, boff=0, bdst=0, nb=0):
+    """a new NHWC tensor [.., dstride], written whole by one launch: a[..., aoff:aoff+na] at channel adst, b[..., boff:boff+nb] (optional)
+    at bdst, zero elsewhere"""
+    a = _nhwc(a)
+    if b is not None:
+        b = _nhwc(b)
+        if b.shape[:3] != a.shape[:3] or b.dtype != a.dtype:
+            raise ValueError("chan_place: pixel grids / dtypes disagree")
+    if dstride % 16:
+        raise ValueError("chan_place: the channel stride must be a multiple of 16")
+    out = torch.empty(*a.shape[:3], dstride, device=a.device, dtype=a.dtype)
+    npix = a.shape[0] * a.shape[1] * a.shape[2]
+    rc = _lib.lib().wm_chan_place(_p(a), c_int(a.shape[3]), c_int(aoff), c_int(adst), c_int(na), _p(b), c_int(b.shape[3] if b is not None else 0), c_int(boff),
+                                  c_int(bdst), c_int(nb), _p(out), c_int(dstride), c_size_t(npix), c_int(dt_id(a.dtype)), _stream())
+    _lib.check(rc, "wm_chan_place")
+    return out
+
+
 def coupling_fwd(x, s, t, clamp, eps, rev):
     _need_cuda(x, s, t)
     if not (x.shape == s.shape == t.shape and x.dtype == s.dtype == t.dtype):
