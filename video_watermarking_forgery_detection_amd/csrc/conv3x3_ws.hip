@@ -52,7 +52,13 @@ struct WsArgs {
     const hx_t* ry; const float* r_scale; const float* r_shift;   // BWDST: raw output [B,H,W,COUT] and scale / shift of the layer whose output gradient this kernel writes
     const hx_t* ay; hx_t* dy_out;   // BNBWD == 2: x is g [B,H,W,64]; ay the layer's raw output, dy_out where dy is written (both dense)
     int reverse;  // walk the workgroup's run of tiles backwards (Infinity Cache reuse of the previous kernel's tail)
+    unsigned mX, mY;   // ceil(2^32 / tilesX), ceil(2^32 / tilesY) (0 for 1): the tile index is divided by mulhi, not by ~40 scalar instructions
 };
+
+inline void ws_magic(WsArgs& a) {
+    auto m = [](int d) { return d == 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
+    a.mX = m(a.tilesX); a.mY = m(a.tilesY);
+}
 
 // 16-byte column swizzles.  Filter rows: key = (row >> 1) & 7.  Halo pixels: key = (halo column >> 1) & 7 -- it does
 // not depend on the halo ROW, so for a consumer lane the swizzled address of tap (kh, kw) is a per-(kw, k-step)
@@ -162,12 +168,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
     const int t_begin = run * a.tiles_per_wg;
     const int t_end = min(a.ntiles, t_begin + a.tiles_per_wg);
     struct TileGeo { int b, ty0, tx0; };
+    // (exact while index * divisor < 2^32: the launchers check)
+    auto fdiv = [](int t, int d, unsigned m) { return d == 1 ? t : (int)__umulhi((unsigned)t, m); };
     auto geo = [&](int tile) {
         TileGeo g;
-        int t = a.reverse ? t_begin + (t_end - 1 - tile) : tile;
-        const int txi = t % a.tilesX; t /= a.tilesX;
-        const int tyi = t % a.tilesY; t /= a.tilesY;
-        g.b = t; g.ty0 = tyi * TH; g.tx0 = txi * TW;
+        const int t = a.reverse ? t_begin + (t_end - 1 - tile) : tile;
+        const int q1 = fdiv(t, a.tilesX, a.mX), txi = t - q1 * a.tilesX;
+        const int q2 = fdiv(q1, a.tilesY, a.mY), tyi = q1 - q2 * a.tilesY;
+        g.b = q2; g.ty0 = tyi * TH; g.tx0 = txi * TW;
         return g;
     };
 
@@ -236,7 +244,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         // does tile T start with the two columns its predecessor in the run ended with?
         auto reuse_of = [&](int T) {
             if (!(EDGE && BNBWD != 2 && !(a.dbg & 64) && T > t_begin)) return false;
-            return a.reverse ? ((t_begin + (t_end - 1 - T)) % a.tilesX) != a.tilesX - 1 : (T % a.tilesX) != 0;
+            const int tt = a.reverse ? t_begin + (t_end - 1 - T) : T;
+            const int col = tt - fdiv(tt, a.tilesX, a.mX) * a.tilesX;
+            return a.reverse ? col != a.tilesX - 1 : col != 0;
         };
         // loads: always a valid address, never under a per-lane branch; the branches on `interior` are wave-uniform
         auto is_interior = [&](const TileGeo& g) {
@@ -807,7 +817,7 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
     a.dbg = dbg; a.xcd_map = 1;
     a.x = (const hx_t*)x; a.ldx = 64; a.wp = (const hx_t*)wp; a.bias = nullptr; a.nbias = 0; a.in_scale = in_scale;
     a.in_shift = in_shift; a.y = (hx_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
-    a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY;
+    a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY; ws_magic(a);
     const int wgs = a.ntiles < 256 ? a.ntiles : 256;
     a.tiles_per_wg = wm_cdiv(a.ntiles, wgs); a.reverse = 0; a.bw_stats4 = nullptr; a.bw_ld = 0; a.bw_coef = nullptr; a.bw_gvec = nullptr; a.ry = nullptr; a.r_scale = nullptr; a.r_shift = nullptr; a.ay = nullptr; a.dy_out = nullptr;
     const dim3 grid((unsigned)wm_cdiv(a.ntiles, a.tiles_per_wg)), block(512);
@@ -846,7 +856,8 @@ int WM_HSYM(wm_launch_conv3x3_ws)(const void* x, int ldx, int Cin, int CoutP, co
     a.dbg = g_ws_variant == 3 ? 8 : (g_ws_variant == 8 ? 64 : (g_ws_variant == 10 ? 128 : 0)); a.xcd_map = g_ws_variant != 2;
     a.x = (const hx_t*)x; a.ldx = ldx; a.wp = (const hx_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
     a.in_shift = in_shift; a.y = (hx_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
-    a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY; a.tiles_per_wg = tiles_per_wg;
+    a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY; ws_magic(a); a.tiles_per_wg = tiles_per_wg;
+    if ((long long)a.ntiles * (a.tilesX > a.tilesY ? a.tilesX : a.tilesY) >= (1LL << 32)) return WM_E_SHAPE;   // (the mulhi tile geometry's range)
     a.reverse = wm_sweep_dir(reverse);
     a.bw_stats4 = bw_stats4; a.bw_ld = bw_ld; a.bw_coef = bw_coef; a.bw_gvec = bw_gvec;
     a.ry = (const hx_t*)ry; a.r_scale = r_scale; a.r_shift = r_shift;
