@@ -98,10 +98,39 @@ __global__ __launch_bounds__(256) void gconv_kernel(GArgs a) {
         arow[f] = n0 + 16 * (p >> 2) + 4 * f + (p & 3);
         aok[f] = arow[f] < a.NC;
     }
+    const int taps = a.KH * a.KW;
+    if (a.NC - n0 <= 16) {
+        // narrow output (<= 16 channels left in this block: the subnets' 72 -> 8 convolutions, input gradients towards 8 / 3 channels, the 5x5
+        // Bayar layer): ONE filter fragment whose row r is channel n0 + r -- a quarter of the MFMAs and filter loads of the 64-channel form
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+        const int row = n0 + p;
+        const bool rok = row < a.NC;
+        for (int tap = 0; tap < taps; ++tap) {
+            const int ky = tap / a.KW, kx = tap - ky * a.KW;
+            int sy = 0, sx = 0;
+            const bool ok = src_of(a, oy, ox, ky, kx, sy, sx) && pok;
+            if (__ballot(ok) == 0) continue;
+            const T* px = in + (((size_t)b * a.IH + (ok ? sy : 0)) * a.IW + (ok ? sx : 0)) * a.KC;
+            const T* wt = w + ((size_t)tap * a.NC + (rok ? row : 0)) * a.KC;
+            for (int c0 = 0; c0 < a.KC; c0 += Op::KSTEP) {
+                const int krem = a.KC - c0;
+                const typename Op::frag bf = ok ? Op::load(px + c0, q, krem) : Op::zero();
+                const typename Op::frag af = rok ? Op::load(wt + c0, q, krem) : Op::zero();
+                acc1 = Op::mma(af, bf, acc1);
+            }
+        }
+        // lane (p, q): channels n0 + 4 q + i of pixel p
+        const int cb = n0 + 4 * q;
+        if (pok && cb < a.NC) {
+            T* o = (T*)a.out + pix * a.NC + cb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = from_f32<T>(acc1[i] + (a.bias ? a.bias[cb + i] : 0.f));
+        }
+        return;
+    }
     f32x4 acc[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int taps = a.KH * a.KW;
     for (int tap = 0; tap < taps; ++tap) {
         const int ky = tap / a.KW, kx = tap - ky * a.KW;
         int sy = 0, sx = 0;
