@@ -512,8 +512,14 @@ __global__ __launch_bounds__(256) void gcolsum_kernel(const T* __restrict__ x, s
 __global__ __launch_bounds__(1024) void gcolsum_reduce_kernel(const float* __restrict__ part, int nsplit, int C, float* __restrict__ out, int Creal, int accumulate) {
     const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, sub = threadIdx.x >> 6;
     float s = 0.f;
-    if (c < Creal)
-        for (int k = sub; k < nsplit; k += 16) s += part[(size_t)k * C + c];
+    if (c < Creal) {
+        int k = sub;
+        for (; k + 48 < nsplit; k += 64) {   // four loads in flight
+            const float r0 = part[(size_t)k * C + c], r1 = part[(size_t)(k + 16) * C + c], r2 = part[(size_t)(k + 32) * C + c], r3 = part[(size_t)(k + 48) * C + c];
+            s += r0; s += r1; s += r2; s += r3;
+        }
+        for (; k < nsplit; k += 16) s += part[(size_t)k * C + c];
+    }
     __shared__ float sh[16][64];
     sh[sub][cl] = s;
     __syncthreads();
@@ -524,9 +530,9 @@ __global__ __launch_bounds__(1024) void gcolsum_reduce_kernel(const float* __res
         out[c] = (accumulate ? out[c] : 0.f) + r;
     }
 }
-inline int colsum_nsplit(size_t npix) {   // >= 256 pixels per split, at most 1024 splits (streaming kernels want ~4 workgroups per CU in flight)
+inline int colsum_nsplit(size_t npix) {   // >= 256 pixels per split, at most 512 splits (2 workgroups per CU; the reduce reads them all from one)
     const size_t n = (npix + 255) / 256;
-    return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
+    return (int)(n < 1 ? 1 : (n > 512 ? 512 : n));
 }
 
 inline int grid1(size_t n, int cap = 4096) {

@@ -102,8 +102,14 @@ __global__ __launch_bounds__(256) void unary_bwd_colsum_kernel(const T* __restri
 __global__ __launch_bounds__(1024) void ubc_reduce_kernel(const float* __restrict__ part, int nsplit, int C, float* __restrict__ out, int Creal, int accumulate) {
     const int cl = threadIdx.x & 63, sub = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float t = 0.f;
-    if (c < Creal)
-        for (int k = sub; k < nsplit; k += 16) t += part[(size_t)k * C + c];
+    if (c < Creal) {
+        int k = sub;
+        for (; k + 48 < nsplit; k += 64) {   // four loads in flight (one workgroup reads every split of its 64 channels: latency, not bandwidth)
+            const float r0 = part[(size_t)k * C + c], r1 = part[(size_t)(k + 16) * C + c], r2 = part[(size_t)(k + 32) * C + c], r3 = part[(size_t)(k + 48) * C + c];
+            t += r0; t += r1; t += r2; t += r3;
+        }
+        for (; k < nsplit; k += 16) t += part[(size_t)k * C + c];
+    }
     __shared__ float sh[16][64];
     sh[sub][cl] = t;
     __syncthreads();
@@ -114,9 +120,9 @@ __global__ __launch_bounds__(1024) void ubc_reduce_kernel(const float* __restric
         out[c] = (accumulate ? out[c] : 0.f) + r;
     }
 }
-inline int ubc_nsplit(size_t npix) {   // >= 128 pixels per split, at most 1024 splits: 4 workgroups per CU keep enough loads in flight
+inline int ubc_nsplit(size_t npix) {   // >= 128 pixels per split, at most 512 splits (2 workgroups per CU; the reduce reads them all from one)
     const size_t n = (npix + 127) / 128;
-    return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
+    return (int)(n < 1 ? 1 : (n > 512 ? 512 : n));
 }
 // out = a + alpha * b
 template <typename T>
