@@ -157,7 +157,7 @@ def test_activation_backward_with_the_bias_gradient():
             for _ in range(2):
                 gx, db = ops.unary_bwd_colsum(x, g, kind, creal)
                 assert rel(gx, gx0) <= {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype], (dtype, C, kind)   # (gelu's FMA contraction may differ by an ulp between the two kernels)
-                assert rel(db, db0) < 1e-5, (dtype, C)
+                assert rel(db, db0) < 1e-4, (dtype, C)      # (f32 sums of +- terms in two different orders)
     torch.manual_seed(0)
     seq = G.FusedSequential(G.Conv2d(5, 24, 3, 1, 1), G.Act("elu"), G.Conv2d(24, 24, 4, 2, 1), G.Act("relu"), G.Conv2d(24, 7, 1, 1, 0)).to(DEV)
     x = detgen.normal((2, 5, 12, 12), 3).to(DEV)

@@ -38,14 +38,41 @@ inline int grid1(size_t n, int cap = 4096) {
     return (int)(g > (size_t)cap ? cap : (g < 1 ? 1 : g));
 }
 
-template <typename T>
+// element-wise kernels: 16-byte vectors when the length and the pointers allow (NHWC tensors with a stride-16 channel dimension always
+// do), the scalar loop for the rest (VEC = false)
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void unary_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n, int kind) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = from_f32<T>(act_f(kind, to_f32(x[i])));
+    if constexpr (VEC) {
+        constexpr int VE = vec16<T>::N;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / VE; i += (size_t)gridDim.x * blockDim.x) {
+            const vec16<T> v = reinterpret_cast<const vec16<T>*>(x)[i];
+            vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) o.set(e, act_f(kind, v.get(e)));
+            reinterpret_cast<vec16<T>*>(y)[i] = o;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = from_f32<T>(act_f(kind, to_f32(x[i])));
+    }
 }
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void unary_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ gx, size_t n, int kind) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        gx[i] = from_f32<T>(to_f32(gy[i]) * act_d(kind, to_f32(x[i])));
+    if constexpr (VEC) {
+        constexpr int VE = vec16<T>::N;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / VE; i += (size_t)gridDim.x * blockDim.x) {
+            const vec16<T> v = reinterpret_cast<const vec16<T>*>(x)[i], g = reinterpret_cast<const vec16<T>*>(gy)[i];
+            vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) o.set(e, g.get(e) * act_d(kind, v.get(e)));
+            reinterpret_cast<vec16<T>*>(gx)[i] = o;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+            gx[i] = from_f32<T>(to_f32(gy[i]) * act_d(kind, to_f32(x[i])));
+    }
+}
+inline bool vec_ok(size_t n, int elem, const void* a, const void* b, const void* c = nullptr) {
+    return n % (16 / elem) == 0 && !(((size_t)a | (size_t)b | (size_t)c) & 15);
 }
 // gx = gy * act'(x) AND the split partials of its column sums as stored (the bias gradient of the convolution that fed the activation) in
 // one pass -- two launches (this + the reduce) instead of three, and gx is not read back: grid (64-channel blocks, pixel splits), thread
@@ -125,10 +152,21 @@ inline int ubc_nsplit(size_t npix) {   // >= 128 pixels per split, at most 512 s
     return (int)(n < 1 ? 1 : (n > 512 ? 512 : n));
 }
 // out = a + alpha * b
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, size_t n, float alpha) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = from_f32<T>(to_f32(a[i]) + alpha * to_f32(b[i]));
+    if constexpr (VEC) {
+        constexpr int VE = vec16<T>::N;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / VE; i += (size_t)gridDim.x * blockDim.x) {
+            const vec16<T> va = reinterpret_cast<const vec16<T>*>(a)[i], vb = reinterpret_cast<const vec16<T>*>(b)[i];
+            vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) o.set(e, va.get(e) + alpha * vb.get(e));
+            reinterpret_cast<vec16<T>*>(out)[i] = o;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+            out[i] = from_f32<T>(to_f32(a[i]) + alpha * to_f32(b[i]));
+    }
 }
 // QFAttention: out[b,p,c] = x + gamma[b,c] * res + beta[b,c]
 template <typename T>
@@ -387,14 +425,21 @@ __global__ void bayar_kernel(float* __restrict__ w, int nfilters) {
 extern "C" int wm_unary_fwd(const void* x, void* y, size_t n, int kind, int dtype, void* stream) {
     WM_REQUIRE(x && y && n > 0 && kind >= 0 && kind <= 5, WM_E_BADARG, "wm_unary_fwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    WM_DISPATCH_DTYPE(dtype, "wm_unary_fwd", hipLaunchKernelGGL(unary_fwd_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, (const T*)x, (T*)y, n, kind));
+    WM_DISPATCH_DTYPE(dtype, "wm_unary_fwd", {
+        if (vec_ok(n, (int)sizeof(T), x, y)) hipLaunchKernelGGL((unary_fwd_kernel<T, true>), dim3(grid1(n / (16 / sizeof(T)))), dim3(256), 0, s, (const T*)x, (T*)y, n, kind);
+        else hipLaunchKernelGGL((unary_fwd_kernel<T, false>), dim3(grid1(n)), dim3(256), 0, s, (const T*)x, (T*)y, n, kind);
+    });
     WM_LAUNCH_CHECK("wm_unary_fwd");
     return WM_OK;
 }
 extern "C" int wm_unary_bwd(const void* x, const void* gy, void* gx, size_t n, int kind, int dtype, void* stream) {
     WM_REQUIRE(x && gy && gx && n > 0 && kind >= 0 && kind <= 5, WM_E_BADARG, "wm_unary_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    WM_DISPATCH_DTYPE(dtype, "wm_unary_bwd", hipLaunchKernelGGL(unary_bwd_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, (const T*)x, (const T*)gy, (T*)gx, n, kind));
+    WM_DISPATCH_DTYPE(dtype, "wm_unary_bwd", {
+        if (vec_ok(n, (int)sizeof(T), x, gy, gx))
+            hipLaunchKernelGGL((unary_bwd_kernel<T, true>), dim3(grid1(n / (16 / sizeof(T)))), dim3(256), 0, s, (const T*)x, (const T*)gy, (T*)gx, n, kind);
+        else hipLaunchKernelGGL((unary_bwd_kernel<T, false>), dim3(grid1(n)), dim3(256), 0, s, (const T*)x, (const T*)gy, (T*)gx, n, kind);
+    });
     WM_LAUNCH_CHECK("wm_unary_bwd");
     return WM_OK;
 }
@@ -416,7 +461,11 @@ extern "C" int wm_unary_bwd_colsum(const void* x, const void* gy, void* gx, size
 extern "C" int wm_add_scaled(const void* a, const void* b, void* out, size_t n, float alpha, int dtype, void* stream) {
     WM_REQUIRE(a && b && out && n > 0, WM_E_BADARG, "wm_add_scaled: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    WM_DISPATCH_DTYPE(dtype, "wm_add_scaled", hipLaunchKernelGGL(add_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, (const T*)a, (const T*)b, (T*)out, n, alpha));
+    WM_DISPATCH_DTYPE(dtype, "wm_add_scaled", {
+        if (vec_ok(n, (int)sizeof(T), a, b, out))
+            hipLaunchKernelGGL((add_kernel<T, true>), dim3(grid1(n / (16 / sizeof(T)))), dim3(256), 0, s, (const T*)a, (const T*)b, (T*)out, n, alpha);
+        else hipLaunchKernelGGL((add_kernel<T, false>), dim3(grid1(n)), dim3(256), 0, s, (const T*)a, (const T*)b, (T*)out, n, alpha);
+    });
     WM_LAUNCH_CHECK("wm_add_scaled");
     return WM_OK;
 }
