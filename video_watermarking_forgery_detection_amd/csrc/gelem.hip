@@ -183,26 +183,54 @@ __global__ __launch_bounds__(256) void qfatt_fwd_kernel(const T* __restrict__ x,
 template <typename T>
 __global__ __launch_bounds__(256) void qfatt_bwd_kernel(const T* __restrict__ g, const T* __restrict__ res, const float* __restrict__ gamma,
                                                         T* __restrict__ gres, float* __restrict__ part, size_t hw, int C, int ldv) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, b = blockIdx.y;
+    // a thread owns one 16-byte vector (VE channels) of the block's cw <= 64 channels and every PL-th pixel of the split (gcolsum's layout)
+    constexpr int VE = 16 / sizeof(T), MAXPL = 256 / (16 / VE);
+    const int cw = min(64, C - (int)blockIdx.x * 64), nv = cw / VE, PL = 256 / nv;
+    const int v = threadIdx.x % nv, pl = threadIdx.x / nv, b = blockIdx.y;
+    const int c0 = blockIdx.x * 64 + v * VE;
     const size_t per = (hw + gridDim.z - 1) / gridDim.z, p0 = (size_t)blockIdx.z * per, p1 = p0 + per < hw ? p0 + per : hw;
-    float s1 = 0.f, s2 = 0.f;
-    if (c < C) {
-        const float gm = gamma[(size_t)b * ldv + c];
-        for (size_t p = p0 + sub; p < p1; p += 4) {
-            const size_t i = ((size_t)b * hw + p) * C + c;
-            const float gv = to_f32(g[i]), rv = to_f32(res[i]);
-            gres[i] = from_f32<T>(gm * gv);
-            s1 += gv * rv;
-            s2 += gv;
+    float s1[VE], s2[VE], gm[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { s1[e] = 0.f; s2[e] = 0.f; gm[e] = pl < PL ? gamma[(size_t)b * ldv + c0 + e] : 0.f; }
+    auto one = [&](const vec16<T>& gv, const vec16<T>& rv, size_t p) {
+        vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            const float gg = gv.get(e);
+            o.set(e, gm[e] * gg);
+            s1[e] += gg * rv.get(e);
+            s2[e] += gg;
+        }
+        *reinterpret_cast<vec16<T>*>(gres + ((size_t)b * hw + p) * C + c0) = o;
+    };
+    if (pl < PL) {
+        size_t p = p0 + pl;
+        for (; p + PL < p1; p += 2 * (size_t)PL) {   // four loads in flight per thread
+            const size_t i0 = ((size_t)b * hw + p) * C + c0, i1 = ((size_t)b * hw + p + PL) * C + c0;
+            const vec16<T> g0 = *reinterpret_cast<const vec16<T>*>(g + i0), r0 = *reinterpret_cast<const vec16<T>*>(res + i0);
+            const vec16<T> g1 = *reinterpret_cast<const vec16<T>*>(g + i1), r1 = *reinterpret_cast<const vec16<T>*>(res + i1);
+            one(g0, r0, p); one(g1, r1, p + PL);
+        }
+        for (; p < p1; p += PL) {
+            const size_t i0 = ((size_t)b * hw + p) * C + c0;
+            one(*reinterpret_cast<const vec16<T>*>(g + i0), *reinterpret_cast<const vec16<T>*>(res + i0), p);
         }
     }
-    __shared__ float sh[2][4][64];
-    sh[0][sub][threadIdx.x & 63] = s1; sh[1][sub][threadIdx.x & 63] = s2;
-    __syncthreads();
-    if (sub == 0 && c < C) {
-        float* o = part + (((size_t)blockIdx.z * gridDim.y + b) * 2) * ldv;
-        o[c] = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
-        o[ldv + c] = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
+    __shared__ float sh[MAXPL][65];
+    float* o = part + (((size_t)blockIdx.z * gridDim.y + b) * 2) * ldv;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        if (pl < PL) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) sh[pl][v * VE + e] = which ? s2[e] : s1[e];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < cw) {
+            float t = 0.f;
+            for (int k = 0; k < PL; ++k) t += sh[k][threadIdx.x];
+            o[which * ldv + blockIdx.x * 64 + threadIdx.x] = t;
+        }
+        __syncthreads();
     }
 }
 __global__ __launch_bounds__(256) void qfatt_bwd_reduce_kernel(const float* __restrict__ part, int nsplit, int B, int C, int ldv, float* __restrict__ ggamma,
