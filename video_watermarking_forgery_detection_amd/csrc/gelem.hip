@@ -339,15 +339,34 @@ __global__ __launch_bounds__(256) void unpack_bwd_kernel(const float* __restrict
 }
 
 // ---- spectral norm (torch.nn.utils.spectral_norm, one power iteration): W [M][N] f32 = weight_orig.view(Cout, -1)
-//   v = normalize(W^T u), u = normalize(W v), sigma = u . (W v); eps = 1e-12.  Four small launches (the matrix is read twice, by many
-//   workgroups): column pass, its norm, row pass, its norm + sigma.  scratch: f32 [N + M + 2 * 256 + 4]
-__global__ __launch_bounds__(256) void sn_cols_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ vraw, float* __restrict__ part,
-                                                      int M, int N) {
+//   v = normalize(W^T u), u = normalize(W v), sigma = u . (W v); eps = 1e-12.  Five small launches (the matrix is read twice, by many
+//   workgroups): column pass (slices, their sum), its norm, row pass, its norm + sigma.  scratch: wm_spectral_norm_scratch_floats(M, N)
+// column pass in two stages (a thread per column walking all M rows left 18 workgroups with 512 dependent loads each: 75 us for a 9 MB
+// matrix): row slices of SN_ROWS rows x column blocks -> slice partials [RS][N]; then the slices are summed per column in a fixed order
+constexpr int SN_ROWS = 32;
+__global__ __launch_bounds__(256) void sn_cols_part_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ partial, int M, int N) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * SN_ROWS, r1 = min(M, r0 + SN_ROWS);
+    if (j >= N) return;
+    float s = 0.f;
+    int i = r0;
+    for (; i + 7 < r1; i += 8) {
+        float w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = W[(size_t)(i + k) * N + j];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += w[k] * u[i + k];
+    }
+    for (; i < r1; ++i) s += W[(size_t)i * N + j] * u[i];
+    partial[(size_t)blockIdx.y * N + j] = s;
+}
+__global__ __launch_bounds__(256) void sn_cols_sum_kernel(const float* __restrict__ partial, int RS, float* __restrict__ vraw, float* __restrict__ part, int N) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     float s = 0.f;
-    if (j < N)
-        for (int i = 0; i < M; ++i) s += W[(size_t)i * N + j] * u[i];
-    if (j < N) vraw[j] = s;
+    if (j < N) {
+        for (int k = 0; k < RS; ++k) s += partial[(size_t)k * N + j];
+        vraw[j] = s;
+    }
     float q = wave_sum(s * s);
     __shared__ float sh[4];
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = q;
@@ -584,7 +603,9 @@ extern "C" int wm_gunpack_nchw_bwd(const float* g, void* gx, int B, int C, int H
 }
 
 // u [M], v [N] updated in place when do_iter != 0 (training); sigma [1]; then Wsn = W / sigma.  scratch: wm_spectral_norm_scratch_floats(M, N)
-extern "C" size_t wm_spectral_norm_scratch_floats(int M, int N) { return (size_t)N + M + (size_t)((N + 255) / 256) + 8; }
+extern "C" size_t wm_spectral_norm_scratch_floats(int M, int N) {
+    return (size_t)N + M + (size_t)((N + 255) / 256) + 8 + (size_t)((M + SN_ROWS - 1) / SN_ROWS) * N;
+}
 extern "C" int wm_spectral_norm_fwd(const float* W, float* u, float* v, float* sigma, float* Wsn, float* scratch, int M, int N, int do_iter, void* stream) {
     WM_REQUIRE(W && u && v && sigma && Wsn && scratch && M > 0 && N > 0, WM_E_BADARG, "wm_spectral_norm_fwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
@@ -593,7 +614,10 @@ extern "C" int wm_spectral_norm_fwd(const float* W, float* u, float* v, float* s
     float* part = scratch + N + M;
     const int nb = (N + 255) / 256;
     if (do_iter) {
-        hipLaunchKernelGGL(sn_cols_kernel, dim3(nb), dim3(256), 0, s, W, u, vraw, part, M, N);
+        const int RS = (M + SN_ROWS - 1) / SN_ROWS;
+        float* slices = scratch + N + M + nb + 8;
+        hipLaunchKernelGGL(sn_cols_part_kernel, dim3(nb, RS), dim3(256), 0, s, W, u, slices, M, N);
+        hipLaunchKernelGGL(sn_cols_sum_kernel, dim3(nb), dim3(256), 0, s, slices, RS, vraw, part, N);
         hipLaunchKernelGGL(sn_vnorm_kernel, dim3(1), dim3(256), 0, s, vraw, part, nb, v, N, 1e-12f);
     }
     hipLaunchKernelGGL(sn_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, W, v, wv, M, N);
