@@ -566,6 +566,33 @@ extern "C" int wm_gconv_pack(const float* w, void* wp, int Cout, int Cin, int KH
 // forward (dgrad == 0): in [B,IH,IW,KC], w [KH*KW][NC][KC] (wm_gconv_pack transpose 0), out [B,OH,OW,NC], OH = (IH + 2 pad - KH)/stride + 1.
 // input gradient / ConvTranspose2d forward (dgrad == 1): in = dout [B,IH,IW,KC] on the conv's OUTPUT grid, w [KH*KW][NC][KC] (pack with
 // transpose 1: rows = the conv's input channels), out = din [B,OH,OW,NC] on the conv's INPUT grid.
+// nn.Linear on a handful of rows (the QF embedding MLPs, the predictor heads: [B <= 64][K] x [N][K]^T): the direct kernel above walks K
+// serially with five dependent global loads per 4-wide MFMA step (38 us for 24 x 512 x 512).  Here a wave owns one output column n, its
+// lanes stride K (coalesced filter row), the rows' partial dots are reduced across the wave; out[p][n] = bias[n] + sum_k in[p][k] w[n][k].
+template <typename T, int PMAX>
+__global__ __launch_bounds__(256) void glinear_small_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
+                                                            int P, int KC, int NC) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= NC) return;
+    float acc[PMAX];
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) acc[p] = 0.f;
+    for (int k = lane; k < KC; k += 64) {
+        const float wv = to_f32(w[(size_t)n * KC + k]);
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p)
+            if (p < P) acc[p] = __builtin_fmaf(to_f32(in[(size_t)p * KC + k]), wv, acc[p]);
+    }
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) {
+        if (p < P) {      // (wave-uniform)
+            const float t = wave_sum(acc[p]);
+            if (lane == 0) out[(size_t)p * NC + n] = from_f32<T>(t + bv);
+        }
+    }
+}
+
 extern "C" int wm_gconv_fwd(const void* in, const void* w, const float* bias, void* out, int B, int IH, int IW, int KC, int OH, int OW, int NC,
                             int KH, int KW, int stride, int pad, int dgrad, int dtype, void* stream) {
     WM_REQUIRE(in && w && out, WM_E_BADARG, "wm_gconv_fwd: null pointer");
@@ -578,6 +605,12 @@ extern "C" int wm_gconv_fwd(const void* in, const void* w, const float* bias, vo
     const size_t npix = (size_t)B * OH * OW;
     const dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((NC + 63) / 64));
     hipStream_t s = (hipStream_t)stream;
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && npix <= 32 && IH == OH && IW == OW) {   // a Linear layer on a few rows (either direction)
+        WM_DISPATCH_DTYPE(dtype, "wm_gconv_fwd",
+            hipLaunchKernelGGL((glinear_small_kernel<T, 32>), dim3((unsigned)((NC + 3) / 4)), dim3(256), 0, s, (const T*)in, (const T*)w, bias, (T*)out, (int)npix, KC, NC));
+        WM_LAUNCH_CHECK("wm_gconv_fwd(linear)");
+        return WM_OK;
+    }
     WM_DISPATCH_DTYPE(dtype, "wm_gconv_fwd", hipLaunchKernelGGL(gconv_kernel<T>, grid, dim3(256), 0, s, a));
     WM_LAUNCH_CHECK("wm_gconv_fwd");
     return WM_OK;
