@@ -628,7 +628,9 @@ def clamp01(x):
 class FlatAdamW:
     """torch.optim.AdamW over ONE flat f32 buffer holding every trainable parameter of `module` (each nn.Parameter becomes a view of
     it, each .grad a view of a flat gradient buffer autograd accumulates into): zero_grad = one memset, clip_grad_norm_ = one norm,
-    step = one launch of the library's Adam kernel with decoupled weight decay."""
+    step = one launch of the library's Adam kernel with decoupled weight decay.  While the optimiser lives, the convolution backward
+    kernels ADD a registered parameter's gradient straight into the flat buffer and hand autograd None for it (_conv_backward): use
+    loss.backward(); torch.autograd.grad(loss, parameters) would see None for those parameters and still change the buffer."""
 
     def __init__(self, module, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
         ps = [p for p in module.parameters() if p.requires_grad]
