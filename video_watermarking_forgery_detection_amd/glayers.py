@@ -72,27 +72,32 @@ def _fast3x3(weight, stride, pad, dtype, out_stride):
     return (dtype in (torch.bfloat16, torch.float16) and tuple(weight.shape[2:]) == (3, 3) and stride == 1 and pad == 1 and out_stride % 32 == 0)
 
 
+def _conv_forward(ctx, x, weight, bias, stride, pad):
+    """the convolution itself + what both autograd nodes below keep for their backward (everything but the saved tensors)"""
+    Cout, Cin, KH, KW = weight.shape
+    B, IH, IW, KC = x.shape
+    if KC != cpad(Cin):
+        raise ValueError(f"conv expects {Cin} input channels (stride {cpad(Cin)}), the activation has stride {KC}")
+    NC = cpad(Cout)
+    OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
+    ctx.geo = (stride, pad, bias is not None)
+    ctx.plan_ok = isinstance(weight, nn.Parameter)       # (a computed weight -- spectral norm -- is a new tensor every call: never planned)
+    ctx.bias_ptr = bias.data_ptr() if bias is not None else 0
+    if _fast3x3(weight, stride, pad, x.dtype, NC):
+        wp = _pack3(weight, NC, KC, x.dtype, False, ctx.plan_ok)
+        out, _ = ops.conv3x3_fwd(x, wp, _pad_bias(bias, NC), None, None, want_stats=False)
+        return out
+    wp = ops.gconv_pack(weight.detach(), NC, KC, False, x.dtype)
+    return ops.gconv_fwd(x, wp, _pad_bias(bias, NC), (OH, OW), KH, KW, stride, pad)
+
+
 class _ConvFn(Function):
     """nn.Conv2d on NHWC: weight [Cout,Cin,KH,KW] f32"""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad):
-        Cout, Cin, KH, KW = weight.shape
-        B, IH, IW, KC = x.shape
-        if KC != cpad(Cin):
-            raise ValueError(f"conv expects {Cin} input channels (stride {cpad(Cin)}), the activation has stride {KC}")
-        NC = cpad(Cout)
-        OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
-        if _fast3x3(weight, stride, pad, x.dtype, NC):
-            wp = _pack3(weight, NC, KC, x.dtype, False, isinstance(weight, nn.Parameter))
-            out, _ = ops.conv3x3_fwd(x, wp, _pad_bias(bias, NC), None, None, want_stats=False)
-        else:
-            wp = ops.gconv_pack(weight.detach(), NC, KC, False, x.dtype)
-            out = ops.gconv_fwd(x, wp, _pad_bias(bias, NC), (OH, OW), KH, KW, stride, pad)
+        out = _conv_forward(ctx, x, weight, bias, stride, pad)
         ctx.save_for_backward(x, weight)
-        ctx.geo = (stride, pad, bias is not None)
-        ctx.plan_ok = isinstance(weight, nn.Parameter)       # (a computed weight -- spectral norm -- is a new tensor every call: never planned)
-        ctx.bias_ptr = bias.data_ptr() if bias is not None else 0
         return out
 
     @staticmethod
@@ -139,8 +144,7 @@ class _ConvActFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, kind):
-        with torch.no_grad():
-            z = _ConvFn.forward(ctx, x, weight, bias, stride, pad)
+        z = _conv_forward(ctx, x, weight, bias, stride, pad)
         ctx.save_for_backward(x, weight, z)
         ctx.kind = kind
         return ops.unary_fwd(z, kind)
