@@ -209,7 +209,9 @@ int wm_conv3x3_dgrad_gvfused(const void* y, int ldy, int CoutY, const void* wpt,
  * ConvBNRelu that FEEDS this layer (conv_bn_relu.py:11-15 stacked as in decoder.py:16-24): dx is that layer's g, and with
  * its raw output ry [B,H,W,64] and r_scale / r_shift the kernel emits partials f32[wm_conv3x3_nparts(..)][2][64] =
  * sum(gz), sum(gz*y) per channel (gz = bf16(dx)*[r_scale*ry + r_shift > 0]) -- wm_bn_bwd_reduce over (dx, ry) is not
- * needed; finish with wm_bn_bwd_finalize_raw.  src = this layer's dy, or (gvec, stats4, coef non-NULL) this layer's raw
+ * needed; finish with wm_bn_bwd_finalize_raw.  dx is WRITTEN as gz (multiplied by the feeding layer's ReLU mask, like
+ * wm_conv3x3_bwd_fused's; every consumer applies that mask itself, twice is the identity), so it may be handed to
+ * wm_conv3x3_bwd_fused with g_premasked = 1.  src = this layer's dy, or (gvec, stats4, coef non-NULL) this layer's raw
  * output with the apply pass fused as in wm_conv3x3_dgrad_gvfused. */
 /* The ordinary 64 -> 64 layer (gradient g a dense bf16 tensor [B,H,W,64]): input gradient with the BatchNorm-backward APPLY
  * pass fused.  The kernel reads g and the layer's raw output y (dense), forms dy from stats4 / coef while staging, writes
@@ -242,6 +244,27 @@ int wm_conv3x3_bwd_fused(const void* g, const float* gvec, const void* y, const 
                          int H, int W, int dtype, int g_premasked, int sweep_reverse, void* stream);
 int wm_conv3x3_bwd_fused_reduce(float* ws, float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, const WmBnBwdFin* fin,
                                 void* stream);
+/* The encoder's after-concat layer WITHOUT the concat (16-bit dtypes).  replaces: /root/reference/hidden_models/encoder.py:34-41
+ * (expand the message to [B,L,H,W], torch.cat([message, features, image]), then the 97 -> 64 ConvBNRelu of encoder.py:25).
+ * A 3x3 conv is linear in its input channels and a message plane is constant over the image, so
+ *   conv(cat) = conv64(features) + P,   P = conv3(image) + bias + sum_{taps inside the image} sum_l W[:, c_msg + l, tap] * msg[b, l].
+ * wm_concat_side_fwd writes P [B,H,W,64] (dtype) in one pass from the f32 NCHW image planes img [B,3,H,W]; w [64][Cin][3][3] is the
+ * layer's f32 weight in the reference's layout, the message channels are [c_msg, c_msg + L), the image channels [c_img, c_img + 3);
+ * bias f32[64] or NULL; msg f32 [B][L].  Scratch owned by the caller: wside (4 KB, 16-byte aligned), mbias f32 [B][9][64].
+ * wm_conv3x3_fwd_addin: y = conv3x3(relu(in_scale * x + in_shift), wp) + addend, dense [B,H,W,64] tensors, wp [9][64][64] from
+ * wm_pack_w3x3 (the feature channels of w through its channel map); the BatchNorm statistics partials
+ * f32[wm_conv3x3_nparts(B,H,W,64,64,dtype)][2][64] are taken AFTER the sum, so (y, partials) are the after-concat layer's.
+ * Backward of the message channels: wm_concat_side_msg_wgrad, dw[:, c_msg + l, tap] (+)= sum_b msg[b,l] * S[b,tap,:], S = the sums of
+ * dy [B,H,W,64] over the pixels for which `tap` lies inside the image; scratch: partial f32 [B][wm_concat_side_partial_rows()][64],
+ * S f32 [B][9][64]; dw f32 [64][Cin][3][3].  (Feature and image channels of dw: wm_conv3x3_wgrad with a channel map.)
+ * H, W >= 2; L <= 64; dtype WM_BF16 or WM_F16. */
+int wm_concat_side_partial_rows(void);
+int wm_concat_side_fwd(const float* img, const float* w, const float* bias, const float* msg, void* wside, float* mbias, void* P,
+                       int B, int H, int W, int Cin, int c_msg, int L, int c_img, int dtype, void* stream);
+int wm_concat_side_msg_wgrad(const void* dy, const float* msg, float* partial, float* S, float* dw, int accumulate, int B, int H,
+                             int W, int Cin, int c_msg, int L, int dtype, void* stream);
+int wm_conv3x3_fwd_addin(const void* x, const void* wp, const float* in_scale, const float* in_shift, const void* addend, void* y,
+                         float* stat_partials, int B, int H, int W, int dtype, int sweep_reverse, void* stream);
 int wm_conv3x3_dgrad_bwdstats_supported(int CoutY, int CinP, int dtype);
 int wm_conv3x3_dgrad_bwdstats(const void* src, int lds, int CoutY, const void* wpt, const float* gvec, const float* stats4,
                               const float* coef, const void* ry, const float* r_scale, const float* r_shift, void* dx,

@@ -40,6 +40,14 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert lib.wm_abi_version() >= 1
+    # ... and the converse: the header IS the boundary -- every wm_* function the release library exports is declared in it
+    # (the wm_debug_* switches exist only in the -DWM_DEBUG twin, which is not a product library)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in nm.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T" and ln.split()[-1].startswith("wm_")})
+    assert len(exported) >= len(names) - 5
+    undeclared = [n for n in exported if n not in set(names)]
+    assert not undeclared, undeclared
 
 
 def test_no_cpu_fallback():

@@ -370,7 +370,8 @@ def _check_integer_mask(m, images):
 
 def test_c5_clip_256_vs_oracle(tmp_path):
     """BASELINE configs[4], one rank's shard: a 16-frame 256x256 clip folded into the batch, JpegSS(70) attack, UNet head,
-    gradient clipping -- f32 path at the north_star tolerance and the bf16 production path at its bound, against the CPU oracle."""
+    gradient clipping -- f32 path at the north_star tolerance, the bf16 production path at its bound, and f16 + the device-side GradScaler
+    (the dtype BASELINE configs[4] states: /root/reference/models/IRNcrop_model.py:340,407-416) at the f16 bound, against the CPU oracle."""
     S, T = 256, 16
     clip = detgen.uniform((1, 3, T, S, S), 9300)
     mask5 = torch.zeros(1, 1, T, S, S)
@@ -386,8 +387,9 @@ def test_c5_clip_256_vs_oracle(tmp_path):
     loc = localise_ref.LocaliseRef(h, unet, attack, gradient_clipping=1.0)
     rlogs, routs, _ = loc.step(images, messages, previous, mask)
     res = {}
-    for name in ("f32", "bf16"):
+    for name in ("f32", "bf16", "f16"):
         m = make_model(tmp_path, S, attacks=["JpegSS70"], gradient_clipping=1.0, compute_dtype=name)
+        assert (m.amp is not None) == (name == "f16")
         m.previous_images = previous.cuda()
         m.previous_previous_images = previous.cuda()
         m.feed_data({"GT": clip, "mask": mask5, "messages": messages})
@@ -410,6 +412,10 @@ def test_c5_clip_256_vs_oracle(tmp_path):
     assert f["tampered"] < 1e-3 and f["pred_vs_oracle_run"] < 1e-1, f
     # bf16: the 18-conv UNet rounds its activations to bf16 per layer
     assert b["enc"] < 2e-2 and b["dec"] < 5e-2 and b["pred"] < 1.5e-1 and b["lB"] < 2e-2 and b["loss"] < 2e-2, b
+    # f16 (C5's stated dtype): 2^-11 relative rounding per layer instead of 2^-9 -- the bounds of test_gpu_fp16.test_f16_step_vs_oracle on
+    # the watermark path, a quarter of bf16's on the UNet's prediction (same-input oracle UNet) and the logged losses
+    h16 = res["f16"]
+    assert h16["enc"] < 5e-3 and h16["dec"] < 1.5e-2 and h16["pred"] < 4e-2 and h16["lB"] < 5e-3 and h16["loss"] < 5e-3, h16
 
 
 def test_grad_sync_one_rank_is_identity():

@@ -176,6 +176,44 @@ def test_captured_step_replays_the_eager_step():
     assert torch.equal(y_e, y2) and torch.equal(opt.grad, g2) and torch.equal(loss_e.detach(), l2.detach())
 
 
+def test_captured_step_refuses_an_fn_that_leaks_its_autograd_graph():
+    """the fn shape that ended round 2's capture in a segmentation fault inside hipStreamEndCapture (gpurun_out/inn3.log; tools/dbg_capture.py
+    1 0 0 1): a first eager call on the default stream, and an fn that rebinds outer names to tensors requiring grad.  CapturedStep must
+    answer with a Python error BEFORE capturing -- never crash --, and the same fn handing out detached tensors must capture and replay."""
+    from video_watermarking_forgery_detection_amd import glayers as G
+    PAMI, ResBlock, _ = _mods()
+    net = PAMI(dims_in=[[4, 32, 32]], block_num=[1, 1, 1], subnet_constructor=ResBlock, dtype=torch.bfloat16).to(DEV)
+    opt = G.FlatAdamW(net, lr=1e-4)
+    xs = detgen.uniform((2, 4, 32, 32), 7).to(DEV)
+    out = {}
+
+    def make(detach):
+        def fwd_bwd():
+            y = net(xs)
+            back, _ = net(y, rev=True)
+            loss = ((y - xs) ** 2).mean() + (back ** 2).mean()
+            opt.zero_grad()
+            loss.backward()
+            out["y"], out["loss"] = (y.detach(), loss.detach()) if detach else (y, loss)
+            return loss.detach()
+        return fwd_bwd
+
+    leaky = make(False)
+    leaky()                                    # the eager call on the default stream that binds the outer names first
+    with pytest.raises(RuntimeError, match="keeps the autograd graph"):
+        G.CapturedStep(leaky)
+    out.clear()
+    clean = make(True)
+    clean()
+    step = G.CapturedStep(clean)
+    step.replay()
+    torch.cuda.synchronize()
+    g_replay, l_replay = opt.grad.clone(), step.result.clone()
+    l_eager = clean()
+    torch.cuda.synchronize()
+    assert torch.equal(opt.grad, g_replay) and torch.equal(l_eager, l_replay) and torch.equal(out["loss"], l_replay)
+
+
 def test_pack_plan_trains_the_same_parameters():
     """glayers.set_pack_plan: persistent packed 3x3 weights re-packed by one launch after FlatAdamW.step give bit-identical training to
     packing per call; an in-place torch write to a weight is noticed (autograd version) and not served from the stale pack."""

@@ -1,4 +1,6 @@
-"""bisect helper for glayers.CapturedStep: python tools/dbg_capture.py <eager_first 0|1> <mid_term 0|1> <fill 0|1> <side_effects 0|1>"""
+"""bisect helper for glayers.CapturedStep: python tools/dbg_capture.py <eager_first 0|1> <mid_term 0|1> <fill 0|1> <side_effects 0|1|2>
+side_effects 1: fn rebinds outer names to tensors that require grad (keeps its autograd graph alive: CapturedStep refuses it since round 3;
+1 0 0 1 crashed inside hipStreamEndCapture before), 2: the same tensors detached"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -22,12 +24,18 @@ def fwd_bwd():
         loss = loss + (mid ** 2).mean()
     opt.zero_grad()
     loss.backward()
-    if side:
+    if side == 1:
         out["y"], out["loss"] = y, loss
+    elif side == 2:
+        out["y"], out["loss"] = y.detach(), loss.detach()
     return loss
 if eager_first:
     fwd_bwd()
-step = G.CapturedStep(fwd_bwd)
+try:
+    step = G.CapturedStep(fwd_bwd)
+except RuntimeError as e:
+    print("refused", sys.argv[1:5], str(e)[:90])
+    sys.exit(0)
 step.replay()
 torch.cuda.synchronize()
 print("ok", sys.argv[1:5], float(step.result))

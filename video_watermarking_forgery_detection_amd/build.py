@@ -7,7 +7,9 @@ Objects and the shared library are written next to the sources
 box with the gpurun snapshot.  hipcc cross-compiles without a GPU.
 """
 import concurrent.futures
+import json
 import os
+import re
 import subprocess
 import sys
 
@@ -21,7 +23,14 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # MFMA kernels: keep the compiler from SLP-packing scalar f32 VALU into v_pk_*_f32 -- packed f32 issues far slower
 # than two scalar ops beside MFMAs (MI355X_MICROARCH.md, constants table)
-EXTRA = {"conv3x3_ws.hip": ["-fno-slp-vectorize"], "wgrad_ws.hip": ["-fno-slp-vectorize"], "upconv_mfma.hip": ["-fno-slp-vectorize"], "conv3x3_stream.hip": ["-fno-slp-vectorize"]}
+MFMA_FILES = ("conv3x3_ws.hip", "bwd_ws.hip", "wgrad_ws.hip", "upconv_mfma.hip", "conv3x3_stream.hip", "concat_side.hip", "gconv.hip")
+EXTRA = {f: ["-fno-slp-vectorize"] for f in MFMA_FILES}
+# every compile reports its kernels' registers (-Rpass-analysis=kernel-resource-usage); a kernel of these files that spills or uses
+# scratch FAILS the build: a scratch reload counts in vmcnt and stalls the tile prefetch of the persistent kernels
+NO_SPILL = ("conv3x3_ws.hip", "bwd_ws.hip", "wgrad_ws.hip", "conv3x3_stream.hip", "upconv_mfma.hip", "concat_side.hip")
+# (file, f16 twin?, substring of the mangled kernel name) known and accepted to spill, with the reason
+SPILL_OK = (("wgrad_ws.hip", True, "wgrad_ws16_kernelILi64ELb1ELi2EE"),)   # f16 twin of the pooled-layer weight gradient: 11 VGPRs; superseded on the step by bwd_ws<GVEC>
+REMARK = "-Rpass-analysis=kernel-resource-usage"
 
 
 # kernels of these files exist for both 16-bit activation dtypes: compiled a second time with -DWM_H16_F16 (the f16 twins)
@@ -43,13 +52,44 @@ def _compile(src, force, debug=False, f16=False):
     sp = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), _deps_mtime()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + (["-DWM_DEBUG"] if debug else []) + (["-DWM_H16_F16"] if f16 else []) + EXTRA.get(src, []) + ["-x", "hip", "-c", sp, "-o", obj]
+    cmd = [HIPCC] + FLAGS + (["-DWM_DEBUG"] if debug else []) + (["-DWM_H16_F16"] if f16 else []) + EXTRA.get(src, []) + [REMARK, "-x", "hip", "-c", sp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-    if r.stderr.strip():
-        sys.stderr.write(r.stderr)
+    res = kernel_resources(r.stderr)
+    with open(obj + ".res.json", "w") as f:
+        json.dump(res, f, indent=0)
+    other = "\n".join(l for l in r.stderr.splitlines() if REMARK not in l and "remark:" not in l and l.strip())
+    if other.strip():
+        sys.stderr.write(other + "\n")
+    if src in NO_SPILL and not debug:
+        bad = {k: v for k, v in res.items() if (v.get("VGPRs Spill", 0) or v.get("ScratchSize [bytes/lane]", 0))
+               and not any(src == f and f16 == h and sub in k for f, h, sub in SPILL_OK)}
+        if bad:
+            os.remove(obj)
+            raise RuntimeError(f"{src}{' (f16 twin)' if f16 else ''}: kernels spill registers / use scratch, which the persistent kernels must not: "
+                               + "; ".join(f"{k}: {v.get('VGPRs Spill', 0)} VGPRs spilled, {v.get('ScratchSize [bytes/lane]', 0)} B/lane scratch" for k, v in bad.items()))
     return obj, True
+
+
+def kernel_resources(stderr):
+    """{mangled kernel name: {"VGPRs": n, "AGPRs": n, "VGPRs Spill": n, "ScratchSize [bytes/lane]": n, "Occupancy [waves/SIMD]": n, "LDS Size [bytes/block]": n, ...}}
+    parsed from hipcc's -Rpass-analysis=kernel-resource-usage remarks"""
+    out, cur = {}, None
+    for line in stderr.splitlines():
+        m = re.search(r"remark:\s+(.*?)\s*\[-Rpass-analysis", line)
+        if not m:
+            continue
+        body = m.group(1)
+        if body.startswith("Function Name:"):
+            cur = out.setdefault(body.split(":", 1)[1].strip(), {})
+        elif cur is not None and ":" in body:
+            k, v = body.rsplit(":", 1)
+            try:
+                cur[k.strip()] = int(v)
+            except ValueError:
+                cur[k.strip()] = v.strip()
+    return out
 
 
 def build(force=False, verbose=True, debug=True):

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                 const int cb = sidx & 1;
                 constexpr bool inter = stage && !(DBG & 128);
                 if constexpr (inter) { if ((2 * sidx) % 18 < 16 && ((2 * sidx) % 18) % 4 == 0) pub_consts(((2 * sidx) % 18) / 4); }
-                if (sidx == 17) load_rsrh(0, 2);   // (all four vectors here cost the unmasked-g variant 2 spilled registers)
+                if (sidx == 17 && (PREMASKED || GVEC)) load_rsrh(0, 2);   // (all four vectors here cost the unmasked-g variant 2 spilled registers; its f16 twin has no room for any)
                 if (sidx + 1 < 18) {
                     load_pix(sidx + 1, cb ^ 1);
                     if (!((DBG & 1024) && (sidx & 1))) { load_fil(sidx + 1, 0, filA[cb ^ 1]); load_fil(sidx + 1, 1, filB[cb ^ 1]); }   // DBG 1024: half the filter fragment reads
@@ -531,6 +531,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         // ---------------- input-gradient epilogue: layer L-1's BatchNorm-backward sums (gz = dx * [z > 0], dx rounded as stored), pack, store
         // (one wave per SIMD pays an issue slot for every instruction: the masked dx is built by two selects per pair and the sums take
         // THEIR operands from it -- 18 VALU instructions per channel pair; branch-free, so both pixel rows schedule as one block)
+        if constexpr (!(PREMASKED || GVEC) && !(DBG & 1)) load_rsrh(0, 2);
         load_rsrh(2, 4);
         if constexpr (!(DBG & 4))
 #pragma unroll

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
 
         f32x4 acc[4][NFR];   // [pixel fragment mf = tile row][channel fragment nf]
         static_assert(!BWDST || (!STATS && COUT == 64), "BWDST: 64-channel dgrads");
-        struct Drain { hx_t* yp; float mk; bool inb; };
+        struct Drain { hx_t* yp; float mk; bool inb; };   // mk: STATS: 1 / 0 inside / outside the image; BWDST: the ReLU threshold 0 / +inf (nothing passes outside)
         float rsc[CPL], rsh[CPL];
         if (BWDST) {
 #pragma unroll
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             Drain d;
             const int gy = g.ty0 + wave * 4 + mf, gx = g.tx0 + p;
             d.inb = gy < a.H && gx < a.W;
-            d.mk = d.inb ? 1.f : 0.f;
+            d.mk = BWDST ? (d.inb ? 0.f : __builtin_inff()) : (d.inb ? 1.f : 0.f);
             d.yp = a.y + (((size_t)g.b * a.H + gy) * a.W + gx) * COUT + CPL * q;
             return d;
         };
@@ -542,14 +542,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                     // are pure arithmetic, the sched_barriers do not hold them), out of the matrix pipe's shadow
                     if (PIN) asm volatile("" : "+v"(s1[2 * j]), "+v"(s1[2 * j + 1]), "+v"(s2[2 * j]), "+v"(s2[2 * j + 1]));
                 }
+                float y0 = 0.f, y1 = 0.f;
+                if (BWDST) {   // The gradient LEAVES multiplied by the ReLU mask of the layer it belongs to (gz, not g: every consumer applies
+                    // that mask anyway -- twice is the identity -- and bwd_ws.hip's PREMASKED staging skips it): the select sits in front
+                    // of the pack instead of behind it, the same number of instructions
+                    y0 = HX::lo(ryv[ml][j]); y1 = HX::hi(ryv[ml][j]);
+                    const float z0 = __builtin_fmaf(rsc[2 * j], y0, rsh[2 * j]), z1 = __builtin_fmaf(rsc[2 * j + 1], y1, rsh[2 * j + 1]);
+                    v0 = z0 > d[ml].mk ? v0 : 0.f; v1 = z1 > d[ml].mk ? v1 : 0.f;   // (outside the image the threshold is +inf: zeros for the sums)
+                }
                 const hx2 p2 = {(hx_t)v0, (hx_t)v1};
                 pk[j] = __builtin_bit_cast(unsigned, p2);
                 if (BWDST) {   // scalar f32, as above
-                    const unsigned gm = d[ml].inb ? pk[j] : 0u;
-                    const float g0 = HX::lo(gm), g1 = HX::hi(gm);
-                    const float y0 = HX::lo(ryv[ml][j]), y1 = HX::hi(ryv[ml][j]);
-                    const float z0 = __builtin_fmaf(rsc[2 * j], y0, rsh[2 * j]), z1 = __builtin_fmaf(rsc[2 * j + 1], y1, rsh[2 * j + 1]);
-                    const float gz0 = z0 > 0.f ? g0 : 0.f, gz1 = z1 > 0.f ? g1 : 0.f;
+                    const float gz0 = HX::lo(pk[j]), gz1 = HX::hi(pk[j]);
                     s1[2 * j] += gz0; s1[2 * j + 1] += gz1;
                     s2[2 * j] = __builtin_fmaf(gz0, y0, s2[2 * j]);
                     s2[2 * j + 1] = __builtin_fmaf(gz1, y1, s2[2 * j + 1]);
@@ -643,14 +647,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             o[4] = now() - t_start; o[5] = rt_end - rt_start;
         }
         if (STATS || BWDST) {
+            // (the lane's channel base is re-derived from an opaque copy of the thread index: the compiler otherwise keeps the pre-loop
+            // value alive across the whole tile loop -- in the BWDST forms, which sit at the 256-register limit, by spilling it)
+            int tid_post = threadIdx.x;
+            asm volatile("" : "+v"(tid_post));
+            const int q_post = (tid_post & 63) >> 4, wave_post = tid_post >> 6;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 float u1 = s1[c], u2 = s2[c];
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) { u1 += __shfl_xor(u1, o, 64); u2 += __shfl_xor(u2, o, 64); }
-                if (p == 0) {
-                    sRed[(wave * 2 + 0) * COUT + CPL * q + c] = u1;
-                    sRed[(wave * 2 + 1) * COUT + CPL * q + c] = u2;
+                if ((tid_post & 15) == 0) {
+                    sRed[(wave_post * 2 + 0) * COUT + CPL * q_post + c] = u1;
+                    sRed[(wave_post * 2 + 1) * COUT + CPL * q_post + c] = u2;
                 }
             }
             __syncthreads();  // matched by the producers' final barrier

@@ -206,7 +206,6 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
             # one kernel for both gradients (csrc/bwd_ws.hip, gvec form): y and the feeding layer's raw output are read once
             gx, part, pcoef = ops.conv3x3_bwd_fused(None, y, ctx.stats, coef, wpt, x.t, x.scale, x.shift, grads[conv.weight], accumulate,
                                                     fin=rider, gvec=gvec)
-            gx._wm_masked = True
             x.bwd = (gx, part, pcoef, gx._version)
             return tag(gx)
         if feed_stats:   # input gradient first: the sums it emits are finished by a rider on the weight gradient's reduction
@@ -229,7 +228,6 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
             # then skips the mask arithmetic -- trusted only for exactly that tensor, unmodified: the check in coef_of())
             gx, part, pcoef = ops.conv3x3_bwd_fused(g, y, ctx.stats, coef, wpt, x.t, x.scale, x.shift, grads[conv.weight], accumulate,
                                                     reverse=d, fin=rider, premasked=pre is not None and getattr(g, "_wm_masked", False))
-            gx._wm_masked = True
             x.bwd = (gx, part, pcoef, gx._version)
         elif feed_stats:
             dy, gx, part = ops.conv3x3_dgrad_applyfused(g, y, ctx.stats, coef, wpt, x.t, x.scale, x.shift, reverse=d)

@@ -683,19 +683,51 @@ class CapturedStep:
         step = CapturedStep(lambda: fwd_bwd(x_static))      # two eager warm-up calls on a side stream, then the capture
         for batch in data: x_static.copy_(batch); step.replay(); opt.step()
 
-    step.result holds what fn returned at capture (tensors that every replay overwrites).  Hand results out through that return value:
-    an fn that rebinds outer variables to its tensors, after an eager call on the default stream had bound them, ended the capture in a
-    segmentation fault inside hipStreamEndCapture on ROCm 7.2 (tools/dbg_capture.py 1 0 0 1)."""
+    step.result holds what fn returned at capture (tensors that every replay overwrites).  Hand results out through that return value, or
+    .detach() what fn stores elsewhere: an fn that keeps the autograd graph of its previous call alive (it rebinds an outer name, a dict
+    entry, an attribute ... to a tensor that requires grad) is REFUSED with a RuntimeError before anything is captured.  Such a graph keeps
+    its AccumulateGrad nodes -- and the stream they were created on -- alive from call to call; when the first call ran eagerly on the
+    default stream, the captured backward then synchronises the capturing stream with the legacy default stream, and hipStreamEndCapture
+    on ROCm 7.2 answers that with a segmentation fault instead of an error (gpurun_out/inn3.log; tools/dbg_capture.py 1 0 0 1).  The check:
+    the last warm-up call runs under torch.autograd.graph.saved_tensors_hooks that tag every tensor a node saves; once the call's result
+    has been dropped, no tag may be alive."""
 
     def __init__(self, fn, warmup=2):
         if not torch.cuda.is_available():
             raise RuntimeError("CapturedStep: GPU only")
+        warmup = max(int(warmup), 1)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        tags = []
+
+        class _Tag:
+            __slots__ = ("t", "__weakref__")
+
+            def __init__(self, t):
+                self.t = t
+
+        def pack(t):
+            tag = _Tag(t)
+            tags.append(weakref.ref(tag))
+            return tag
+
         with torch.cuda.stream(side):
-            for _ in range(warmup):
-                fn()
+            for i in range(warmup):
+                if i == warmup - 1:
+                    with torch.autograd.graph.saved_tensors_hooks(pack, lambda tag: tag.t):
+                        r = fn()
+                else:
+                    r = fn()
+                del r
         torch.cuda.current_stream().wait_stream(side)
+        import gc
+        gc.collect()
+        leaked = sum(1 for w in tags if w() is not None)
+        if leaked:
+            raise RuntimeError(
+                f"CapturedStep: fn keeps the autograd graph of its previous call alive ({leaked} of {len(tags)} saved tensors survive the call): "
+                "it stores a tensor that requires grad outside itself (an outer variable, a dict entry, an attribute).  Return such tensors "
+                "from fn (step.result) or .detach() them; capturing this fn can crash the process inside hipStreamEndCapture")
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.result = fn()

@@ -464,6 +464,7 @@ def conv3x3_dgrad_bwdstats(src, wpt, ry, r_scale, r_shift, gvec=None, stats=None
                                               _p(r_shift), _p(dx), _p(part), c_int(B), c_int(H), c_int(W), c_int(CinP),
                                               c_int(dtype_id(src)), _sweep(reverse), _stream())
     _lib.check(rc, "wm_conv3x3_dgrad_bwdstats")
+    dx._wm_masked = True   # the kernel writes gz = g * [z > 0] of the feeding layer (what conv3x3_bwd_fused's premasked staging expects)
     return dx, part
 
 
@@ -487,6 +488,8 @@ def conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry=None, r_scale=None, r_sh
         _p(g), _p(y), _p(stats), _p(coef), _p(wpt), _p(dy), _p(dx), _p(ry), _p(r_scale), _p(r_shift), _p(part), c_int(B), c_int(H), c_int(W),
         c_int(CinP), c_int(dtype_id(y)), _sweep(reverse), _stream()))
     _lib.check(rc, "wm_conv3x3_dgrad_applyfused")
+    if ry is not None:
+        dx._wm_masked = True   # as conv3x3_dgrad_bwdstats
     return dy, dx, part
 
 
@@ -527,6 +530,7 @@ def conv3x3_bwd_fused(g, y, stats, coef, wpt, xr, in_scale, in_shift, dw, accumu
     rc = L.wm_conv3x3_bwd_fused_reduce(_p(ws), _p(dw), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(Cout),
                                        ctypes.byref(fst) if fst is not None else None, _stream())
     _lib.check(rc, "wm_conv3x3_bwd_fused_reduce")
+    dx._wm_masked = True
     return dx, part, fcoef
 
 
