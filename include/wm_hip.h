@@ -215,7 +215,8 @@ int wm_conv3x3_dgrad_gvfused(const void* y, int ldy, int CoutY, const void* wpt,
  * output with the apply pass fused as in wm_conv3x3_dgrad_gvfused. */
 /* The ordinary 64 -> 64 layer (gradient g a dense bf16 tensor [B,H,W,64]): input gradient with the BatchNorm-backward APPLY
  * pass fused.  The kernel reads g and the layer's raw output y (dense), forms dy from stats4 / coef while staging, writes
- * dy_out [B,H,W,64] (bit-identical to wm_bn_bwd_apply's; input of the wm_conv3x3_wgrad that follows) and dx = conv(dy, wpt)
+ * dy_out [B,H,W,64] (bit-identical to wm_bn_bwd_apply's; input of the wm_conv3x3_wgrad that follows; NULL: not written -- an input
+ * gradient whose weight gradient nobody reads, e.g. the discriminator under the generator's loss, hidden.py:85-103) and dx = conv(dy, wpt)
  * [B,H,W,CinP], CinP = 64, or 32 for an image-fed layer (wpt [9][CinP][64]).
  * ry / r_scale / r_shift / partials: optional, all or none -- the sums of the feeding layer as in
  * wm_conv3x3_dgrad_bwdstats. */

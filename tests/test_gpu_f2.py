@@ -177,13 +177,17 @@ def test_captured_step_replays_the_eager_step():
 
 
 def test_captured_step_refuses_an_fn_that_leaks_its_autograd_graph():
-    """the fn shape that ended round 2's capture in a segmentation fault inside hipStreamEndCapture (gpurun_out/inn3.log; tools/dbg_capture.py
-    1 0 0 1): a first eager call on the default stream, and an fn that rebinds outer names to tensors requiring grad.  CapturedStep must
-    answer with a Python error BEFORE capturing -- never crash --, and the same fn handing out detached tensors must capture and replay."""
+    """the fn shape that ended round 2's capture in a segmentation fault inside hipStreamEndCapture (gpurun_out/inn3.log): a first eager
+    call on the default stream, an fn that rebinds outer names to tensors requiring grad (so every call's autograd graph lives until the
+    next call has built its own), and a parameter whose gradient goes through autograd's AccumulateGrad node (then: every conv weight;
+    now: the plain `gain` -- round 3 reproduced the crash with exactly this fn on round 2's CapturedStep, tools/dbg_capture.py 1 0 0 1 1 1).
+    CapturedStep must answer with a Python error BEFORE capturing -- never crash --, and the same fn handing out detached tensors must
+    capture and replay."""
     from video_watermarking_forgery_detection_amd import glayers as G
     PAMI, ResBlock, _ = _mods()
     net = PAMI(dims_in=[[4, 32, 32]], block_num=[1, 1, 1], subnet_constructor=ResBlock, dtype=torch.bfloat16).to(DEV)
     opt = G.FlatAdamW(net, lr=1e-4)
+    gain = torch.nn.Parameter(torch.ones(4, 1, 1, device=DEV))
     xs = detgen.uniform((2, 4, 32, 32), 7).to(DEV)
     out = {}
 
@@ -191,8 +195,10 @@ def test_captured_step_refuses_an_fn_that_leaks_its_autograd_graph():
         def fwd_bwd():
             y = net(xs)
             back, _ = net(y, rev=True)
-            loss = ((y - xs) ** 2).mean() + (back ** 2).mean()
+            loss = ((y - xs) ** 2).mean() + (back ** 2).mean() + ((y * gain) ** 2).mean()
             opt.zero_grad()
+            if gain.grad is not None:
+                gain.grad.zero_()
             loss.backward()
             out["y"], out["loss"] = (y.detach(), loss.detach()) if detach else (y, loss)
             return loss.detach()
@@ -208,10 +214,11 @@ def test_captured_step_refuses_an_fn_that_leaks_its_autograd_graph():
     step = G.CapturedStep(clean)
     step.replay()
     torch.cuda.synchronize()
-    g_replay, l_replay = opt.grad.clone(), step.result.clone()
+    g_replay, gg_replay, l_replay = opt.grad.clone(), gain.grad.clone(), step.result.clone()
+    assert float(gg_replay.abs().max()) > 0
     l_eager = clean()
     torch.cuda.synchronize()
-    assert torch.equal(opt.grad, g_replay) and torch.equal(l_eager, l_replay) and torch.equal(out["loss"], l_replay)
+    assert torch.equal(opt.grad, g_replay) and torch.equal(gain.grad, gg_replay) and torch.equal(l_eager, l_replay) and torch.equal(out["loss"], l_replay)
 
 
 def test_pack_plan_trains_the_same_parameters():

@@ -59,9 +59,18 @@ def _compile(src, force, debug=False, f16=False):
     res = kernel_resources(r.stderr)
     with open(obj + ".res.json", "w") as f:
         json.dump(res, f, indent=0)
-    other = "\n".join(l for l in r.stderr.splitlines() if REMARK not in l and "remark:" not in l and l.strip())
-    if other.strip():
-        sys.stderr.write(other + "\n")
+    other, skip = [], 0
+    for l in r.stderr.splitlines():      # everything but the resource remarks (each is followed by its source line and a caret line)
+        if "remark:" in l:
+            skip = 2
+        elif skip and (re.match(r"\s*\d+ \|", l) or re.match(r"\s*\|\s*\^", l)):
+            skip -= 1
+        else:
+            skip = 0
+            if l.strip() and not re.match(r"\d+ (warning|remark)s? generated", l.strip()):
+                other.append(l)
+    if other:
+        sys.stderr.write("\n".join(other) + "\n")
     if src in NO_SPILL and not debug:
         bad = {k: v for k, v in res.items() if (v.get("VGPRs Spill", 0) or v.get("ScratchSize [bytes/lane]", 0))
                and not any(src == f and f16 == h and sub in k for f, h, sub in SPILL_OK)}

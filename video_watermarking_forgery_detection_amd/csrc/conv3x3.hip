@@ -469,7 +469,7 @@ extern "C" int wm_conv3x3_dgrad_applyfused_supported(int CoutY, int CinP, int dt
 extern "C" int wm_conv3x3_dgrad_applyfused(const void* g, const void* y, const float* stats4, const float* coef, const void* wpt,
                                            void* dy_out, void* dx, const void* ry, const float* r_scale, const float* r_shift,
                                            float* partials, int B, int H, int W, int CinP, int dtype, int sweep_reverse, void* stream) {
-    WM_REQUIRE(g && y && stats4 && coef && wpt && dy_out && dx, WM_E_BADARG, "wm_conv3x3_dgrad_applyfused: null pointer");
+    WM_REQUIRE(g && y && stats4 && coef && wpt && dx, WM_E_BADARG, "wm_conv3x3_dgrad_applyfused: null pointer");   // (dy_out may be NULL)
     WM_REQUIRE((ry == nullptr) == (partials == nullptr) && (ry == nullptr) == (r_scale == nullptr) && (ry == nullptr) == (r_shift == nullptr),
                WM_E_BADARG, "wm_conv3x3_dgrad_applyfused: ry, r_scale, r_shift and partials come together");
     WM_REQUIRE(B > 0 && H > 0 && W > 0, WM_E_BADARG, "wm_conv3x3_dgrad_applyfused: bad shape");

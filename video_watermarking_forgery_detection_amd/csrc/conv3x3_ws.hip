@@ -361,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
 #pragma unroll
                     for (int q = 0; q < 4; ++q) w[q] &= keep;
                     if (k + 1 < XVP || last_live) *reinterpret_cast<u32x4*>(sX + lds[k]) = w;
-                    if (((wmask >> k) & 1u) && inimg) *reinterpret_cast<u32x4*>(a.dy_out + tofs + rel[k]) = w;
+                    if (((wmask >> k) & 1u) && inimg && a.dy_out) *reinterpret_cast<u32x4*>(a.dy_out + tofs + rel[k]) = w;   // (dy_out NULL: nobody wants dy -- an input gradient without its weight gradient)
                 }
             };
             if (t_begin < t_end) load_both(geo(t_begin));
@@ -879,7 +879,7 @@ int WM_HSYM(wm_launch_conv3x3_ws)(const void* x, int ldx, int Cin, int CoutP, co
         return WM_OK;
     }
     if (ay) {   // dgrad with the BatchNorm-backward apply (tensor gradient) fused; x = g, dy written out for the weight gradient
-        if (Cin != 64 || (CoutP != 64 && CoutP != 32) || ldx != 64 || in_scale || !bw_stats4 || !bw_coef || bw_gvec || !dy_out ||
+        if (Cin != 64 || (CoutP != 64 && CoutP != 32) || ldx != 64 || in_scale || !bw_stats4 || !bw_coef || bw_gvec ||
             (ry != nullptr) != (stat != nullptr) || (ry && CoutP != 64))
             return WM_E_SHAPE;
         if (CoutP == 32) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 32, false, false, true, false, 2, false>), grid, block, 0, s, a, nullptr);   // image-fed layer: dx has 3 (-> 32) channels

@@ -49,11 +49,13 @@ class GradSync:
     callable(bucket) = start + finish + the division applied in place (for callers that read the averaged gradients).
     `force` runs the collectives at world size 1 too (tests exercise the exact multi-rank code path on one GPU)."""
 
-    def __init__(self, group=None, force=False):
+    def __init__(self, group=None, force=False, profile=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
         self.scale = 1.0 / self.world
+        self.profile = profile      # record, per bucket, its bytes and how long the compute stream stood waiting for it (report())
+        self._waits = []
 
     def start(self, flat):
         if not self.active:
@@ -61,8 +63,27 @@ class GradSync:
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat
 
     def finish(self, handle):
-        if handle is not None:
+        if handle is None:
+            return
+        if self.profile and handle[1].is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            handle[0].wait()        # the current stream waits for the collective: e1 - e0 is the part of it that did NOT travel under compute
+            e1.record()
+            self._waits.append((handle[1].numel() * handle[1].element_size(), e0, e1))
+        else:
             handle[0].wait()
+
+    def report(self, steps=1):
+        """(profile=True) -> {"buckets_per_step", "bytes_per_step", "bucket_bytes": the distinct sizes, "wait_ms_per_step": the time the
+        compute stream stood in finish() -- the exposed, non-overlapped part of the all-reduces --, "wait_ms_max_bucket"}; clears the log"""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        w, self._waits = self._waits, []
+        ms = [e0.elapsed_time(e1) for _, e0, e1 in w]
+        steps = max(int(steps), 1)
+        return {"world": self.world, "buckets_per_step": len(w) / steps, "bytes_per_step": sum(b for b, _, _ in w) / steps,
+                "bucket_bytes": sorted({b for b, _, _ in w}), "wait_ms_per_step": sum(ms) / steps, "wait_ms_max_bucket": max(ms) if ms else 0.0}
 
     def finish_all(self, handles):
         for h in handles:
@@ -77,6 +98,44 @@ class GradSync:
     def __call__(self, flat):
         self.finish(self.start(flat))
         return self.average_(flat)
+
+
+class CallableGradSync:
+    """a plain callable(flat_grad_tensor) -- expected to leave the AVERAGED gradient in the tensor -- behind GradSync's interface: it runs
+    synchronously where the bucket would be waited for; nothing is folded into the optimiser (scale 1)"""
+    scale = 1.0
+    world = 1
+    active = True
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def start(self, flat):
+        return flat
+
+    def finish(self, handle):
+        if handle is not None:
+            self.fn(handle)
+
+    def finish_all(self, handles):
+        for h in handles:
+            self.finish(h)
+
+    def average_(self, flat):
+        return flat
+
+    def __call__(self, flat):
+        self.fn(flat)
+        return flat
+
+
+def as_grad_sync(obj):
+    """None, a GradSync-like object (has start / finish), or a plain callable -> the interface Hidden / UNet drive"""
+    if obj is None or hasattr(obj, "start"):
+        return obj
+    if callable(obj):
+        return CallableGradSync(obj)
+    raise TypeError("grad_sync must be None, a distributed.GradSync or a callable(flat_grad_tensor)")
 
 
 def broadcast_parameters(modules, src=0, group=None):

@@ -139,11 +139,14 @@ def fin_rider(x, part, grads, accumulate):
 
 
 def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, accumulate=False,
-                 dgrad_channels=None, perm_dev=None, pool_stats=None):
+                 dgrad_channels=None, perm_dev=None, pool_stats=None, weight_grads=True):
     """Backward of ConvBNRelu.  g: NHWC gradient wrt the ReLU output ([B,H,W,>=CoutP]) or gvec [B,CoutP]
     (global-average-pool gradient, already / (H*W)).  grads: dict param -> f32 grad view.
     Returns the NHWC gradient wrt the (activated) input, `dgrad_channels` wide (default: the input's
-    physical channels rounded up to 32), or None."""
+    physical channels rounded up to 32), or None.
+    weight_grads=False: the input gradient alone -- conv.weight's gradient is neither computed nor touched (the BatchNorm affine
+    gradients, a by-product of the backward coefficients, still are): the discriminator under the generator's loss, whose parameter
+    gradients nobody reads (hidden.py:67 zeroes them first thing in the next step)."""
     if not ctx.training:
         raise RuntimeError("backward through eval-mode BatchNorm is not supported by the HIP path")
     y, x = ctx.y, ctx.x
@@ -179,7 +182,7 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
 
     # An image-fed first layer whose input needs no gradient: dy has ONE consumer, the weight gradient -- its kernel forms dy
     # from (g, y) while staging the tile, so the apply pass (a write and a read of dy) disappears.
-    if (not need_input_grad and g is not None and x.scale is None and perm_dev is None and ctx.stats.is_contiguous()
+    if (weight_grads and not need_input_grad and g is not None and x.scale is None and perm_dev is None and ctx.stats.is_contiguous()
             and g.shape[-1] == y.shape[-1] and ops.conv3x3_wgrad_bnfused_supported(x.t.shape[-1], y.shape[-1], dtype)):
         ops.conv3x3_wgrad_bnfused(x.t, g, y, ctx.stats, coef_of(), grads[conv.weight], accumulate)
         return None
@@ -195,6 +198,27 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
         return dict(partials=part, y_shape=tuple(x.t.shape), stats=pstats, C=x.C, gamma=pbn.weight.data, dgamma=grads[pbn.weight],
                     dbeta=grads[pbn.bias], accumulate=accumulate)
 
+    if not weight_grads:
+        if not need_input_grad:
+            coef_of()      # dgamma / dbeta only
+            return None
+        rows16 = ctx.perm is None and perm_dev is None and ctx.stats.is_contiguous() and y.shape[-1] == 64 and rows in (64, 32)
+        if gvec is not None and rows16 and rows == 64 and feed_stats and ops.conv3x3_gvfused_supported(64, 64, dtype):
+            gx, part = ops.conv3x3_dgrad_bwdstats(y, _packed(conv, 64, 64, dtype, None, True), x.t, x.scale, x.shift, gvec, ctx.stats, coef_of())
+            x.bwd = (gx, part, None, gx._version)
+            return tag(gx)
+        if g is not None and rows16 and g.shape == y.shape and g.is_contiguous() and ops.conv3x3_dgrad_applyfused_supported(64, rows, dtype):
+            wpt = _packed(conv, 64, rows, dtype, None, True)
+            if feed_stats and rows == 64:
+                _, gx, part = ops.conv3x3_dgrad_applyfused(g, y, ctx.stats, coef_of(), wpt, x.t, x.scale, x.shift, reverse=d, want_dy=False)
+                x.bwd = (gx, part, None, gx._version)
+            else:
+                _, gx, _ = ops.conv3x3_dgrad_applyfused(g, y, ctx.stats, coef_of(), wpt, reverse=d, want_dy=False)
+            return tag(gx)
+        # shapes / dtypes without a fused input-gradient kernel: the apply pass, then the plain input gradient
+        dy = ops.bn_bwd(g, gvec, y, ctx.stats, Cout, gam, dgam, dbet, accumulate, dbias, coef=coef_of())
+        gx, _ = ops.conv3x3_fwd(dy, _packed(conv, y.shape[-1], rows, dtype, ctx.perm, True), None, None, None, want_stats=False)
+        return tag(gx, False)
     # A globally pooled layer (the gradient wrt its ReLU output is one row per sample): both consumers of dy -- the weight
     # gradient and the input gradient -- form it from (gvec, y) while staging their tiles; no apply pass, no dy tensor.
     if (gvec is not None and need_input_grad and x.scale is not None and perm_dev is None and ctx.perm is None and rows == 64

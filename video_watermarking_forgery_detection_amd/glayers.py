@@ -685,49 +685,46 @@ class CapturedStep:
 
     step.result holds what fn returned at capture (tensors that every replay overwrites).  Hand results out through that return value, or
     .detach() what fn stores elsewhere: an fn that keeps the autograd graph of its previous call alive (it rebinds an outer name, a dict
-    entry, an attribute ... to a tensor that requires grad) is REFUSED with a RuntimeError before anything is captured.  Such a graph keeps
-    its AccumulateGrad nodes -- and the stream they were created on -- alive from call to call; when the first call ran eagerly on the
-    default stream, the captured backward then synchronises the capturing stream with the legacy default stream, and hipStreamEndCapture
-    on ROCm 7.2 answers that with a segmentation fault instead of an error (gpurun_out/inn3.log; tools/dbg_capture.py 1 0 0 1).  The check:
-    the last warm-up call runs under torch.autograd.graph.saved_tensors_hooks that tag every tensor a node saves; once the call's result
-    has been dropped, no tag may be alive."""
+    entry, an attribute ... to a tensor that requires grad) is REFUSED with a RuntimeError before anything is captured.  Why: a graph that
+    outlives its call keeps the AccumulateGrad node of every parameter it used alive, and the next call's graph picks those nodes up
+    again, so they never die -- and a node runs on the stream that was current when it was CREATED.  When the first call ran eagerly on
+    the default stream, the captured backward therefore makes the legacy default stream wait on an event of the capturing stream;
+    CUDA invalidates such a capture with an error, hipStreamEndCapture on ROCm 7.2 ended it in a segmentation fault
+    (gpurun_out/inn3.log, round 2; tools/dbg_capture.py).  The check: before the last warm-up call the AccumulateGrad node of every CUDA
+    parameter is tagged (Node.metadata); a node with no graph holding it dies with the tag, so a tag that is still there after the call's
+    result has been dropped proves a leaked graph."""
 
     def __init__(self, fn, warmup=2):
         if not torch.cuda.is_available():
             raise RuntimeError("CapturedStep: GPU only")
-        warmup = max(int(warmup), 1)
+        import gc
+        warmup = max(int(warmup), 2)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        tags = []
+        tag, key = object(), "wm_captured_step_probe"
+        params = []
 
-        class _Tag:
-            __slots__ = ("t", "__weakref__")
-
-            def __init__(self, t):
-                self.t = t
-
-        def pack(t):
-            tag = _Tag(t)
-            tags.append(weakref.ref(tag))
-            return tag
+        def accumulator(p):
+            return torch.autograd.graph.get_gradient_edge(p).node
 
         with torch.cuda.stream(side):
             for i in range(warmup):
                 if i == warmup - 1:
-                    with torch.autograd.graph.saved_tensors_hooks(pack, lambda tag: tag.t):
-                        r = fn()
-                else:
-                    r = fn()
+                    gc.collect()
+                    params = [o for o in gc.get_objects() if isinstance(o, torch.nn.Parameter) and o.is_cuda and o.requires_grad]
+                    for p in params:
+                        accumulator(p).metadata[key] = tag
+                r = fn()
                 del r
+            gc.collect()
+            leaked = [p for p in params if accumulator(p).metadata.get(key) is tag]
         torch.cuda.current_stream().wait_stream(side)
-        import gc
-        gc.collect()
-        leaked = sum(1 for w in tags if w() is not None)
         if leaked:
             raise RuntimeError(
-                f"CapturedStep: fn keeps the autograd graph of its previous call alive ({leaked} of {len(tags)} saved tensors survive the call): "
-                "it stores a tensor that requires grad outside itself (an outer variable, a dict entry, an attribute).  Return such tensors "
-                "from fn (step.result) or .detach() them; capturing this fn can crash the process inside hipStreamEndCapture")
+                f"CapturedStep: fn keeps the autograd graph of its previous call alive (the AccumulateGrad nodes of {len(leaked)} of {len(params)} "
+                "parameters survive the call): it stores a tensor that requires grad outside itself (an outer variable, a dict entry, an "
+                "attribute).  Return such tensors from fn (step.result) or .detach() them; capturing this fn can crash the process inside "
+                "hipStreamEndCapture")
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.result = fn()

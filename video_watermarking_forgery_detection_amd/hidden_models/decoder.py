@@ -37,15 +37,16 @@ def head_bwd(mod, ctx, I, g_out, grads, accumulate):
                                accumulate, CP, 1.0 / ctx.HW)
 
 
-def stack_bwd(blocks, ctx, gvec, grads, accumulate, need_input_grad):
-    """gvec [B,CP] f32 (gradient wrt the pooled features / (H*W), zero padded) -> gradient wrt the image [B,3,H,W] or None"""
+def stack_bwd(blocks, ctx, gvec, grads, accumulate, need_input_grad, weight_grads=True):
+    """gvec [B,CP] f32 (gradient wrt the pooled features / (H*W), zero padded) -> gradient wrt the image [B,3,H,W] or None
+    (weight_grads False: engine.cbr_backward's input-gradient-only form)"""
     g = None
     n = len(blocks)
     for i in range(n - 1, -1, -1):
         blk = blocks[i]
         g = engine.cbr_backward(blk.layers[0], blk.layers[1], ctx.layers[i], grads, g=g, gvec=gvec if i == n - 1 else None,
                                 accumulate=accumulate, need_input_grad=(i > 0 or need_input_grad),
-                                pool_stats=ctx.pool_stats if i == n - 1 else None)
+                                pool_stats=ctx.pool_stats if i == n - 1 else None, weight_grads=weight_grads)
     if not need_input_grad:
         return None
     return ops.nhwc_to_nchw(g, 3, 0)

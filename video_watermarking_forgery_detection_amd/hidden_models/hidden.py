@@ -142,7 +142,7 @@ class _FlatAdam:
         """accepts torch.optim.Adam / AdamW state_dicts (the reference's files) and this class's round-1 flat layout"""
         self._ensure()
         if "state" not in sd:   # round-1 layout: {step, param_groups, exp_avg[list], exp_avg_sq[list]}
-            self.step_count = int(sd["step"])
+            self._set_steps(int(sd["step"]))
             self._update_group(sd["param_groups"][0])
             for t, src in zip(self._m, sd["exp_avg"]):
                 t.copy_(src)
@@ -177,7 +177,14 @@ class _FlatAdam:
                 i += 1
         if len(steps) > 1:
             raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused flat-buffer step keeps one count")
-        self.step_count = steps.pop() if steps else 0
+        self._set_steps(steps.pop() if steps else 0)
+
+    def _set_steps(self, n):
+        """the loaded step count: on the host, and -- under a scaler -- in the device slot adam_amp_kernel takes its bias correction's t from
+        (a resumed f16 run otherwise stepped with t = 1 on warm moments: bc1 = 0.1, bc2 = 0.001 instead of ~1)"""
+        self.step_count = n
+        if getattr(self, "amp", None) is not None:
+            self.amp.set_step_count(self.amp_slot, n)
 
     def _update_group(self, g):
         for k in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
@@ -231,7 +238,7 @@ _ACCEPTS_ID = {}
 
 class Hidden:
     def __init__(self, configuration: HiDDenConfiguration, device: torch.device, noiser, tb_logger=None,
-                 compute_dtype=torch.bfloat16, grad_sync=None, amp=None):
+                 compute_dtype=torch.bfloat16, grad_sync=None, amp=None, keep_dead_discriminator_grads=True):
         """
         :param configuration: sizes / loss weights (options.HiDDenConfiguration)
         :param device: must be a cuda (ROCm) device -- the step has no CPU path
@@ -239,8 +246,15 @@ class Hidden:
                        (noise_layers.Noiser) or any module of noise_layers
         :param tb_logger: accepted for signature compatibility; unused
         :param compute_dtype: torch.bfloat16 (production) or torch.float32 (parity path)
-        :param grad_sync: optional callable(flat_grad_tensor) run before each optimiser step
-                          (data-parallel all-reduce, see parallel.py)
+        :param grad_sync: None or a distributed.GradSync (its interface is required: start / finish / finish_all / scale / average_) --
+                          the data-parallel bucket all-reduce started from inside the backward.  A plain callable(flat_grad_tensor) is
+                          wrapped into that interface (run once per bucket, synchronously, where the bucket would be waited for)
+        :param keep_dead_discriminator_grads: True (default) = the reference's state after a step: g_loss.backward() (hidden.py:101) also
+                    accumulates the generator loss's gradients into the DISCRIMINATOR's parameters; nothing ever reads them (no optimiser
+                    step uses them, hidden.py:67 zeroes them first thing in the next step).  False: that third pass through the
+                    discriminator computes the gradient wrt `encoded` only (no conv weight gradients: 2 body-layer + 1 first-layer
+                    weight-gradient GEMMs fewer per step, 9.9 of the step's 249.0 GFLOP per 256x256 frame).  Losses, outputs and every
+                    parameter update are identical either way; only the discriminator's .grad left behind after the step differs.
         :param amp: optional ops.AmpState -- torch.cuda.amp.GradScaler semantics on the device (models/IRNcrop_model.py:143,
                     407-416): every loss gradient is multiplied by its scale, both optimisers step through it.  Required in
                     practice with compute_dtype=torch.float16 (the gradients of a 3M-element mean loss underflow f16 otherwise)
@@ -265,7 +279,9 @@ class Hidden:
         self.cover_label = 1
         self.encoded_label = 0
         self.tb_logger = tb_logger
-        self.grad_sync = grad_sync
+        from ..distributed import as_grad_sync
+        self.grad_sync = as_grad_sync(grad_sync)
+        self.keep_dead_discriminator_grads = bool(keep_dead_discriminator_grads)
         self.amp = amp
         self.amp_owner = True   # this object calls amp.update() at the end of a step (a wrapping model may take that over)
         if amp is not None:
@@ -358,9 +374,9 @@ class Hidden:
         # ---------------- train the generator (hidden.py:85-103)
         d_on_encoded_for_enc, c = D.fwd(encoded)
         g_loss_adv, g = self._bce_logits(d_on_encoded_for_enc, self.cover_label, cfg.adversarial_loss)
-        # the reference's g_loss.backward() also accumulates into the discriminator's .grad (zeroed at
-        # the start of the next step); kept, so .grad state matches
-        g_enc = D.bwd(c, g, gD, accumulate=True, need_input_grad=True)
+        # the reference's g_loss.backward() also accumulates into the discriminator's .grad (zeroed at the start of the next step, never
+        # read): kept by default so the .grad state matches; keep_dead_discriminator_grads=False computes the image gradient alone
+        g_enc = D.bwd(c, g, gD, accumulate=True, need_input_grad=True, weight_grads=self.keep_dead_discriminator_grads)
 
         n_img = encoded.numel()
         gate = enc_gate(encoded, images) if enc_gate is not None else None

@@ -472,7 +472,7 @@ def conv3x3_dgrad_applyfused_supported(CoutY, CinP, dtype):
     return bool(_lib.lib().wm_conv3x3_dgrad_applyfused_supported(c_int(CoutY), c_int(CinP), c_int(dt_id(dtype))))
 
 
-def conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry=None, r_scale=None, r_shift=None, reverse=False):
+def conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry=None, r_scale=None, r_shift=None, reverse=False, want_dy=True):
     """64 -> 64 layer, gradient g a dense tensor: the BatchNorm-backward apply pass inside the input-gradient kernel.
     Returns (dy, dx, partials or None): dy for the weight gradient, dx = conv3x3(dy, wpt), partials = the feeding layer's
     BatchNorm-backward sums when its raw output ry (+ r_scale, r_shift) is given."""
@@ -480,7 +480,7 @@ def conv3x3_dgrad_applyfused(g, y, stats, coef, wpt, ry=None, r_scale=None, r_sh
     CinP = wpt.shape[1]
     assert C == 64 and g.shape == y.shape and g.is_contiguous() and y.is_contiguous() and tuple(wpt.shape) == (9, CinP, 64) and CinP in (64, 32)
     assert stats.is_contiguous() and coef.is_contiguous() and (ry is None or (CinP == 64 and ry.shape == y.shape and ry.is_contiguous()))
-    dy = torch.empty_like(y)
+    dy = torch.empty_like(y) if want_dy else None     # want_dy False: the input gradient alone (no weight gradient will read dy)
     dx = torch.empty(B, H, W, CinP, device=y.device, dtype=y.dtype)
     part = torch.empty(conv3x3_nparts(B, H, W, 64, 64, y.dtype), 2, 64, device=y.device, dtype=torch.float32) if ry is not None else None
     info = {"B": B, "H": H, "W": W, "feed": ry is not None, "dtype": y.dtype}
@@ -768,6 +768,23 @@ class AmpState:
 
     def step_count(self, k):
         return int(self.state[12 + k].item())
+
+    def set_step_count(self, k, n):
+        """restore optimiser k's step count (the t of Adam's bias correction under the scaler lives on the device, not on the host)"""
+        self.state[12 + k] = float(n)
+
+    def state_dict(self):
+        """torch.amp.GradScaler.state_dict()'s keys (scale, growth_factor, backoff_factor, growth_interval, _growth_tracker)"""
+        st = self.state.detach().cpu()
+        return {"scale": float(st[0]), "growth_factor": float(st[2]), "backoff_factor": float(st[3]), "growth_interval": int(st[4]),
+                "_growth_tracker": int(st[1])}
+
+    def load_state_dict(self, sd):
+        st = self.state.detach().cpu()
+        st[0], st[1], st[2], st[3], st[4] = float(sd["scale"]), float(sd.get("_growth_tracker", 0)), float(sd["growth_factor"]), \
+            float(sd["backoff_factor"]), float(sd["growth_interval"])
+        st[8:12] = 0.0
+        self.state.copy_(st)
 
 
 def adam_step_amp(p, g, m, v, lr, beta1, beta2, eps, weight_decay, amp, k, decoupled=False, grad_scale=1.0):
