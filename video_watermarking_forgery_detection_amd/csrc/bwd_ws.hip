@@ -80,7 +80,13 @@ __device__ __forceinline__ hx8 tr_frag(const char* p0, const char* p1) {
 // staging's compare + select + the z fma disappear; masking twice is the identity, so results do not depend on the flag
 // GVEC: the layer's output was globally pooled, so its gradient is one value per (sample, channel): the staging reads y only and takes
 // k3 + ca * gvec[b][c] (wm_bn_fold_g) from an LDS table [B][64] built at the start (bit-identical to conv3x3_ws.hip's BNBWD = 1 form)
-template <int DBG, bool PREMASKED, bool GVEC = false>
+// ALIGNED: H % 8 == 0 and W % 16 == 0 (every tile is whole).  The staged operands are then fetched with BUFFER loads: a slot's byte offset
+// is a per-thread constant (its halo pixel, relative to the tile's halo origin) plus one wave-uniform tile base -- one v_add per slot instead
+// of ~24 instructions of clamped addressing per load pair (one wave per SIMD pays an issue slot for every one of them) --, a halo pixel
+// left or right of the image reads its neighbour in memory (a valid address; the value is zeroed when it is published), one above the first
+// or below the last image falls outside the buffer descriptor's range and reads zeros; which slots lie outside the image is a wave-uniform
+// choice among four per-thread bit masks (top / bottom / left / right edge), and the a tile needs no masking at all.
+template <int DBG, bool PREMASKED, bool GVEC = false, bool ALIGNED = false>
 __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SW_BYTES + 2 * BUF_BYTES + 4 * 2 * C * 4 + 2 * C * 4 + (C * 8 + 32) * 4 + (GVEC ? GV_MAXB * C * 4 : 0)];
     hx_t* sW = reinterpret_cast<hx_t*>(smem);
@@ -147,12 +153,46 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
     const bool last_live = slot + 32 * (XV - 1) < NPX;
     hx8 dG[XV], dY[XV], dA[AV];
     unsigned okh = 0, oka = 0;
+    // ALIGNED: byte offsets of this thread's slots relative to the tile's halo origin (halo) / first pixel (a tile); edge masks: bit
+    // k + 6 e of `edge` = slot k lies in the halo's top (e = 0) / bottom (1) row, left (2) / right (3) column
+    unsigned hofs[XV], aofs[AV], edge = 0;
+    __amdgpu_buffer_rsrc_t rsG, rsY, rsX;
+    if constexpr (ALIGNED) {
+#pragma unroll
+        for (int k = 0; k < XV; ++k) {
+            const int hp = min(slot + 32 * k, NPX - 1), py = hp / HW, px = hp - py * HW;
+            hofs[k] = (unsigned)(((py * a.W + px) * C + vec * 8) * 2);
+            edge |= (py == 0 ? 1u : 0u) << k | (py == HH - 1 ? 1u : 0u) << (k + 6) | (px == 0 ? 1u : 0u) << (k + 12) | (px == HW - 1 ? 1u : 0u) << (k + 18);
+        }
+#pragma unroll
+        for (int k = 0; k < AV; ++k) {
+            const int ip = slot + 32 * k;
+            aofs[k] = (unsigned)((((ip >> 4) * a.W + (ip & 15)) * C + vec * 8) * 2);
+        }
+        const unsigned nbytes = (unsigned)a.B * (unsigned)a.H * (unsigned)a.W * (unsigned)(C * 2);
+        rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<hx_t*>(GVEC ? a.y : a.g), 0, nbytes, 0x00020000);
+        rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<hx_t*>(a.y), 0, nbytes, 0x00020000);
+        rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<hx_t*>(a.xr), 0, nbytes, 0x00020000);
+    }
+    // wave-uniform byte offset of the tile's halo origin (pixel (ty0 - 1, tx0 - 1); "negative" = wraps beyond the descriptor's range)
+    auto halo_base = [&](const TileGeo& t) { return ((unsigned)(t.b * a.H + t.ty0) * (unsigned)a.W + (unsigned)t.tx0) * (unsigned)(C * 2) - (unsigned)((a.W + 1) * C * 2); };
+    auto inside_bits = [&](const TileGeo& t) {   // ALIGNED: bit k = slot k's halo pixel of tile t lies inside the image
+        const unsigned sel = (t.ty0 == 0 ? 0x3fu : 0u) | (t.ty0 + TH == a.H ? 0x3fu << 6 : 0u) | (t.tx0 == 0 ? 0x3fu << 12 : 0u) | (t.tx0 + TW == a.W ? 0x3fu << 18 : 0u);
+        const unsigned e = edge & sel;
+        return ~(e | (e >> 6) | (e >> 12) | (e >> 18)) & 0x3fu;
+    };
     // Staged operands travel in registers for a whole tile: slot k (a 16-byte vector of g + y, or of the feeding layer's y) is requested
     // during tile t-1 right after the slot's previous content was published, and is transformed + written to the LDS during tile t
     // (for tile t+1): one register set, a prefetch distance of one tile, so the wave never waits on memory it has just asked for.
     // branch-free addressing (a branch would split the tile body's one basic block): clamp with v_med3, 24-bit multiplies, 32-bit
     // element offsets (the host checks B*H*W*64 < 2^31)
     auto load_dy_slot = [&](const TileGeo& t, int k) {
+        if constexpr (ALIGNED) {   // (okh: inside_bits(t), computed once per tile by the caller)
+            const unsigned o = halo_base(t) + hofs[k];
+            if constexpr (!GVEC) dG[k] = __builtin_bit_cast(hx8, __builtin_amdgcn_raw_buffer_load_b128(rsG, o, 0, 0));
+            dY[k] = __builtin_bit_cast(hx8, __builtin_amdgcn_raw_buffer_load_b128(rsY, o, 0, 0));
+            return;
+        }
         const int hp = min(slot + 32 * k, NPX - 1), py = (hp * 3641) >> 16, px = hp - py * HW;   // / 18 for hp < 200
         const int gy = t.ty0 - 1 + py, gx = t.tx0 - 1 + px;
         const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
@@ -162,6 +202,10 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         okh = (okh & ~(1u << k)) | (((gy == gyc && gx == gxc) ? 1u : 0u) << k);
     };
     auto load_a_slot = [&](const TileGeo& t, int k) {
+        if constexpr (ALIGNED) {   // every pixel of a whole tile lies inside the image
+            dA[k] = __builtin_bit_cast(hx8, __builtin_amdgcn_raw_buffer_load_b128(rsX, halo_base(t) + (unsigned)((a.W + 1) * C * 2) + aofs[k], 0, 0));
+            return;
+        }
         const int ip = slot + 32 * k;
         const int gy = t.ty0 + (ip >> 4), gx = t.tx0 + (ip & 15);
         const int gyc = min(gy, a.H - 1), gxc = min(gx, a.W - 1);
@@ -172,6 +216,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
     auto load_halo = [&](const TileGeo& t) {
 #pragma unroll
         for (int k = 0; k < XV; ++k) load_dy_slot(t, k);
+        if constexpr (ALIGNED) okh = inside_bits(t);
     };
     auto load_atile = [&](const TileGeo& t) {
 #pragma unroll
@@ -227,9 +272,11 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
 #pragma unroll
         for (int k = 0; k < AV; ++k) {
             u32x4 w = __builtin_bit_cast(u32x4, dA[k]);
-            const unsigned keep = 0u - ((oka >> k) & 1u);
+            if constexpr (!ALIGNED) {
+                const unsigned keep = 0u - ((oka >> k) & 1u);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w[q] &= keep;
+                for (int q = 0; q < 4; ++q) w[q] &= keep;
+            }
             *reinterpret_cast<u32x4*>(buf + (alds0 + k * 32 * 128)) = w;
         }
     };
@@ -314,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
     // issue port 4), hence the sched_group_barrier pipelines in the loop (tools/phase_bwd.py: 6.8k -> cycles per tile for this loop)
     auto hs_first = [](int h) { const int g = h / 18, r = h - 18 * g, m = r & 3; return 25 * g + (r < 16 ? (r / 4) * 5 + (m == 0 ? 0 : m == 1 ? 0 : m == 2 ? 2 : 4) : 20 + (r == 16 ? 0 : 3)); };
     auto hs_count = [](int h) { const int r = h % 18, m = r & 3; return r < 16 ? (m == 0 ? 0 : m == 3 ? 1 : 2) : (r == 16 ? 3 : 2); };
-    auto pub_unit = [&](int u, unsigned char* buf, bool refill, const TileGeo& g2) {
+    auto pub_unit = [&](int u, unsigned char* buf, bool refill, const TileGeo& g2, unsigned okn) {
         const int grp = u / 25, v = u - grp * 25;
         const int j = v < 20 ? v % 5 : v - 20;
         const bool is_dy = j < 3;
@@ -354,12 +401,17 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) w[q4] &= keep;
             if (k + 1 < XV || last_live) *reinterpret_cast<u32x4*>(buf + hlds[k]) = w;
-            if (refill && !(DBG & 64)) load_dy_slot(g2, k);   // DBG 64: no refill loads
+            if (refill && !(DBG & 64)) {   // DBG 64: no refill loads
+                load_dy_slot(g2, k);
+                if constexpr (ALIGNED) okh = (okh & ~(1u << k)) | (okn & (1u << k));   // the slot now holds tile + 2's pixel (one v_bfi)
+            }
         } else {
             u32x4 w = __builtin_bit_cast(u32x4, dA[k]);
-            const unsigned keep = 0u - ((oka >> k) & 1u);
+            if constexpr (!ALIGNED) {
+                const unsigned keep = 0u - ((oka >> k) & 1u);
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) w[q4] &= keep;
+                for (int q4 = 0; q4 < 4; ++q4) w[q4] &= keep;
+            }
             *reinterpret_cast<u32x4*>(buf + (alds0 + k * 32 * 128)) = w;
             if (refill && !(DBG & 64)) load_a_slot(g2, k);
         }
@@ -384,6 +436,8 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         unsigned char* nxt = sBuf + (((tile - t_begin) & 1) ^ 1) * BUF_BYTES;
         if constexpr (GVEC && decltype(stage_c)::value) bpub = geo(tile + 1).b;
         const TileGeo g2 = (DBG & 16) ? geo(t_begin) : geo(refill ? tile + 2 : tile);   // DBG 16: every refill re-reads the run's first tile (L2 hits)
+        unsigned okn = 0;
+        if constexpr (ALIGNED && refill) okn = inside_bits(g2);
         // this tile's epilogue operand (the feeding layer's y at this lane's two output pixels): requested first, used last
         unsigned ryv[2][8];
         bool inb[2];
@@ -502,7 +556,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                     for (int n = 0; n < 2; ++n) acc[ml][n] = HX::mfma16(filA[cb][n], pix[cb][ml], acc[ml][n]);
                 if constexpr (inter) {
 #pragma unroll
-                    for (int u = hs_first(2 * sidx); u < hs_first(2 * sidx) + hs_count(2 * sidx); ++u) pub_unit(u, nxt, refill, g2);
+                    for (int u = hs_first(2 * sidx); u < hs_first(2 * sidx) + hs_count(2 * sidx); ++u) pub_unit(u, nxt, refill, g2, okn);
                     interleave4();
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -514,18 +568,18 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                     for (int n = 0; n < 2; ++n) acc[ml][2 + n] = HX::mfma16(filB[cb][n], pix[cb][ml], acc[ml][2 + n]);
                 if constexpr (inter) {
 #pragma unroll
-                    for (int u = hs_first(2 * sidx + 1); u < hs_first(2 * sidx + 1) + hs_count(2 * sidx + 1); ++u) pub_unit(u, nxt, refill, g2);
+                    for (int u = hs_first(2 * sidx + 1); u < hs_first(2 * sidx + 1) + hs_count(2 * sidx + 1); ++u) pub_unit(u, nxt, refill, g2, okn);
                     interleave4();
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (stage && (DBG & 128) != 0) {   // DBG 128: the staging as one block after the MFMAs instead of between them
 #pragma unroll
-                for (int u = 0; u < NUNIT; ++u) { if (u % 25 < 20 && u % 5 == 0) pub_consts((u % 25) / 5); pub_unit(u, nxt, refill, g2); __builtin_amdgcn_sched_barrier(0); }
+                for (int u = 0; u < NUNIT; ++u) { if (u % 25 < 20 && u % 5 == 0) pub_consts((u % 25) / 5); pub_unit(u, nxt, refill, g2, okn); __builtin_amdgcn_sched_barrier(0); }
             }
         } else if constexpr (stage) {
 #pragma unroll
-            for (int u = 0; u < NUNIT; ++u) { if (u % 25 < 20 && u % 5 == 0) pub_consts((u % 25) / 5); pub_unit(u, nxt, refill, g2); }
+            for (int u = 0; u < NUNIT; ++u) { if (u % 25 < 20 && u % 5 == 0) pub_consts((u % 25) / 5); pub_unit(u, nxt, refill, g2, okn); }
         }
         if constexpr ((DBG & 4096) != 0) { __builtin_amdgcn_sched_barrier(0); ts[4] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         // ---------------- input-gradient epilogue: layer L-1's BatchNorm-backward sums (gz = dx * [z > 0], dx rounded as stored), pack, store
@@ -653,6 +707,13 @@ void WM_HSYM(wm_launch_bwd_ws)(const void* g, const void* y, const float* stats4
     }
 #endif
     (void)dbg;
+    const bool aligned = H % TH == 0 && W % TW == 0 && !(dbg & (1 << 20));   // (debug bit 20: the general addressing on an aligned shape, for A/B)
+    if (aligned) {
+        if (gvec) hipLaunchKernelGGL((bwd_ws_kernel<0, false, true, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+        else if (premasked) hipLaunchKernelGGL((bwd_ws_kernel<0, true, false, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((bwd_ws_kernel<0, false, false, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+        return;
+    }
     if (gvec) hipLaunchKernelGGL((bwd_ws_kernel<0, false, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
     else if (premasked) hipLaunchKernelGGL((bwd_ws_kernel<0, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((bwd_ws_kernel<0, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);

@@ -496,8 +496,10 @@ WM_KNOB_INT(g_bwd_dbg, "WM_BWD_DBG", 0);
 WM_KNOB_SETTER(wm_debug_bwd_variant, g_bwd_dbg)   // phase ablations of bwd_ws.hip (debug build only; results are then meaningless)
 extern "C" int wm_conv3x3_bwd_fused_supported(int dtype) { return (g_bwdfuse && is16(dtype)) ? 1 : 0; }
 // ... and the tensor fits the kernel's 32-bit element offsets / 24-bit row and column counts
+// (byte offsets are 32-bit, and the last MB of the range stays free so that a "negative" (wrapped) halo offset lies outside the buffer
+// descriptor's range: tensors up to 2^31 - 2^19 elements)
 extern "C" int wm_conv3x3_bwd_fused_supported_shape(int B, int H, int W, int dtype) {
-    if (!(wm_conv3x3_bwd_fused_supported(dtype) && B > 0 && H > 0 && W > 0 && (long long)B * H * W * 64 < (1LL << 31) && (long long)B * H < (1 << 23) &&
+    if (!(wm_conv3x3_bwd_fused_supported(dtype) && B > 0 && H > 0 && W > 0 && (long long)B * H * W * 64 <= (1LL << 31) - (1LL << 19) && (long long)B * H < (1 << 23) &&
           W < (1 << 23)))
         return 0;
     // the tile index is divided by mulhi with ceil(2^32 / d): exact while index * d < 2^32
@@ -517,7 +519,7 @@ extern "C" int wm_conv3x3_bwd_fused(const void* g, const float* gvec, const void
     WM_REQUIRE(y && stats4 && coef && wpt && xr && in_scale && in_shift && dx && partials && ws, WM_E_BADARG, "wm_conv3x3_bwd_fused: null pointer");
     WM_REQUIRE(wm_conv3x3_bwd_fused_supported(dtype), WM_E_SHAPE, "wm_conv3x3_bwd_fused: 16-bit activations only (dtype %d)", dtype);
     WM_REQUIRE(B > 0 && H > 0 && W > 0, WM_E_BADARG, "wm_conv3x3_bwd_fused: bad shape");
-    WM_REQUIRE((long long)B * H * W * 64 < (1LL << 31) && (long long)B * H < (1 << 23) && W < (1 << 23), WM_E_SHAPE,
+    WM_REQUIRE((long long)B * H * W * 64 <= (1LL << 31) - (1LL << 19) && (long long)B * H < (1 << 23) && W < (1 << 23), WM_E_SHAPE,
                "wm_conv3x3_bwd_fused: tensors of 2^31 elements or more (32-bit element offsets, 24-bit row / column counts)");
     WM_REQUIRE((((uintptr_t)g | (uintptr_t)y | (uintptr_t)wpt | (uintptr_t)xr | (uintptr_t)dx | (uintptr_t)ws) & 15) == 0, WM_E_SHAPE,
                "wm_conv3x3_bwd_fused: pointers must be 16-byte aligned");
