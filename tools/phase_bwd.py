@@ -1,7 +1,8 @@
 """per-phase cycle sums of the one-pass backward kernel (csrc/bwd_ws.hip, debug variant 4096 + 512: s_memtime stamps at the phase
 boundaries of wave 0's tiles, summed per workgroup and written where dx would start).
 usage: python3 tools/phase_bwd.py [extra variant bits; default 256 = the premasked form the step launches 10 times of 13]
-(only the combinations instantiated in bwd_ws.hip's debug switch exist: 0, 8, 32, 64, 256)"""
+(only the combinations instantiated in bwd_ws.hip's debug switch exist: 0, 8, 32, 64, 256; + 1048576 = the general addressing instead of
+the whole-tile buffer-addressed form, which exists for 0, 8, 256)"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

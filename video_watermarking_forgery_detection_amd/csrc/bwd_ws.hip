@@ -156,8 +156,10 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
     // ALIGNED: byte offsets of this thread's slots relative to the tile's halo origin (halo) / first pixel (a tile); edge masks: bit
     // k + 6 e of `edge` = slot k lies in the halo's top (e = 0) / bottom (1) row, left (2) / right (3) column
     unsigned hofs[XV], aofs[AV], edge = 0;
-    __amdgpu_buffer_rsrc_t rsG, rsY, rsX;
+    __amdgpu_buffer_rsrc_t rsG, rsY, rsX, rsD;
+    unsigned eofs = 0;   // this lane's epilogue pixel (tile row 2 wave, column lane & 15), channels 16 (lane >> 4): byte offset from the tile's first pixel
     if constexpr (ALIGNED) {
+        eofs = (unsigned)(((wave * 2 * a.W + (lane & 15)) * C + 16 * (lane >> 4)) * 2);
 #pragma unroll
         for (int k = 0; k < XV; ++k) {
             const int hp = min(slot + 32 * k, NPX - 1), py = hp / HW, px = hp - py * HW;
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<hx_t*>(GVEC ? a.y : a.g), 0, nbytes, 0x00020000);
         rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<hx_t*>(a.y), 0, nbytes, 0x00020000);
         rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<hx_t*>(a.xr), 0, nbytes, 0x00020000);
+        rsD = __builtin_amdgcn_make_buffer_rsrc(a.dx, 0, nbytes, 0x00020000);
     }
     // wave-uniform byte offset of the tile's halo origin (pixel (ty0 - 1, tx0 - 1); "negative" = wraps beyond the descriptor's range)
     auto halo_base = [&](const TileGeo& t) { return ((unsigned)(t.b * a.H + t.ty0) * (unsigned)a.W + (unsigned)t.tx0) * (unsigned)(C * 2) - (unsigned)((a.W + 1) * C * 2); };
@@ -440,15 +443,23 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         if constexpr (ALIGNED && refill) okn = inside_bits(g2);
         // this tile's epilogue operand (the feeding layer's y at this lane's two output pixels): requested first, used last
         unsigned ryv[2][8];
-        bool inb[2];
-        hx_t* outp[2];
+        bool inb[2] = {true, true};
+        hx_t* outp[2] = {nullptr, nullptr};
+        unsigned eo[2] = {0, 0};   // ALIGNED: byte offset of this lane's 16 channels of output pixel (row 2 wave + ml, column p) -- for xr and for dx
 #pragma unroll
         for (int ml = 0; ml < 2; ++ml) {
-            const int gy = g.ty0 + wave * 2 + ml, gx = g.tx0 + p;
-            inb[ml] = gy < a.H && gx < a.W;
-            const size_t o = inb[ml] ? (((size_t)g.b * a.H + gy) * a.W + gx) * C + 16 * q : (size_t)(16 * q);
-            outp[ml] = a.dx + o;
-            const u32x4 t0 = *reinterpret_cast<const u32x4*>(a.xr + o), t1 = *reinterpret_cast<const u32x4*>(a.xr + o + 8);
+            u32x4 t0, t1;
+            if constexpr (ALIGNED) {
+                eo[ml] = halo_base(g) + (unsigned)((a.W + 1) * C * 2) + eofs + (unsigned)(ml * a.W * C * 2);
+                t0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, eo[ml], 0, 0);
+                t1 = __builtin_amdgcn_raw_buffer_load_b128(rsX, eo[ml] + 16u, 0, 0);
+            } else {
+                const int gy = g.ty0 + wave * 2 + ml, gx = g.tx0 + p;
+                inb[ml] = gy < a.H && gx < a.W;
+                const size_t o = inb[ml] ? (((size_t)g.b * a.H + gy) * a.W + gx) * C + 16 * q : (size_t)(16 * q);
+                outp[ml] = a.dx + o;
+                t0 = *reinterpret_cast<const u32x4*>(a.xr + o); t1 = *reinterpret_cast<const u32x4*>(a.xr + o + 8);
+            }
             ryv[ml][0] = t0[0]; ryv[ml][1] = t0[1]; ryv[ml][2] = t0[2]; ryv[ml][3] = t0[3];
             ryv[ml][4] = t1[0]; ryv[ml][5] = t1[1]; ryv[ml][6] = t1[2]; ryv[ml][7] = t1[3];
         }
@@ -583,29 +594,36 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         }
         if constexpr ((DBG & 4096) != 0) { __builtin_amdgcn_sched_barrier(0); ts[4] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         // ---------------- input-gradient epilogue: layer L-1's BatchNorm-backward sums (gz = dx * [z > 0], dx rounded as stored), pack, store
-        // (one wave per SIMD pays an issue slot for every instruction: the masked dx is built by two selects per pair and the sums take
-        // THEIR operands from it -- 18 VALU instructions per channel pair; branch-free, so both pixel rows schedule as one block)
+        // (one wave per SIMD pays an issue slot for every instruction: 15 VALU instructions per channel pair; branch-free, so both pixel rows
+        // schedule as one block)
         if constexpr (!(PREMASKED || GVEC) && !(DBG & 1)) load_rsrh(0, 2);
         load_rsrh(2, 4);
         if constexpr (!(DBG & 4))
 #pragma unroll
         for (int ml = 0; ml < 2; ++ml) {
             unsigned pk[8];
+            // the ReLU mask is applied IN FRONT of the pack (a select per value, the same count as selecting halves of the packed word
+            // behind it, but without the two ANDs that prepared those halves); outside the image the threshold is +inf: nothing passes,
+            // the sums take zeros (whole-tile shapes: the threshold is the constant 0)
+            const float thr = (ALIGNED || inb[ml]) ? 0.f : __builtin_inff();
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int nf = j >> 1, i0 = 2 * (j & 1), jj = j >> 1, jh = j & 1;
-                const hx2 p2v = {(hx_t)acc[ml][nf][i0], (hx_t)acc[ml][nf][i0 + 1]};
-                const unsigned raw = inb[ml] ? __builtin_bit_cast(unsigned, p2v) : 0u;
                 const float y0 = HX::lo(ryv[ml][j]), y1 = HX::hi(ryv[ml][j]);
                 const float z0 = __builtin_fmaf(rsv[jj][2 * jh], y0, rhv[jj][2 * jh]), z1 = __builtin_fmaf(rsv[jj][2 * jh + 1], y1, rhv[jj][2 * jh + 1]);
-                const unsigned t = z0 > 0.f ? raw : (raw & 0xffff0000u);
-                pk[j] = z1 > 0.f ? t : (t & 0xffffu);   // dx leaves masked: gz, not g
+                const hx2 p2v = {(hx_t)(z0 > thr ? acc[ml][nf][i0] : 0.f), (hx_t)(z1 > thr ? acc[ml][nf][i0 + 1] : 0.f)};
+                pk[j] = __builtin_bit_cast(unsigned, p2v);   // dx leaves masked: gz, not g
                 const float gz0 = HX::lo(pk[j]), gz1 = HX::hi(pk[j]);
                 s1[2 * j] += gz0; s1[2 * j + 1] += gz1;
                 s2[2 * j] = __builtin_fmaf(gz0, y0, s2[2 * j]);
                 s2[2 * j + 1] = __builtin_fmaf(gz1, y1, s2[2 * j + 1]);
             }
-            if (inb[ml] && !(DBG & 512)) {   // DBG 512: no dx stores
+            if constexpr (ALIGNED) {
+                if (!(DBG & 512)) {   // DBG 512: no dx stores
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[0], pk[1], pk[2], pk[3]}, rsD, eo[ml], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[4], pk[5], pk[6], pk[7]}, rsD, eo[ml] + 16u, 0, 0);
+                }
+            } else if (inb[ml] && !(DBG & 512)) {
                 *reinterpret_cast<u32x4*>(outp[ml]) = u32x4{pk[0], pk[1], pk[2], pk[3]};
                 *reinterpret_cast<u32x4*>(outp[ml] + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
             }
@@ -683,9 +701,17 @@ void WM_HSYM(wm_launch_bwd_ws)(const void* g, const void* y, const float* stats4
     auto magic = [](int d) { return d == 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
     a.mX = magic(a.tilesX); a.mY = magic(a.tilesY); a.m2X = magic(2 * a.tilesX);
     a.reverse = wm_sweep_dir(reverse);
+    const bool aligned = H % TH == 0 && W % TW == 0 && !(dbg & (1 << 20));   // (debug bit 20: the general addressing on a whole-tile shape, for A/B)
 #ifdef WM_DEBUG
-    if (!gvec)   // (the ablation variants exist for the tensor-gradient form only; a gvec launch has no g to read)
+    if (!gvec && aligned)   // phase stamps of the whole-tile (buffer-addressed) form: tools/phase_bwd.py
     switch (dbg) {
+        case 4608: hipLaunchKernelGGL((bwd_ws_kernel<4608, false, false, true>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 4864: hipLaunchKernelGGL((bwd_ws_kernel<4864, false, false, true>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        case 4616: hipLaunchKernelGGL((bwd_ws_kernel<4616, false, false, true>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
+        default: break;
+    }
+    if (!gvec)   // (the ablation variants exist for the tensor-gradient form only; a gvec launch has no g to read)
+    switch (dbg & ~(1 << 20)) {
         case 1: hipLaunchKernelGGL((bwd_ws_kernel<1, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         case 2: hipLaunchKernelGGL((bwd_ws_kernel<2, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
         case 3: hipLaunchKernelGGL((bwd_ws_kernel<3, false>), dim3((unsigned)nwg), dim3(256), 0, s, a); return;
@@ -707,7 +733,6 @@ void WM_HSYM(wm_launch_bwd_ws)(const void* g, const void* y, const float* stats4
     }
 #endif
     (void)dbg;
-    const bool aligned = H % TH == 0 && W % TW == 0 && !(dbg & (1 << 20));   // (debug bit 20: the general addressing on an aligned shape, for A/B)
     if (aligned) {
         if (gvec) hipLaunchKernelGGL((bwd_ws_kernel<0, false, true, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
         else if (premasked) hipLaunchKernelGGL((bwd_ws_kernel<0, true, false, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
