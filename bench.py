@@ -12,17 +12,26 @@ D(enc) fwd/bwd, Adam(D), D(enc) + MSE + MSE fwd/bwd, Adam(enc+dec); L=30, encode
 decoder 7x64, discriminator 3x64; bf16 activations, f32 accumulate/params; synthetic data,
 random-init weights; inputs resident in HBM before the timed region.  One step = one batch.
 
+Dead work (round 3): the reference's g_loss.backward() (hidden.py:101) also accumulates the generator loss's gradients into the
+DISCRIMINATOR's parameters -- gradients no optimiser step uses and hidden.py:67 zeroes unread.  By default the bench runs
+Hidden(keep_dead_discriminator_grads=False): that pass computes the gradient wrt the encoded image only; every loss, output and
+parameter update is identical (tests/test_gpu_configs.py), and the FLOPs NOT executed are NOT counted: 239.1 GFLOP per 256x256 frame
+instead of the reference autograd's 249.0 in `step_flops_frac_of_peak` (config.workload says which).  --keep-dead-grads runs and
+counts the reference's full set.
+
 The JSON line carries, besides the driver contract:
-  roofline     -- the dominant kernel (most time per step, 13 launches): bwd_ws_kernel (csrc/bwd_ws.hip) = the whole backward of a
+  roofline     -- the dominant kernel (most time per step, 13-15 launches): bwd_ws_kernel (csrc/bwd_ws.hip) = the whole backward of a
                   64->64 body layer in one pass: input gradient with the BatchNorm-backward apply fused, the feeding layer's
                   BatchNorm sums, and the weight gradient, from one staged dy / activation tile.  Its 154.6 GFLOP ride on 4 tensor
                   passes (reads g, y, y of the layer below; writes dx = 537 MB algorithmic per launch at B=16 256x256:
                   288 FLOP/B, just under the 312 FLOP/B ridge), so the bound is HBM: achieved = algorithmic bytes / launch
                   duration measured live with events on the launch stream inside the timed region; peak = 8 TB/s; `traffic` =
-                  HBM bytes / launch from the committed rocprofv3 PMC passes of this round (profiles/r02_pmc_traffic.json;
+                  HBM bytes / launch from the committed rocprofv3 PMC passes of this round (profiles/r03_pmc_traffic.json;
                   FETCH_SIZE doubled as the gfx950 guide says); `mfma_util_pmc` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x
-                  1024 SIMDs) from the committed counter pass (profiles/r02_bench_c2_pmc_mfma.csv); `step_mfma_util_pmc` = the same
-                  ratio over every kernel of the step.  (Until this kernel the work was two launches -- the fused input gradient,
+                  1024 SIMDs) from the committed counter pass (profiles/r03_bench_c2_pmc_mfma.csv); `step_mfma_util_pmc` = the same
+                  ratio over every kernel of the step.  Those three come from a FILE, not from this run: the file carries the sha256
+                  of the kernel sources it was measured on (csrc/*, build.py), and when the sources here hash differently the three
+                  are null and `pmc_stale` is true.  (Until this kernel the work was two launches -- the fused input gradient,
                   671 MB, and the weight gradient, 268 MB: 939 MB for the same result.)
   roofline_mfma -- the runner-up, conv3x3_ws_kernel<64,64,XFORM,STATS,M16> (forward 64->64 conv, fused BN+ReLU input and
                   BatchNorm statistics, 15 launches / step): 77.3 GFLOP per launch against 2.5 PFLOP/s dense bf16
@@ -51,6 +60,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--noise", default="Jpeg50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--keep-dead-grads", action="store_true", help="also compute the discriminator weight gradients of the generator pass (the reference's state; nothing reads them)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames per step of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (median reported) after one warm-up step")
     return ap.parse_args()
@@ -137,17 +147,43 @@ def attack_roofline(timer, B, S, name):
     return out or None
 
 
+def kernel_sources_sha():
+    """sha256 over the kernel sources and the build recipe: what a committed PMC measurement is valid for"""
+    import hashlib
+    pkg = os.path.join(ROOT, "video_watermarking_forgery_detection_amd")
+    h = hashlib.sha256()
+    csrc = os.path.join(pkg, "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(pkg, "build.py"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC_FILE = "r03_pmc_traffic.json"
+_pmc = {}
+
+
 def pmc_traffic(args, S, B, key="hbm_bytes_per_launch"):
-    """HBM bytes per launch of the dominant kernel (key: of the runner-up), from this round's committed PMC passes (same workload only)."""
-    if args.dtype != "bf16" or S != 256 or B != 16:
+    """HBM bytes per launch of the dominant kernel (key: of the runner-up), from this round's committed PMC passes: same workload, same
+    kernel sources only (else None)."""
+    if args.dtype != "bf16" or S != 256 or B != 16 or args.keep_dead_grads:
         return None
+    if not _pmc:
+        try:
+            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
+                _pmc["d"] = json.load(f)
+        except (OSError, ValueError):
+            _pmc["d"] = None
+        _pmc["stale"] = _pmc["d"] is None or _pmc["d"].get("kernel_sources_sha") != kernel_sources_sha()
+    if _pmc["stale"]:
+        return None
+    d = _pmc["d"]
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            d = json.load(f)
         for part in key.split("."):
             d = d[part]
         return d
-    except (OSError, KeyError, ValueError):
+    except (KeyError, TypeError):
         return None
 
 
@@ -204,7 +240,8 @@ def main():
 
     torch.manual_seed(10)  # identical initial weights on every rank (plus the DDP-style broadcast below)
     cfg = HiDDenConfiguration(H=S, W=S)
-    h = Hidden(cfg, dev, noise, None, compute_dtype=dtype, grad_sync=GradSync() if world > 1 else None)
+    sync = GradSync(profile=True) if world > 1 else None
+    h = Hidden(cfg, dev, noise, None, compute_dtype=dtype, grad_sync=sync, keep_dead_discriminator_grads=args.keep_dead_grads)
     broadcast_parameters([h.encoder_decoder.encoder, h.encoder_decoder.decoder, h.discriminator])
     torch.manual_seed(10 + rank)  # rank r draws its shard with seed 10+r
     images = torch.rand(B, 3, S, S, device=dev)
@@ -217,6 +254,8 @@ def main():
 
     for _ in range(args.warmup):
         h.train_on_batch([images, messages])
+    if sync is not None:
+        sync.report()   # (drop the warm-up's entries)
     # the two heaviest kernels: the one-pass backward of the 64->64 body layers (13 launches / step, 16-bit activations only) and the
     # forward 64->64 conv with fused BN+ReLU input transform (15 launches / step)
     timer = ops.KernelTimer(lambda name, i: (name == "conv3x3_bwd_fused" and not i["gvec"]) or
@@ -237,6 +276,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
+    sync_rep = sync.report(args.steps) if sync is not None else None
+    if sync_rep is not None:   # every rank: its buckets and how long its compute stream stood waiting for them (the exposed part of the all-reduces)
+        sys.stderr.write(f"[bench rank {rank}] grad sync: {json.dumps(sync_rep)}\n")
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -258,6 +300,9 @@ def main():
                 "traffic": pmc_traffic(args, S, B, "fwd_hbm_bytes_per_launch"), "mfma_util_pmc": pmc_traffic(args, S, B, "fwd.mfma_util"),
                 "launches_timed": len(kms), "avg_launch_ms": avg_ms,
                 "flops_per_launch": flops_per_launch, "hbm_algorithmic_bytes_per_launch": 2.0 * tensor_bytes}
+        # FLOPs per frame as executed: the reference autograd's 249.0 GFLOP at 256x256 minus, unless --keep-dead-grads, the
+        # two 64->64 and the 3->64 discriminator weight-gradient GEMMs of the generator pass (2 x 4.832 + 0.226 GFLOP)
+        step_gflop = (249.0 if args.keep_dead_grads else 249.0 - 2 * 4.8318 - 0.2265) * (S / 256.0) ** 2
         if dms:   # bf16: the one-pass backward kernel is the dominant one; 288 FLOP/B sits just under the ridge: HBM-bound
             davg = sum(dms) / len(dms)
             dbytes = 4.0 * tensor_bytes   # reads g, y, y of the layer below; writes dx
@@ -272,11 +317,12 @@ def main():
         else:
             roof = mfma
         out = {
-            "metric": "frames/sec training step (embed->JPEG->decode), 256x256",
+            "metric": f"frames/sec training step (embed->JPEG->decode), {S}x{S}",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"C2: HiDDeN GAN step enc(4x64)->{args.noise}->dec(7x64)+disc(3x64), L=30, {S}x{S}, batch {B}/GPU",
+            "config": {"workload": f"C2: HiDDeN GAN step enc(4x64)->{args.noise}->dec(7x64)+disc(3x64), L=30, {S}x{S}, batch {B}/GPU"
+                                   + ("" if args.keep_dead_grads else "; the generator pass through the discriminator computes no (dead) discriminator weight gradients"),
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "ms_per_step_median_events": step_ms[len(step_ms) // 2], "ms_per_step_min_events": step_ms[0], "ms_per_step_max_events": step_ms[-1],
             "host_enqueue_ms_median": host_ms[len(host_ms) // 2], "host_enqueue_ms_max": host_ms[-1],
@@ -284,7 +330,10 @@ def main():
             "roofline_mfma": mfma,
             "roofline_attack": attack_roofline(timer, B, S, args.noise),
             "step_mfma_util_pmc": pmc_traffic(args, S, B, "step_mfma_util"),
-            "step_flops_frac_of_peak": (249.0e9 * (S / 256.0) ** 2 * world * B * args.steps / dt) / (peak * 1e12 * world),
+            "step_gflop_per_frame": step_gflop,
+            "step_flops_frac_of_peak": (step_gflop * 1e9 * world * B * args.steps / dt) / (peak * 1e12 * world),
+            "pmc_stale": bool(_pmc.get("stale", True)),
+            "grad_sync": sync_rep,
             "last_losses": {k.strip(): v for k, v in losses.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

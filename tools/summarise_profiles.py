@@ -8,7 +8,7 @@ import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_final")
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 os.makedirs(dst, exist_ok=True)
 NXCD, NCU, NSIMD = 8, 256, 4
 
@@ -94,9 +94,9 @@ def kern(pattern):
 
 res = {"note": "FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads); KB = 1024 B; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 * 4)",
        "step_mfma_util": step_util,
-       "bwd_fused": kern("bwd_ws_kernel<0, true, false>"),
-       "bwd_fused_unmasked_g": kern("bwd_ws_kernel<0, false, false>"),
-       "bwd_fused_gvec": kern("bwd_ws_kernel<0, false, true>"),
+       "bwd_fused": kern("bwd_ws_kernel<0, true, false"),
+       "bwd_fused_unmasked_g": kern("bwd_ws_kernel<0, false, false"),
+       "bwd_fused_gvec": kern("bwd_ws_kernel<0, false, true"),
        "dgrad_fused": kern("conv3x3_ws_kernel<64, 64, false, false, true, false, 2, true"),
        "fwd": kern("conv3x3_ws_kernel<64, 64, true, true"),
        "wgrad": kern("wgrad_ws16_kernel<64, true, 0>")}
@@ -107,6 +107,11 @@ elif res["dgrad_fused"]:
     res["hbm_bytes_per_launch"] = res["dgrad_fused"]["hbm_bytes_per_launch"]
 if res["fwd"]:
     res["fwd_hbm_bytes_per_launch"] = res["fwd"]["hbm_bytes_per_launch"]
+# what the measurement is valid for: bench.py drops these numbers when the kernel sources hash differently
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+res["kernel_sources_sha"] = bench.kernel_sources_sha()
+res["collected_at_commit"] = os.popen(f"git -C {ROOT} rev-parse --short HEAD").read().strip()
 json.dump(res, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 
 # ---- attack kernels
