@@ -109,6 +109,10 @@ int wm_resample_bwd(const float* gy, const float* y_clamped, float* gx, int N, i
  * is the identity and needs no kernel). */
 int wm_quant_fwd(const float* x, float* y, size_t n, void* stream);
 
+/* The clip loader's device path (replaces: /root/reference/data/Dataloader.py:22-57, the per-frame numpy -> cv2.resize -> torch chain):
+ * decoded frames uint8 x[N][H][W][C] (C <= 4) -> float planes y[N][C][H][W] = x * scale (1/255 for images); the resize itself is
+ * wm_resample_fwd(WM_BILINEAR) over the whole frame (half-pixel centres, no antialias = cv2.INTER_LINEAR's float arithmetic). */
+int wm_u8_hwc_to_planes(const unsigned char* x, float* y, int N, int H, int W, int C, float scale, void* stream);
 /* ------------------------------------------------------------------ layout / packing
  * image planes [B,C,H,W] f32 -> NHWC dtype with per-pixel stride ld, written at channel
  * offset c0; channels [c0+C, c0+C+zero_tail) are zero-filled (padding for MFMA K). */

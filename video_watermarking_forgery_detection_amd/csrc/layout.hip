@@ -145,6 +145,15 @@ inline int grid_for(size_t n) {
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
+// decoded frames, uint8 [N][H][W][C] (what an image decoder hands out) -> float planes [N][C][H][W] * scale: the first step of the clip
+// loader's device path (data/Dataloader.py: scale = 1/255); a thread converts one pixel (C <= 4 bytes read as one unit when C == 4)
+__global__ void u8_hwc_to_planes_kernel(const unsigned char* __restrict__ x, float* __restrict__ y, size_t npix, size_t hw, int C, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / hw, p = i - n * hw;
+        for (int c = 0; c < C; ++c) y[(n * C + c) * hw + p] = (float)x[i * C + c] * scale;
+    }
+}
+
 }  // namespace
 
 extern "C" int wm_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int ld, int c0, int zero_tail,
@@ -217,5 +226,15 @@ extern "C" int wm_concat_full(const void* x, int ldx, const float* scale, const 
         hipLaunchKernelGGL((concat_full_kernel<T>), dim3(grid), dim3(256), lds, s, (const T*)x, ldx, scale, shift,
                            msg, img, (T*)y, B, C, L, hw, ld));
     WM_LAUNCH_CHECK("wm_concat_full");
+    return WM_OK;
+}
+
+extern "C" int wm_u8_hwc_to_planes(const unsigned char* x, float* y, int N, int H, int W, int C, float scale, void* stream) {
+    WM_REQUIRE(x && y, WM_E_BADARG, "wm_u8_hwc_to_planes: null pointer");
+    WM_REQUIRE(N > 0 && H > 0 && W > 0 && C >= 1 && C <= 4, WM_E_BADARG, "wm_u8_hwc_to_planes: bad shape (1 <= C <= 4)");
+    const size_t npix = (size_t)N * H * W;
+    const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
+    hipLaunchKernelGGL(u8_hwc_to_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, npix, (size_t)H * W, C, scale);
+    WM_LAUNCH_CHECK("wm_u8_hwc_to_planes");
     return WM_OK;
 }

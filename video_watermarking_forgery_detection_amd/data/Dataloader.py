@@ -7,9 +7,16 @@ resized DIRECTLY to S x S (no crop, :33-34) by bilinear interpolation with half-
 The reference file cannot run as written (SURVEY box: `read_mask` is never called and `read_img`'s single return value is unpacked into
 two at :88, the frames are binarised by a line copied from the mask path at :38, a bare `import util`): what is implemented is its evident
 intent -- frames as floats, masks binarised at > 0, a clip accepted when its mean mask rate is below 0.2 and put on a skip list
-otherwise (:77-95), `IOError("Load <clip> Error")` on a failed read (:89-90).  cv2 is absent from the image, so decoding goes through PIL
-and the resize through torch's CPU bilinear kernel (the same arithmetic as cv2's float path; cv2's uint8 fixed-point path may differ by
-one grey level: parity unpinned for that, like every cv2 / kornia dependency of the reference)."""
+otherwise (:77-95), `IOError("Load <clip> Error")` on a failed read (:89-90).  cv2 is absent from the image, so decoding goes through PIL.
+
+Two resize paths, same arithmetic (bilinear, half-pixel centres, no antialiasing):
+  * resize_on="host" (default; works in DataLoader worker processes): torch's CPU bilinear kernel per frame;
+  * resize_on="device": the decoded uint8 frames of a clip go to the GPU as they are (854x480x3 bytes per frame instead of 3 float planes)
+    and are converted and resized there by the HIP kernels (ops.u8_hwc_to_planes -> ops.resample_fwd, the same ATen-exact bilinear kernel
+    the Crop attack runs on); items come back as CUDA tensors, so this path is for num_workers = 0 / the training process itself.
+What stays unpinned against the reference: cv2.resize on uint8 input uses a fixed-point (11-bit coefficient) path whose result can
+differ from the float arithmetic by one grey level (1/255) before the reference's `.float()`; cv2 is not in the image, the reference holds
+no fixture for its loader, and the reference's read_img cannot run as written."""
 import os
 
 import numpy as np
@@ -28,6 +35,41 @@ def _frame_key(name):
 def _resize(t, size):
     """[C,H,W] float -> [C,size,size]; cv2.INTER_LINEAR = bilinear, half-pixel centres, no antialias"""
     return F.interpolate(t.unsqueeze(0), size=(size, size), mode="bilinear", align_corners=False).squeeze(0)
+
+
+def _decode_clip(clip, root_path, sub, mode, clip_length):
+    """the clip's frames decoded on the host: uint8 [T,H,W,C] (C = 3 for "RGB", 1 for "L")"""
+    d = os.path.join(root_path, sub, clip)
+    names = sorted(os.listdir(d), key=_frame_key)
+    if clip_length:
+        names = names[:clip_length]
+    frames = [np.asarray(Image.open(os.path.join(d, n)).convert(mode), dtype=np.uint8) for n in names]
+    a = np.stack(frames)
+    return a if a.ndim == 4 else a[..., None]
+
+
+def resize_clip_device(frames_u8, size, device="cuda"):
+    """uint8 [T,H,W,C] (numpy or tensor) -> float32 [C,T,size,size] in [0,1] on the GPU: one conversion launch and one bilinear launch for
+    the whole clip (Dataloader.py:27-35 per frame on the host)"""
+    from .. import ops
+    t = torch.as_tensor(frames_u8).to(device, non_blocking=True)
+    planes = ops.u8_hwc_to_planes(t, 1.0 / 255.0)                                   # [T,C,H,W]
+    T, C, H, W = planes.shape
+    out = ops.resample_fwd(planes, (0, H, 0, W), (size, size), 0).view(T, C, size, size)    # kind 0 = bilinear
+    return out.permute(1, 0, 2, 3).contiguous()
+
+
+def read_img_device(clip, root_path, videopath, GT_size, clip_length=None, device="cuda"):
+    """read_img with the resize on the GPU: [3,T,S,S] float32 cuda"""
+    return resize_clip_device(_decode_clip(clip, root_path, videopath, "RGB", clip_length), GT_size, device)
+
+
+def read_mask_device(clip, root_path, maskpath, GT_size, clip_length=None, device="cuda"):
+    """read_mask with the resize on the GPU: ([1,T,S,S] in {0,1} cuda, mean mask rate as a float -- one host sync per clip, the skip-list
+    decision of DVDataset.__getitem__ needs the number)"""
+    m = resize_clip_device(_decode_clip(clip, root_path, maskpath, "L", clip_length), GT_size, device)
+    m = (m > 0).float()
+    return m, float(m.mean())
 
 
 def read_img(clip, root_path, videopath, GT_size, clip_length=None):
@@ -61,8 +103,11 @@ def read_mask(clip, root_path, maskpath, GT_size, clip_length=None):
 
 
 class DVDataset(data.Dataset):
-    def __init__(self, root_path='/home/groupshare/DAVIS/', image_size=256, is_train=True, clip_length=None, max_mask_rate=0.2):
+    def __init__(self, root_path='/home/groupshare/DAVIS/', image_size=256, is_train=True, clip_length=None, max_mask_rate=0.2, resize_on="host"):
         super(DVDataset, self).__init__()
+        if resize_on not in ("host", "device"):
+            raise ValueError("resize_on must be 'host' or 'device'")
+        self.resize_on = resize_on          # "device": items are CUDA tensors (HIP resize); use with num_workers = 0
         self.is_train = is_train
         self.root_path = root_path
         self.image_size = image_size
@@ -84,8 +129,9 @@ class DVDataset(data.Dataset):
                 continue
             clip = self.list[index]
             try:
-                Video_GT = read_img(clip, self.root_path, self.videopath, self.image_size, self.clip_length)
-                Mask_GT, rate = read_mask(clip, self.root_path, self.maskpath, self.image_size, self.clip_length)
+                rd_img, rd_mask = (read_img_device, read_mask_device) if self.resize_on == "device" else (read_img, read_mask)
+                Video_GT = rd_img(clip, self.root_path, self.videopath, self.image_size, self.clip_length)
+                Mask_GT, rate = rd_mask(clip, self.root_path, self.maskpath, self.image_size, self.clip_length)
             except Exception:
                 raise IOError("Load {} Error".format(clip))
             if rate < self.max_mask_rate:

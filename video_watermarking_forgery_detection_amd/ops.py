@@ -94,6 +94,18 @@ def nchw_to_nhwc(x, out, C_off=0, zero_tail=0):
     return out
 
 
+def u8_hwc_to_planes(x, scale=1.0 / 255.0):
+    """decoded frames uint8 [N,H,W,C] (cuda) -> float32 planes [N,C,H,W] * scale"""
+    _need_cuda(x)
+    assert x.dtype == torch.uint8 and x.dim() == 4 and x.shape[-1] <= 4
+    x = x.contiguous()
+    N, H, W, C = x.shape
+    y = torch.empty(N, C, H, W, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().wm_u8_hwc_to_planes(_p(x), _p(y), c_int(N), c_int(H), c_int(W), c_int(C), c_float(scale), _stream())
+    _lib.check(rc, "wm_u8_hwc_to_planes")
+    return y
+
+
 def nhwc_to_nchw(x, C, C_off=0):
     _need_cuda(x)
     B, H, W, ld = x.shape
