@@ -46,5 +46,11 @@ for i in range(N + 2):
     if i >= 2:
         ms.append(a.elapsed_time(b))
 ms.sort()
-print(json.dumps({"graph": GRAPH, "frames_per_step": bs, "dtype": str(dt).split(".")[1], "ms_per_step_median": ms[len(ms) // 2], "ms_per_step_min": ms[0],
+try:   # FLOPs as counted on the CPU oracle (tools/count_flops.py), default configuration at 256 x 256 only
+    gf = json.load(open(os.path.join(ROOT, "profiles", "r03_f1_f2_flop_counts.json")))["f2_embedder_step"]["gflop_per_frame_256"] * bs if (SIZE == 256 and BLOCKS == [8, 8, 8]) else None
+except (OSError, KeyError, ValueError):
+    gf = None
+_med = ms[len(ms) // 2]
+_peak = 157.3 if dt == torch.float32 else 2500.0
+print(json.dumps({"step_gflop": gf, "tflops": gf / _med if gf else None, "flops_frac_of_mfma_peak": gf / _med / _peak if gf else None, "graph": GRAPH, "frames_per_step": bs, "dtype": str(dt).split(".")[1], "ms_per_step_median": ms[len(ms) // 2], "ms_per_step_min": ms[0],
                   "frames_per_s": bs / ms[len(ms) // 2] * 1e3, "params": sum(p.numel() for p in net.parameters()), "loss": float(loss.detach())}))

@@ -28,5 +28,13 @@ for i in range(N + 2):
         ms.append(a.elapsed_time(b))
 ms.sort()
 params = {k: sum(p.numel() for p in getattr(model, k).parameters()) for k in ("generator", "localizer", "discriminator")}
-print(json.dumps({"frames_per_step": 6 * bs, "dtype": dt, "ms_per_step_median": ms[len(ms) // 2], "ms_per_step_min": ms[0], "params": params,
+# FLOPs of the step as torch.utils.flop_counter counts them on the CPU oracle (tools/count_flops.py -> profiles/r03_f1_f2_flop_counts.json)
+try:
+    gf = json.load(open(os.path.join(ROOT, "profiles", "r03_f1_f2_flop_counts.json")))["f1_literal_step"]["gflop_per_frame_256"] * 6 * bs
+except (OSError, KeyError, ValueError):
+    gf = None
+med = ms[len(ms) // 2]
+peak = 157.3 if dt == "f32" else 2500.0
+print(json.dumps({"frames_per_step": 6 * bs, "dtype": dt, "ms_per_step_median": med, "ms_per_step_min": ms[0], "params": params,
+                  "step_gflop": gf, "tflops": gf / med if gf else None, "flops_frac_of_mfma_peak": gf / med / peak if gf else None,
                   "logs": {k: round(v, 5) for k, v in logs}}))
