@@ -145,6 +145,8 @@ def broadcast_parameters(modules, src=0, group=None):
     for m in modules:
         if hasattr(m, "flat_params"):
             dist.broadcast(m.flat_params, src, group=group)
+            if hasattr(m, "invalidate_packs"):
+                m.invalidate_packs()      # the parameters changed behind every version counter
         else:
             for p in m.parameters():
                 dist.broadcast(p.data, src, group=group)

@@ -90,7 +90,8 @@ def _packed(conv, CoutP, CinP, dtype, perm, transpose):
     plan = getattr(conv, "_wm_plan", None)
     if plan is None:
         return ops.pack_w3x3(conv.weight.data, CoutP, CinP, dtype, perm=perm, transpose=transpose)
-    return plan.get(conv.weight.data, CoutP, CinP, dtype, perm=perm, transpose=transpose)
+    # (the Parameter itself, not a `.data` alias: its version counter is the one torch bumps for `with no_grad(): w.add_(..)` etc.)
+    return plan.get(conv.weight.detach(), CoutP, CinP, dtype, perm=perm, transpose=transpose)
 
 
 def cbr_forward(conv, bn, x, dtype, perm=None, training=True, momentum=0.1):
@@ -323,6 +324,10 @@ class FlatModule:
             off += k
         object.__setattr__(self, "_flat", flat)
         object.__setattr__(self, "_gflat", gflat)
+        if not getattr(self, "_wm_load_hook", False):
+            # a state_dict load writes the parameters behind every version check (copy_ into `.data` aliases): drop the packs
+            self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packs())
+            object.__setattr__(self, "_wm_load_hook", True)
         # BatchNorm step counters: views of one int64 tensor, so a forward bumps them with one launch
         bns = [m for m in self.modules() if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None]
         if bns:

@@ -37,6 +37,16 @@ def _need_cuda(*ts):
             raise RuntimeError("wm ops run on the GPU only (tensor is on %s); there is no CPU fallback" % t.device)
 
 
+def _wrote(*ts):
+    """a kernel of this library wrote these tensors in place through their raw pointers: bump torch's version counter of each, so that
+    every check built on `_version` (engine.cbr_backward's "is this still the tensor my consumer produced", PackPlan's stale-pack test,
+    autograd's saved-tensor check) sees the write as it sees torch's own in-place ops.  The counter is shared by a tensor and the views
+    torch made of it (a flat buffer and its slices); a parameter whose `.data` was pointed at such a view keeps a counter of its own."""
+    for t in ts:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -184,7 +194,12 @@ class PackPlan:
         self.valid = False
         self.max_elems = 0
         self._perm_dev = {}
-        self.ver = {}        # key -> the weight's autograd version at the last refresh (an in-place torch write since then = stale)
+        self.ver = {}        # key -> the weight tensor's version counter at the last refresh.  What this catches: an in-place write -- torch's or,
+                             # through ops._wrote, this library's -- to the very tensor OBJECT handed to get() (or a torch view sharing its
+                             # counter).  What it cannot catch: writes through another alias of the storage (`p.data` makes a fresh counter
+                             # every time; a parameter pointed at a slice of a flat buffer does not share the buffer's): the owner of
+                             # the parameters calls invalidate() / refresh() for those (FlatModule: optimiser step, load_state_dict,
+                             # broadcast_parameters)
 
     @staticmethod
     def key(w, CoutP, CinP, dtype, perm, transpose):
@@ -734,6 +749,7 @@ def axpy_(a, b, s=1.0):
     assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
     rc = _lib.lib().wm_axpy(_p(a), _p(b), c_float(s), c_size_t(a.numel()), _stream())
     _lib.check(rc, "wm_axpy")
+    _wrote(a)
     return a
 
 
@@ -742,6 +758,7 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, decoupled=F
                                  c_float(eps), c_float(weight_decay), c_int(1 if decoupled else 0), c_int(step),
                                  c_float(grad_scale), _stream())
     _lib.check(rc, "wm_adam_step")
+    _wrote(p, m, v)
 
 
 class AmpState:
@@ -803,6 +820,7 @@ def adam_step_amp(p, g, m, v, lr, beta1, beta2, eps, weight_decay, amp, k, decou
     rc = _lib.lib().wm_adam_step_amp(_p(p), _p(g), _p(m), _p(v), c_size_t(p.numel()), c_float(lr), c_float(beta1), c_float(beta2), c_float(eps),
                                      c_float(weight_decay), c_int(1 if decoupled else 0), c_float(grad_scale), _p(amp.state), c_int(k), _stream())
     _lib.check(rc, "wm_adam_step_amp")
+    _wrote(p, m, v)
 
 
 def sumsq(x):
@@ -891,6 +909,7 @@ def masked_axpy_(a, g, mask):
     assert a.is_contiguous() and g.is_contiguous() and g.shape == a.shape and mask.is_contiguous() and tuple(mask.shape) == (B, 1, H, W)
     rc = _lib.lib().wm_masked_axpy(_p(a), _p(g), _p(mask), c_int(B), c_int(C), c_size_t(H * W), _stream())
     _lib.check(rc, "wm_masked_axpy")
+    _wrote(a)
     return a
 
 
@@ -1575,4 +1594,5 @@ def scale_dev_(x, scale_dev):
     assert x.is_contiguous() and x.dtype == torch.float32 and scale_dev.dtype == torch.float32
     rc = _lib.lib().wm_scale_dev(_p(x), c_size_t(x.numel()), _p(scale_dev), _stream())
     _lib.check(rc, "wm_scale_dev")
+    _wrote(x)
     return x
