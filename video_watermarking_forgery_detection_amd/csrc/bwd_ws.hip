@@ -434,37 +434,41 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
         if constexpr ((DBG & 4096) != 0) ts[0] = __builtin_amdgcn_s_memtime();
         constexpr bool stage = decltype(stage_c)::value && !(DBG & 8);
         constexpr bool refill = decltype(refill_c)::value && !(DBG & 8);
-        const TileGeo g = geo(tile);
         const unsigned char* cur = sBuf + ((tile - t_begin) & 1) * BUF_BYTES;
         unsigned char* nxt = sBuf + (((tile - t_begin) & 1) ^ 1) * BUF_BYTES;
-        if constexpr (GVEC && decltype(stage_c)::value) bpub = geo(tile + 1).b;
-        const TileGeo g2 = (DBG & 16) ? geo(t_begin) : geo(refill ? tile + 2 : tile);   // DBG 16: every refill re-reads the run's first tile (L2 hits)
+        // the tile's scalar bookkeeping and the request of its epilogue operand (the feeding layer's y at this lane's two output pixels:
+        // requested early, used last) run AFTER the weight-gradient loop's first fragment reads have been issued, in the shadow of their
+        // LDS latency (one wave per SIMD: nobody else hides it)
+        TileGeo g, g2;
         unsigned okn = 0;
-        if constexpr (ALIGNED && refill) okn = inside_bits(g2);
-        // this tile's epilogue operand (the feeding layer's y at this lane's two output pixels): requested first, used last
         unsigned ryv[2][8];
         bool inb[2] = {true, true};
         hx_t* outp[2] = {nullptr, nullptr};
         unsigned eo[2] = {0, 0};   // ALIGNED: byte offset of this lane's 16 channels of output pixel (row 2 wave + ml, column p) -- for xr and for dx
+        auto head_work = [&]() __attribute__((always_inline)) {
+            g = geo(tile);
+            if constexpr (GVEC && decltype(stage_c)::value) bpub = geo(tile + 1).b;
+            g2 = (DBG & 16) ? geo(t_begin) : geo(refill ? tile + 2 : tile);   // DBG 16: every refill re-reads the run's first tile (L2 hits)
+            if constexpr (ALIGNED && refill) okn = inside_bits(g2);
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml) {
-            u32x4 t0, t1;
-            if constexpr (ALIGNED) {
-                eo[ml] = halo_base(g) + (unsigned)((a.W + 1) * C * 2) + eofs + (unsigned)(ml * a.W * C * 2);
-                t0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, eo[ml], 0, 0);
-                t1 = __builtin_amdgcn_raw_buffer_load_b128(rsX, eo[ml] + 16u, 0, 0);
-            } else {
-                const int gy = g.ty0 + wave * 2 + ml, gx = g.tx0 + p;
-                inb[ml] = gy < a.H && gx < a.W;
-                const size_t o = inb[ml] ? (((size_t)g.b * a.H + gy) * a.W + gx) * C + 16 * q : (size_t)(16 * q);
-                outp[ml] = a.dx + o;
-                t0 = *reinterpret_cast<const u32x4*>(a.xr + o); t1 = *reinterpret_cast<const u32x4*>(a.xr + o + 8);
+            for (int ml = 0; ml < 2; ++ml) {
+                u32x4 t0, t1;
+                if constexpr (ALIGNED) {
+                    eo[ml] = halo_base(g) + (unsigned)((a.W + 1) * C * 2) + eofs + (unsigned)(ml * a.W * C * 2);
+                    t0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, eo[ml], 0, 0);
+                    t1 = __builtin_amdgcn_raw_buffer_load_b128(rsX, eo[ml] + 16u, 0, 0);
+                } else {
+                    const int gy = g.ty0 + wave * 2 + ml, gx = g.tx0 + p;
+                    inb[ml] = gy < a.H && gx < a.W;
+                    const size_t o = inb[ml] ? (((size_t)g.b * a.H + gy) * a.W + gx) * C + 16 * q : (size_t)(16 * q);
+                    outp[ml] = a.dx + o;
+                    t0 = *reinterpret_cast<const u32x4*>(a.xr + o); t1 = *reinterpret_cast<const u32x4*>(a.xr + o + 8);
+                }
+                ryv[ml][0] = t0[0]; ryv[ml][1] = t0[1]; ryv[ml][2] = t0[2]; ryv[ml][3] = t0[3];
+                ryv[ml][4] = t1[0]; ryv[ml][5] = t1[1]; ryv[ml][6] = t1[2]; ryv[ml][7] = t1[3];
             }
-            ryv[ml][0] = t0[0]; ryv[ml][1] = t0[1]; ryv[ml][2] = t0[2]; ryv[ml][3] = t0[3];
-            ryv[ml][4] = t1[0]; ryv[ml][5] = t1[1]; ryv[ml][6] = t1[2]; ryv[ml][7] = t1[3];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr ((DBG & 4096) != 0) { ts[1] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        };
+        if constexpr ((DBG & 2) != 0) { head_work(); if constexpr ((DBG & 4096) != 0) ts[1] = __builtin_amdgcn_s_memtime(); }
         // ---------------- weight gradient: 4 K-steps x 9 taps x (2 x 2 fragments); the dy fragments of the next tap are requested while
         // this tap's four MFMAs run (fenced: an unfenced schedule hoists dozens of fragment reads and spills)
         if constexpr (!(DBG & 2)) {
@@ -486,6 +490,9 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
             load_b(0, 0);
 #pragma unroll
             for (int i = 0; i < WR - 1; ++i) load_a(i, i);
+            head_work();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((DBG & 4096) != 0) { ts[1] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
             for (int st = 0; st < 36; ++st) {
                 const int ks = st / 9, tap = st - ks * 9;
