@@ -32,10 +32,16 @@ cd $ROOT
  python3 tools/bench_c5.py train_hidden_c5_fp16.yml f16 72) 2> $OUT/c3_c5.err | grep '^{' > $OUT/c3_c5_steps.jsonl
 (python3 tools/bench_literal.py 4 bf16 12 && python3 tools/bench_literal.py 4 f16 12) 2> $OUT/literal.err | grep '^{' > $OUT/literal_steps.jsonl
 (python3 tools/bench_inn.py 8 bf16 6 && python3 tools/bench_inn.py 8 bf16 6 graph && python3 tools/bench_inn.py 8 f16 6 graph) 2> $OUT/inn.err | grep '^{' > $OUT/inn_steps.jsonl
-(python3 tools/phase_bwd.py 0 && python3 tools/phase_bwd.py 256 && python3 tools/phase_bwd.py 8) 2>&1 | grep -v amdgpu.ids > $OUT/bwd_phase_cycles.txt
+(python3 tools/phase_bwd.py 0 && python3 tools/phase_bwd.py 256 && python3 tools/phase_bwd.py 8 && python3 tools/phase_bwd.py 1048832) 2>&1 | grep -v amdgpu.ids > $OUT/bwd_phase_cycles.txt
 if [ -x tools/micro/mfma_rate ]; then tools/micro/mfma_rate > $OUT/mfma_coissue_micro.txt 2>&1; fi
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lit_stats -o l -- python3 $ROOT/tools/bench_literal.py 4 bf16 6 > $OUT/lit_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_stats -o c -- python3 $ROOT/tools/bench_c5.py train_hidden_c5_fp16.yml f16 44 > $OUT/c5_stats.log 2>&1
+# north_star's second size: 512 x 512 (C4's per-GPU shard: 8 frames), bench line + kernel stats
+python3 $ROOT/bench.py --no-cpu-baseline --size 512 --batch 8 2> $OUT/b512.err | tail -1 > $OUT/bench_512_b8.json
+python3 $ROOT/bench.py --no-cpu-baseline --keep-dead-grads 2> /dev/null | tail -1 > $OUT/bench_c2_keep_dead_grads.json
+python3 $ROOT/bench.py --no-cpu-baseline 2> /dev/null | tail -1 > $OUT/bench_c2.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s512_stats -o q -- python3 $ROOT/bench.py --no-cpu-baseline --size 512 --batch 8 --steps 10 --warmup 3 > $OUT/s512_stats.log 2>&1
+bash $ROOT/tools/pmc_bwd.sh > $OUT/bwd_sq_counters.txt 2>&1
 echo "widened done"
 ls -R $OUT | head -40

@@ -18,6 +18,6 @@ w = torch.randn(C, C, 3, 3, device="cuda") * 0.05
 wpt = ops.pack_w3x3(w, C, C, dt, transpose=True)
 dw = torch.zeros(C, C, 3, 3, device="cuda")
 for _ in range(n):
-    ops.conv3x3_bwd_fused(g, y, stats, coef, wpt, xr, sc, sh, dw, False)
+    ops.conv3x3_bwd_fused(g, y, stats, coef, wpt, xr, sc, sh, dw, False, premasked=True)   # the form the step launches (11 of its 13 launches)
 torch.cuda.synchronize()
 print("done", n)

@@ -132,13 +132,16 @@ except (IndexError, OSError) as e:
     print("attack profiles missing:", e)
 # ---- widened configurations, the literal step, the one-pass backward kernel's phases, the co-issue microbenchmark
 for name, out in (("c3_c5_steps.jsonl", f"{tag}_c3_c5_steps.jsonl"), ("literal_steps.jsonl", f"{tag}_literal_steps.jsonl"), ("inn_steps.jsonl", f"{tag}_inn_steps.jsonl"),
-                  ("bwd_phase_cycles.txt", f"{tag}_bwd_phase_cycles.txt"), ("mfma_coissue_micro.txt", f"{tag}_mfma_coissue_micro.txt")):
+                  ("bwd_phase_cycles.txt", f"{tag}_bwd_phase_cycles.txt"), ("mfma_coissue_micro.txt", f"{tag}_mfma_coissue_micro.txt"),
+                  ("bench_512_b8.json", f"{tag}_bench_512_b8.json"), ("bench_c2.json", f"{tag}_bench_c2.json"),
+                  ("bench_c2_keep_dead_grads.json", f"{tag}_bench_c2_keep_dead_grads.json"), ("bwd_sq_counters.txt", f"{tag}_bwd_sq_counters.txt")):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 0:
         shutil.copy(f, os.path.join(dst, out))
     else:
         print("missing:", name)
 for sub, base, steps, cmd in (("lit_stats", f"{tag}_literal_step_kernel_stats", 8.0, "python3 tools/bench_literal.py 4 bf16 6   (8 steps: the reference's literal IRNrhi step, 24 frames 256x256, bf16)"),
+                              ("s512_stats", f"{tag}_bench_512_b8_kernel_stats", 13.0, "python3 bench.py --no-cpu-baseline --size 512 --batch 8 --steps 10 --warmup 3   (13 steps of 8 frames 512x512)"),
                               ("c5_stats", f"{tag}_c5_fp16_kernel_stats", 42.0, "python3 tools/bench_c5.py train_hidden_c5_fp16.yml f16 44   (42 steps with work, 16 frames 256x256 each, UNet head, f16 + device GradScaler)")):
     try:
         stats_summary(sub, base, steps, cmd)
