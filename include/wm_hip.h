@@ -270,6 +270,18 @@ int wm_concat_side_msg_wgrad(const void* dy, const float* msg, float* partial, f
                              int W, int Cin, int c_msg, int L, int dtype, void* stream);
 int wm_conv3x3_fwd_addin(const void* x, const void* wp, const float* in_scale, const float* in_shift, const void* addend, void* y,
                          float* stat_partials, int B, int H, int W, int dtype, int sweep_reverse, void* stream);
+/* The backward of an IMAGE-FED first ConvBNRelu (3 -> 64 channels; replaces autograd's backward of conv_bn_relu.py:11-15 for the layers of
+ * decoder.py:16 / discriminator.py:13, whose input image needs a gradient) in ONE pass (csrc/bwd_ws16.hip): reads g, y [B,H,W,64] (gradient
+ * wrt the layer's ReLU output, its raw conv output; stats4 / coef as wm_conv3x3_dgrad_applyfused) and the layer's input x [B,H,W,16] (the
+ * image, 3 real channels), forms dy while staging and produces dx [B,H,W,16] = conv(dy, wpt) (wpt [9][16][64] from wm_pack_w3x3, transposed)
+ * and dw [Cout][Cin][3][3] (+)= sum dy (x) x through ws (f32 [wm_conv3x3_bwd_fused16_nwg][9][16][64] slabs + wm_conv3x3_wgrad's reduction).
+ * dy is never written: 335 MB per launch at B = 16, 256x256 instead of the two-kernel form's 637.  Whole-tile shapes only
+ * (_supported: H % 8 == 0, W % 16 == 0, 16-bit dtype); g_premasked as wm_conv3x3_bwd_fused. */
+int wm_conv3x3_bwd_fused16_supported(int B, int H, int W, int dtype);
+int wm_conv3x3_bwd_fused16_nwg(int B, int H, int W);
+int wm_conv3x3_bwd_fused16(const void* g, const void* y, const float* stats4, const float* coef, const void* wpt, const void* x, void* dx,
+                           float* ws, float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, int dtype, int g_premasked,
+                           int sweep_reverse, void* stream);
 int wm_conv3x3_dgrad_bwdstats_supported(int CoutY, int CinP, int dtype);
 int wm_conv3x3_dgrad_bwdstats(const void* src, int lds, int CoutY, const void* wpt, const float* gvec, const float* stats4,
                               const float* coef, const void* ry, const float* r_scale, const float* r_shift, void* dx,

@@ -1037,3 +1037,51 @@ def test_fused_backward_kernel_gvec_form(case):
     assert (dw1 - dw0).abs().max().item() <= 2e-4 * dw0.abs().max().item()
     with pytest.raises(RuntimeError):
         ops.conv3x3_bwd_fused(None, y, stats, coef, wpt, xr, in_scale, in_shift, dw1, False)      # neither g nor gvec
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, torch.bfloat16, False), (3, 24, 48, torch.bfloat16, True), (1, 8, 16, torch.bfloat16, False),
+                                  (16, 128, 128, torch.bfloat16, True), (2, 40, 32, torch.float16, False), (5, 8, 208, torch.bfloat16, True)])
+def test_fused_backward_of_an_image_fed_first_layer(case):
+    """csrc/bwd_ws16.hip (3 -> 64 first layer whose image input needs a gradient: dx and dW from one staged dy tile) against the two-kernel
+    form on the same operands: wm_conv3x3_dgrad_applyfused (writes dy, dx with 32 channels) + wm_conv3x3_wgrad on the 16-channel image."""
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, dt, rev = case
+    C = 64
+    g = nhwc(detgen.normal((B, C, H, W), 951, std=0.1), dt, C)
+    y = nhwc(detgen.normal((B, C, H, W), 952, mean=0.2), dt, C)
+    x16 = torch.zeros(B, H, W, 16, device="cuda", dtype=dt)
+    ops.nchw_to_nhwc(detgen.uniform((B, 3, H, W), 953).cuda(), x16, 0, 13)
+    stats = torch.empty(4, C, device="cuda")
+    stats[0] = detgen.normal((C,), 954, mean=1.0, std=0.3).cuda(); stats[1] = detgen.normal((C,), 955, std=0.3).cuda()
+    stats[2] = detgen.normal((C,), 956, std=0.2).cuda(); stats[3] = detgen.uniform((C,), 957).cuda() + 0.5
+    coef = torch.empty(3, C, device="cuda")
+    coef[0] = detgen.normal((C,), 958, mean=1.0, std=0.2).cuda(); coef[1] = detgen.normal((C,), 959, std=0.01).cuda(); coef[2] = detgen.normal((C,), 960, std=0.01).cuda()
+    w = detgen.normal((C, 3, 3, 3), 961, std=0.2).cuda()
+    assert ops.conv3x3_bwd_fused16_supported(y.shape, dt) and not ops.conv3x3_bwd_fused16_supported((B, H + 1, W, C), dt)
+    # the two-kernel form
+    wpt32 = ops.pack_w3x3(w, C, 32, dt, transpose=True)
+    dy, dx0, _ = ops.conv3x3_dgrad_applyfused(g, y, stats, coef, wpt32, reverse=rev)
+    dw0 = torch.zeros(C, 3, 3, 3, device="cuda")
+    ops.conv3x3_wgrad(x16, 16, None, None, dy, dw0, False, reverse=not rev)
+    # one pass
+    wpt16 = ops.pack_w3x3(w, C, 16, dt, transpose=True)
+    dw1 = torch.full((C, 3, 3, 3), 0.25, device="cuda")
+    dx1 = ops.conv3x3_bwd_fused16(g, y, stats, coef, wpt16, x16, dw1, True, reverse=rev)
+    torch.cuda.synchronize()
+    assert tuple(dx1.shape) == (B, H, W, 16) and dx0.float().abs().max().item() > 0
+    assert float(dx1[..., 3:].float().abs().max()) == 0.0                       # the 13 padding channels of the image tensor
+    if dt == torch.bfloat16:
+        assert torch.equal(dx1[..., :3], dx0[..., :3])                          # same dy, same MFMA order over K
+    else:
+        d = (dx1[..., :3].float() - dx0[..., :3].float()).abs()
+        assert (d > 0).float().mean().item() < 2e-3 and d.max().item() <= 2.0 ** -10 * max(1.0, dx0.float().abs().max().item())
+    assert (dw1 - (dw0 + 0.25)).abs().max().item() <= 2e-4 * dw0.abs().max().item()
+    # a gradient already multiplied by the layer's ReLU mask gives the same results with the flag
+    zl = stats[0] * y.float() + stats[1]
+    gm = torch.where(zl > 0, g, torch.zeros_like(g))
+    dw2 = torch.zeros(C, 3, 3, 3, device="cuda"); dw3 = torch.zeros(C, 3, 3, 3, device="cuda")
+    dx2 = ops.conv3x3_bwd_fused16(gm, y, stats, coef, wpt16, x16, dw2, False, reverse=rev, premasked=True)
+    dx3 = ops.conv3x3_bwd_fused16(gm, y, stats, coef, wpt16, x16, dw3, False, reverse=rev, premasked=False)
+    assert torch.equal(dx2, dx3) and torch.equal(dw2, dw3)
+    near0 = (zl.abs() <= 1e-4).float().mean().item()
+    assert near0 < 1e-3 and (dx2.float() - dx1.float()).abs().max().item() <= (1e-6 if near0 == 0 else 1.0)

@@ -38,6 +38,11 @@ template <typename... A> static inline void wm_launch_wgrad_ws(int dtype, A... a
     else wm_launch_wgrad_ws_bf16(args...);
 }
 static inline bool is16(int dtype) { return dtype == WM_BF16 || dtype == WM_F16; }
+// fused input + weight gradient of an image-fed first layer (bwd_ws16.hip), compiled twice
+void wm_launch_bwd_ws16_bf16(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt, const void* x,
+                             void* dx, float* ws, int B, int H, int W, int nwg, int reverse, hipStream_t s, int premasked);
+void wm_launch_bwd_ws16_f16(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt, const void* x,
+                            void* dx, float* ws, int B, int H, int W, int nwg, int reverse, hipStream_t s, int premasked);
 // fused input + weight gradient of a 64 -> 64 body layer (bwd_ws.hip), compiled twice like the above
 #define WM_DECL_BWDWS(sfx)                                                                                                             \
     void wm_launch_bwd_ws##sfx(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt,      \
@@ -530,6 +535,36 @@ extern "C" int wm_conv3x3_bwd_fused(const void* g, const float* gvec, const void
     WM_LAUNCH_CHECK("wm_conv3x3_bwd_fused");
     return WM_OK;
 }
+// ---- the image-fed first layer in one pass (bwd_ws16.hip): input gradient wrt the 16-channel image tensor + weight gradient
+WM_KNOB_ON(g_bwdfuse16, "WM_NO_BWD_FUSE16");
+WM_KNOB_SETTER(wm_debug_bwd_fuse16, g_bwdfuse16)   // A/B knob (debug build only)
+extern "C" int wm_conv3x3_bwd_fused16_supported(int B, int H, int W, int dtype) {
+    return (g_bwdfuse16 && is16(dtype) && B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 16 == 0 &&
+            (long long)B * H * W * 64 <= (1LL << 31) - (1LL << 19)) ? 1 : 0;
+}
+extern "C" int wm_conv3x3_bwd_fused16_nwg(int B, int H, int W) {
+    const long n = (long)B * (H / 8) * (W / 16);
+    return (int)(n < 512 ? n : 512);   // two workgroups per CU
+}
+extern "C" int wm_conv3x3_bwd_fused16(const void* g, const void* y, const float* stats4, const float* coef, const void* wpt, const void* x,
+                                      void* dx, float* ws, float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, int dtype,
+                                      int g_premasked, int sweep_reverse, void* stream) {
+    WM_REQUIRE(g && y && stats4 && coef && wpt && x && dx && ws && dw, WM_E_BADARG, "wm_conv3x3_bwd_fused16: null pointer");
+    WM_REQUIRE(wm_conv3x3_bwd_fused16_supported(B, H, W, dtype), WM_E_SHAPE,
+               "wm_conv3x3_bwd_fused16: 16-bit activations, H %% 8 == 0, W %% 16 == 0, fewer than 2^31 elements (B=%d H=%d W=%d dtype=%d)", B, H, W, dtype);
+    WM_REQUIRE(Cin > 0 && Cin <= 16 && Cout > 0 && Cout <= 64, WM_E_SHAPE, "wm_conv3x3_bwd_fused16: Cin <= 16, Cout <= 64 (got %d, %d)", Cin, Cout);
+    WM_REQUIRE((((uintptr_t)g | (uintptr_t)y | (uintptr_t)wpt | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)ws) & 15) == 0, WM_E_SHAPE,
+               "wm_conv3x3_bwd_fused16: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int nwg = wm_conv3x3_bwd_fused16_nwg(B, H, W);
+    if (dtype == WM_F16) wm_launch_bwd_ws16_f16(g, y, stats4, 64, coef, wpt, x, dx, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_premasked);
+    else wm_launch_bwd_ws16_bf16(g, y, stats4, 64, coef, wpt, x, dx, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_premasked);
+    WM_LAUNCH_CHECK("wm_conv3x3_bwd_fused16");
+    WM_REQUIRE(launch_wgrad_reduce(ws, nwg, 16, 64, dw, Cin, Cout, nullptr, accumulate, nullptr, s) == WM_OK, WM_E_BADARG, "wm_conv3x3_bwd_fused16: reduction");
+    WM_LAUNCH_CHECK("wm_conv3x3_bwd_fused16(reduce)");
+    return WM_OK;
+}
+
 // the slab reduction of wm_conv3x3_bwd_fused's workspace (its own call so that the kernel above can be timed alone): dw (+)= sum of the
 // nwg slabs; `fin`: an optional BatchNorm-backward finalisation riding on the launch, as in wm_conv3x3_wgrad_fin
 extern "C" int wm_conv3x3_bwd_fused_reduce(float* ws, float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, const WmBnBwdFin* fin,

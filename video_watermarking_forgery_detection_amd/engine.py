@@ -240,6 +240,14 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
             return tag(gx)
         ops.conv3x3_wgrad_gvfused(x.t, x.scale, x.shift, gvec, y, ctx.stats, coef, grads[conv.weight], accumulate)
         return tag(ops.conv3x3_dgrad_gvfused(y, wpt, gvec, ctx.stats, coef))
+    # An image-fed first layer whose input needs a gradient too (the decoder's and the discriminator's conv1): one kernel forms dy from
+    # (g, y) once and feeds both the input gradient (16 channels, 3 real) and the weight gradient (csrc/bwd_ws16.hip); no dy tensor
+    if (g is not None and need_input_grad and x.scale is None and perm_dev is None and ctx.perm is None and dgrad_channels is None
+            and x.t.shape[-1] == 16 and y.shape[-1] == 64 and g.shape == y.shape and g.is_contiguous() and ctx.stats.is_contiguous()
+            and conv.weight.shape[1] <= 16 and ops.conv3x3_bwd_fused16_supported(y.shape, dtype)):
+        gx = ops.conv3x3_bwd_fused16(g, y, ctx.stats, coef_of(), _packed(conv, 64, 16, dtype, None, True), x.t, grads[conv.weight], accumulate,
+                                     reverse=d, premasked=pre is not None and getattr(g, "_wm_masked", False))
+        return tag(gx)
     # An ordinary 64 -> 64 layer: the input-gradient kernel reads g and y, forms dy while staging and leaves it in memory
     # for the weight gradient -- the stand-alone apply pass is gone.
     if (g is not None and need_input_grad and perm_dev is None and ctx.perm is None and rows in (64, 32)

@@ -561,6 +561,29 @@ def conv3x3_bwd_fused(g, y, stats, coef, wpt, xr, in_scale, in_shift, dw, accumu
     return dx, part, fcoef
 
 
+def conv3x3_bwd_fused16_supported(shape, dtype):
+    """the one-kernel backward of an image-fed first layer exists for y's shape [B,H,W,64] (whole 8x16 tiles) and dtype"""
+    return bool(_lib.lib().wm_conv3x3_bwd_fused16_supported(c_int(shape[0]), c_int(shape[1]), c_int(shape[2]), c_int(dt_id(dtype))))
+
+
+def conv3x3_bwd_fused16(g, y, stats, coef, wpt, x, dw, accumulate, reverse=False, premasked=False):
+    """The whole backward of an image-fed first ConvBNRelu in one pass (csrc/bwd_ws16.hip): returns dx [B,H,W,16] (gradient wrt the 16-channel
+    image tensor x); dw [Cout,Cin<=16,3,3] is written in place by the slab reduction that follows the kernel."""
+    B, H, W, C = y.shape
+    assert C == 64 and g.shape == y.shape and g.is_contiguous() and y.is_contiguous() and tuple(x.shape) == (B, H, W, 16) and x.is_contiguous()
+    assert tuple(wpt.shape) == (9, 16, 64) and stats.is_contiguous() and coef.is_contiguous() and dw.is_contiguous() and dw.shape[0] <= 64 and dw.shape[1] <= 16
+    L = _lib.lib()
+    nwg = L.wm_conv3x3_bwd_fused16_nwg(c_int(B), c_int(H), c_int(W))
+    dx = torch.empty(B, H, W, 16, device=y.device, dtype=y.dtype)
+    ws = torch.empty(nwg * 9 * 16 * 64, device=y.device, dtype=torch.float32)
+    info = {"B": B, "H": H, "W": W, "dtype": y.dtype}
+    rc = _timed("conv3x3_bwd_fused16", info, lambda: L.wm_conv3x3_bwd_fused16(
+        _p(g), _p(y), _p(stats), _p(coef), _p(wpt), _p(x), _p(dx), _p(ws), _p(dw), c_int(1 if accumulate else 0), c_int(B), c_int(H), c_int(W),
+        c_int(dw.shape[1]), c_int(dw.shape[0]), c_int(dtype_id(y)), c_int(1 if premasked else 0), _sweep(reverse), _stream()))
+    _lib.check(rc, "wm_conv3x3_bwd_fused16")
+    return dx
+
+
 def linear_head_fwd(pooled, w, bias, I):
     """pooled [B,ldp] f32 (first I columns used), w [O,I], bias [O] -> [B,O]"""
     _need_cuda(pooled, w)
