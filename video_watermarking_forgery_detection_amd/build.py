@@ -23,18 +23,18 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # MFMA kernels: keep the compiler from SLP-packing scalar f32 VALU into v_pk_*_f32 -- packed f32 issues far slower
 # than two scalar ops beside MFMAs (MI355X_MICROARCH.md, constants table)
-MFMA_FILES = ("conv3x3_ws.hip", "bwd_ws.hip", "bwd_ws16.hip", "wgrad_ws.hip", "upconv_mfma.hip", "conv3x3_stream.hip", "concat_side.hip", "gconv.hip")
+MFMA_FILES = ("conv3x3_ws.hip", "bwd_ws.hip", "bwd_ws8.hip", "bwd_ws16.hip", "wgrad_ws.hip", "upconv_mfma.hip", "conv3x3_stream.hip", "concat_side.hip", "gconv.hip")
 EXTRA = {f: ["-fno-slp-vectorize"] for f in MFMA_FILES}
 # every compile reports its kernels' registers (-Rpass-analysis=kernel-resource-usage); a kernel of these files that spills or uses
 # scratch memory FAILS the build: a scratch reload counts in vmcnt and stalls the tile prefetch of the persistent kernels
-NO_SPILL = ("conv3x3_ws.hip", "bwd_ws.hip", "bwd_ws16.hip", "wgrad_ws.hip", "conv3x3_stream.hip", "upconv_mfma.hip", "concat_side.hip")
+NO_SPILL = ("conv3x3_ws.hip", "bwd_ws.hip", "bwd_ws8.hip", "bwd_ws16.hip", "wgrad_ws.hip", "conv3x3_stream.hip", "upconv_mfma.hip", "concat_side.hip")
 # (file, f16 twin?, substring of the mangled kernel name) known and accepted to spill, with the reason
 SPILL_OK = (("wgrad_ws.hip", True, "wgrad_ws16_kernelILi64ELb1ELi2EE"),)   # f16 twin of the pooled-layer weight gradient: 11 VGPRs; superseded on the step by bwd_ws<GVEC>
 REMARK = "-Rpass-analysis=kernel-resource-usage"
 
 
 # kernels of these files exist for both 16-bit activation dtypes: compiled a second time with -DWM_H16_F16 (the f16 twins)
-TWICE = ("conv3x3_ws.hip", "wgrad_ws.hip", "conv3x3_stream.hip", "upconv_mfma.hip", "concat_side.hip", "bwd_ws.hip", "bwd_ws16.hip")
+TWICE = ("conv3x3_ws.hip", "wgrad_ws.hip", "conv3x3_stream.hip", "upconv_mfma.hip", "concat_side.hip", "bwd_ws.hip", "bwd_ws8.hip", "bwd_ws16.hip")
 
 
 def _sources():

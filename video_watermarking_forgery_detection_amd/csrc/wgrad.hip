@@ -38,6 +38,13 @@ template <typename... A> static inline void wm_launch_wgrad_ws(int dtype, A... a
     else wm_launch_wgrad_ws_bf16(args...);
 }
 static inline bool is16(int dtype) { return dtype == WM_BF16 || dtype == WM_F16; }
+// the same with the two GEMMs on different waves (bwd_ws8.hip: whole-tile shapes, premasked gradient), compiled twice
+#define WM_DECL_BWDWS8(sfx)                                                                                                            \
+    void wm_launch_bwd_ws8##sfx(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt,     \
+                                const void* xr, const float* in_scale, const float* in_shift, void* dx, float* stat, float* ws, int B, \
+                                int H, int W, int nwg, int reverse, hipStream_t s, int premasked, const float* gvec, int gv_ld)
+WM_DECL_BWDWS8(_bf16);
+WM_DECL_BWDWS8(_f16);
 // fused input + weight gradient of an image-fed first layer (bwd_ws16.hip), compiled twice
 void wm_launch_bwd_ws16_bf16(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt, const void* x,
                              void* dx, float* ws, int B, int H, int W, int nwg, int reverse, hipStream_t s, int premasked);
@@ -499,6 +506,8 @@ WM_KNOB_ON(g_bwdfuse, "WM_NO_BWD_FUSE");
 WM_KNOB_SETTER(wm_debug_bwd_fuse, g_bwdfuse)   // A/B knob (tools/ab_step.py, debug build only)
 WM_KNOB_INT(g_bwd_dbg, "WM_BWD_DBG", 0);
 WM_KNOB_SETTER(wm_debug_bwd_variant, g_bwd_dbg)   // phase ablations of bwd_ws.hip (debug build only; results are then meaningless)
+WM_KNOB_ON(g_bwd_split, "WM_NO_BWD_SPLIT");
+WM_KNOB_SETTER(wm_debug_bwd_split, g_bwd_split)   // A/B knob (debug build only): 0 = every form on bwd_ws.hip
 extern "C" int wm_conv3x3_bwd_fused_supported(int dtype) { return (g_bwdfuse && is16(dtype)) ? 1 : 0; }
 // ... and the tensor fits the kernel's 32-bit element offsets / 24-bit row and column counts
 // (byte offsets are 32-bit, and the last MB of the range stays free so that a "negative" (wrapped) halo offset lies outside the buffer
@@ -530,7 +539,12 @@ extern "C" int wm_conv3x3_bwd_fused(const void* g, const float* gvec, const void
                "wm_conv3x3_bwd_fused: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int nwg = wm_conv3x3_bwd_fused_nwg(B, H, W);
-    if (dtype == WM_F16) wm_launch_bwd_ws_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked, gvec, 64);
+    // whole-tile shapes with a premasked tensor gradient (what the step launches 11 times of 13): the role-split 8-wave form
+    const bool split = g_bwd_split && !gvec && g_premasked && H % 8 == 0 && W % 16 == 0 && g_bwd_dbg == 0;
+    if (split) {
+        if (dtype == WM_F16) wm_launch_bwd_ws8_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, 1, nullptr, 64);
+        else wm_launch_bwd_ws8_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, 1, nullptr, 64);
+    } else if (dtype == WM_F16) wm_launch_bwd_ws_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked, gvec, 64);
     else wm_launch_bwd_ws_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked, gvec, 64);
     WM_LAUNCH_CHECK("wm_conv3x3_bwd_fused");
     return WM_OK;
