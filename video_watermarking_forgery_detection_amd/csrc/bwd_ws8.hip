@@ -512,8 +512,10 @@ void WM_HSYM(wm_launch_bwd_ws8)(const void* g, const void* y, const float* stats
     auto magic = [](int d) { return d == 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
     a.mX = magic(a.tilesX); a.mY = magic(a.tilesY); a.m2X = magic(2 * a.tilesX);
     a.reverse = wm_sweep_dir(reverse);
-    // (only the premasked form is instantiated: the other two need 1-15 registers more than a two-waves-per-SIMD kernel has; they stay on
-    // bwd_ws.hip -- wgrad.hip dispatches)
-    (void)premasked; (void)gvec;
-    hipLaunchKernelGGL((bwd_ws8_kernel<true, false>), dim3((unsigned)nwg), dim3(512), 0, s, a);
+    // (the unmasked-gradient form is not instantiated: it needs ~15 registers more than a two-waves-per-SIMD kernel has and stays on
+    // bwd_ws.hip -- wgrad.hip dispatches.  The per-sample-gradient form parks ONE loop-invariant LDS offset in scratch, reloaded only in the
+    // bodies of a run's last two tiles, never in the steady-state loop: build.py's SPILL_OK names it)
+    (void)premasked;
+    if (gvec) hipLaunchKernelGGL((bwd_ws8_kernel<false, true>), dim3((unsigned)nwg), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((bwd_ws8_kernel<true, false>), dim3((unsigned)nwg), dim3(512), 0, s, a);
 }

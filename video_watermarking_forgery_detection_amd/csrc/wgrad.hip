@@ -539,11 +539,11 @@ extern "C" int wm_conv3x3_bwd_fused(const void* g, const float* gvec, const void
                "wm_conv3x3_bwd_fused: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int nwg = wm_conv3x3_bwd_fused_nwg(B, H, W);
-    // whole-tile shapes with a premasked tensor gradient (what the step launches 11 times of 13): the role-split 8-wave form
-    const bool split = g_bwd_split && !gvec && g_premasked && H % 8 == 0 && W % 16 == 0 && g_bwd_dbg == 0;
+    // whole-tile shapes with a premasked tensor gradient or a per-sample gradient (all 13 launches of the step): the role-split 8-wave form
+    const bool split = g_bwd_split && (gvec || g_premasked) && H % 8 == 0 && W % 16 == 0 && g_bwd_dbg == 0;
     if (split) {
-        if (dtype == WM_F16) wm_launch_bwd_ws8_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, 1, nullptr, 64);
-        else wm_launch_bwd_ws8_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, 1, nullptr, 64);
+        if (dtype == WM_F16) wm_launch_bwd_ws8_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, 1, gvec, 64);
+        else wm_launch_bwd_ws8_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, 1, gvec, 64);
     } else if (dtype == WM_F16) wm_launch_bwd_ws_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked, gvec, 64);
     else wm_launch_bwd_ws_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked, gvec, 64);
     WM_LAUNCH_CHECK("wm_conv3x3_bwd_fused");
