@@ -447,6 +447,10 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
             units(2 * sidx + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // The tile's barrier sits HERE, in front of the epilogue: every read of this tile's LDS buffer and every staging write into the next
+        // one is done, and the epilogue touches neither (accumulators, its operand registers, the constant table) -- so the W waves start
+        // the next tile's weight-gradient MFMAs while this role still masks, packs and sums: VALU work beside the partner's matrix work
+        __syncthreads();
         // epilogue: the feeding layer's BatchNorm-backward sums (gz = dx * [z > 0], dx rounded as stored), pack, store
         f32x4 rsv[4], rhv[4];
 #pragma unroll
@@ -472,7 +476,6 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[0], pk[1], pk[2], pk[3]}, rsD, eo[ml], 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[4], pk[5], pk[6], pk[7]}, rsD, eo[ml] + 16u, 0, 0);
         }
-        __syncthreads();
     };
     {
         int tile = t_begin;
