@@ -94,9 +94,10 @@ def kern(pattern):
 
 res = {"note": "FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads); KB = 1024 B; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 * 4)",
        "step_mfma_util": step_util,
-       "bwd_fused": kern("bwd_ws_kernel<0, true, false"),
+       "bwd_fused": kern("bwd_ws8_kernel<true, false>") or kern("bwd_ws_kernel<0, true, false"),
        "bwd_fused_unmasked_g": kern("bwd_ws_kernel<0, false, false"),
-       "bwd_fused_gvec": kern("bwd_ws_kernel<0, false, true"),
+       "bwd_fused_gvec": kern("bwd_ws8_kernel<false, true>") or kern("bwd_ws_kernel<0, false, true"),
+       "bwd_fused16": kern("bwd_ws16_kernel<true>"),
        "dgrad_fused": kern("conv3x3_ws_kernel<64, 64, false, false, true, false, 2, true"),
        "fwd": kern("conv3x3_ws_kernel<64, 64, true, true"),
        "wgrad": kern("wgrad_ws16_kernel<64, true, 0>")}
