@@ -20,8 +20,8 @@ instead of the reference autograd's 249.0 in `step_flops_frac_of_peak` (config.w
 counts the reference's full set.
 
 The JSON line carries, besides the driver contract:
-  roofline     -- the dominant kernel (most time per step, 13-15 launches): bwd_ws_kernel (csrc/bwd_ws.hip) = the whole backward of a
-                  64->64 body layer in one pass: input gradient with the BatchNorm-backward apply fused, the feeding layer's
+  roofline     -- the dominant kernel (most time per step, 13 launches): bwd_ws8_kernel (csrc/bwd_ws8.hip; csrc/bwd_ws.hip for shapes that
+                  are not whole 8x16 tiles) = the whole backward of a 64->64 body layer in one pass: input gradient with the BatchNorm-backward apply fused, the feeding layer's
                   BatchNorm sums, and the weight gradient, from one staged dy / activation tile.  Its 154.6 GFLOP ride on 4 tensor
                   passes (reads g, y, y of the layer below; writes dx = 537 MB algorithmic per launch at B=16 256x256:
                   288 FLOP/B, just under the 312 FLOP/B ridge), so the bound is HBM: achieved = algorithmic bytes / launch
@@ -308,7 +308,7 @@ def main():
             dbytes = 4.0 * tensor_bytes   # reads g, y, y of the layer below; writes dx
             dflops = 2.0 * flops_per_launch   # the input gradient and the weight gradient
             roof = {"bound": "hbm",
-                    "kernel": "bwd_ws_kernel (64->64 body layer, one pass: input gradient + BatchNorm-backward apply + the feeding layer's BatchNorm sums + weight gradient)",
+                    "kernel": "bwd_ws8_kernel (64->64 body layer, one pass: input gradient + BatchNorm-backward apply + the feeding layer's BatchNorm sums + weight gradient; the two GEMMs on different waves)",
                     "achieved": dbytes / (davg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": dbytes / (davg * 1e-3) / 1e9 / 8000.0,
                     "traffic": pmc_traffic(args, S, B), "mfma_util_pmc": pmc_traffic(args, S, B, "bwd_fused.mfma_util"),
                     "launches_timed": len(dms), "avg_launch_ms": davg,

@@ -54,7 +54,16 @@ struct Bwd8Args {
     float* ws;                                             // [gridDim.x][9][64][64]
     int B, H, W, tilesX, tilesY, ntiles, reverse;
     unsigned mX, mY, m2X;
+    int stamps;                                            // debug build: per-wave phase cycle sums instead of the partial rows
 };
+
+// debug build (tools/phase_bwd8.py): s_memtime sums per wave -- [0] the MFMA loop (+ the units between its MFMAs), [1] W: staging of the
+// a tile / D: the wait at the tile's barrier, [2] W: the wait at the barrier / D: the epilogue; written over the workgroup's partial rows
+#ifdef WM_DEBUG
+#define WM_STAMP(i) if (a.stamps) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); tacc[i] += now_ - tprev; tprev = now_; }
+#else
+#define WM_STAMP(i)
+#endif
 
 __device__ __forceinline__ int fsw(int px) { return ((px >> 2) & 1) | (((px >> 1) & 1) << 1) | (((px >> 3) & 1) << 2); }
 __device__ __forceinline__ int swz16(int col) { return (((col >> 1) & 1) << 5) | (((col >> 3) & 1) << 6); }
@@ -81,6 +90,9 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const bool wrole = tid >= 256;           // waves 4..7: the weight gradient
     const int rt = tid & 255, wave = rt >> 6;   // index inside the role
+#ifdef WM_DEBUG
+    long long tacc[4] = {0, 0, 0, 0}, tprev = a.stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;   // [3]: everything outside the tile loop
+#endif
     if (tid < C) {
         sTab[tid] = a.in_scale[tid]; sTab[C + tid] = a.in_shift[tid];
         float k2, k3;
@@ -235,6 +247,7 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
                     for (int fj = 0; fj < 2; ++fj) wacc[tap][fi][fj] = HX::mfma16(afrag[st % WR][fi], bfrag[ks & 1][fj], wacc[tap][fi][fj]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            WM_STAMP(0)
             // the a tile of tile + 1 AFTER the loop: a W wave is done long before its D partner (144 MFMAs against 144 + the dy staging + the
             // epilogue), the fragment registers are free now, and nothing of it sits on the tile's critical path
             if constexpr (stage) {
@@ -252,8 +265,11 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
                     for (int k = 0; k < AV; ++k) load_a_slot(g2, k);
                 }
             }
+            WM_STAMP(1)
             __syncthreads();
+            WM_STAMP(2)
         };
+        WM_STAMP(3)
         {
             int tile = t_begin;
             for (; tile + 2 < t_end; ++tile) w_tile(tile, yes{}, yes{});
@@ -271,11 +287,23 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
                     const int ci = ni * 32 + fj * 16 + r, co = mi * 32 + fi * 16 + 4 * kq;
                     *reinterpret_cast<f32x4*>(slab + ((size_t)(8 - tap) * C + ci) * C + co) = wacc[tap][fi][fj];
                 }
+#ifdef WM_DEBUG
+        if (a.stamps) {
+            __builtin_amdgcn_s_waitcnt(0);
+            WM_STAMP(3)
+            if (lane == 0) {
+                long long* o = reinterpret_cast<long long*>(a.stat + (size_t)blockIdx.x * 2 * C) + (tid >> 6) * 4;
+                o[0] = tacc[0]; o[1] = tacc[1]; o[2] = tacc[2]; o[3] = tacc[3];
+            }
+        }
+#endif
         __syncthreads();   // (the D role's final barrier: its partial sums)
         return;
     }
 
     // ================================================================================================================ D role
+    // (s_setprio for either role measured nothing: D at 2 152.4-152.9 us against 152.7-153.1, W at 2 155.6-155.9 -- the SIMD's vector issue
+    // port is what both roles compete for, not the arbitration order: tools/phase_bwd8.py)
     const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<hx_t*>(GVEC ? a.y : a.g), 0, nbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<hx_t*>(a.y), 0, nbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<hx_t*>(a.xr), 0, nbytes, 0x00020000);
@@ -447,10 +475,12 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
             units(2 * sidx + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        WM_STAMP(0)
         // The tile's barrier sits HERE, in front of the epilogue: every read of this tile's LDS buffer and every staging write into the next
         // one is done, and the epilogue touches neither (accumulators, its operand registers, the constant table) -- so the W waves start
         // the next tile's weight-gradient MFMAs while this role still masks, packs and sums: VALU work beside the partner's matrix work
         __syncthreads();
+        WM_STAMP(1)
         // epilogue: the feeding layer's BatchNorm-backward sums (gz = dx * [z > 0], dx rounded as stored), pack, store
         f32x4 rsv[4], rhv[4];
 #pragma unroll
@@ -468,6 +498,9 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
                 const float z0 = __builtin_fmaf(rsv[jj][2 * jh], y0, rhv[jj][2 * jh]), z1 = __builtin_fmaf(rsv[jj][2 * jh + 1], y1, rhv[jj][2 * jh + 1]);
                 const hx2 p2v = {(hx_t)(z0 > 0.f ? acc[ml][nf][i0] : 0.f), (hx_t)(z1 > 0.f ? acc[ml][nf][i0 + 1] : 0.f)};
                 pk[j] = __builtin_bit_cast(unsigned, p2v);   // dx leaves masked: gz, not g
+                // (the compiler converts each value on its own, selects between the converted halves and joins them with a v_perm: 17 VALU per
+                // channel pair.  Pinning the f32 selects and the packed pair with empty asm statements gives the 15 one would write by hand, and
+                // 46 s_nop beside them -- the pins keep the scheduler from interleaving the pairs across the VCC / conversion hazards: no gain)
                 const float gz0 = HX::lo(pk[j]), gz1 = HX::hi(pk[j]);
                 s1[2 * j] += gz0; s1[2 * j + 1] += gz1;
                 s2[2 * j] = __builtin_fmaf(gz0, y0, s2[2 * j]);
@@ -476,7 +509,9 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[0], pk[1], pk[2], pk[3]}, rsD, eo[ml], 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[4], pk[5], pk[6], pk[7]}, rsD, eo[ml] + 16u, 0, 0);
         }
+        WM_STAMP(2)
     };
+    WM_STAMP(3)
     {
         int tile = t_begin;
         for (; tile + 2 < t_end; ++tile) d_tile(tile, yes{}, yes{});
@@ -495,6 +530,16 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
         }
     }
     __syncthreads();
+#ifdef WM_DEBUG
+    if (a.stamps) {
+        WM_STAMP(3)
+        if (lane == 0) {
+            long long* o = reinterpret_cast<long long*>(a.stat + (size_t)blockIdx.x * 2 * C) + (tid >> 6) * 4;
+            o[0] = tacc[0]; o[1] = tacc[1]; o[2] = tacc[2]; o[3] = tacc[3];
+        }
+        return;
+    }
+#endif
     if (tid < 2 * C) {
         const int which = tid / C, n = tid - which * C;
         a.stat[((size_t)blockIdx.x * 2 + which) * C + n] =
@@ -506,8 +551,9 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
 
 void WM_HSYM(wm_launch_bwd_ws8)(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt, const void* xr,
                                 const float* in_scale, const float* in_shift, void* dx, float* stat, float* ws, int B, int H, int W, int nwg,
-                                int reverse, hipStream_t s, int premasked, const float* gvec, int gv_ld) {
+                                int reverse, hipStream_t s, int premasked, const float* gvec, int gv_ld, int stamps) {
     Bwd8Args a;
+    a.stamps = stamps;
     a.g = (const hx_t*)g; a.y = (const hx_t*)y; a.stats4 = stats4; a.st_ld = st_ld; a.coef = coef; a.wpt = (const hx_t*)wpt;
     a.gvec = gvec; a.gv_ld = gv_ld;
     a.xr = (const hx_t*)xr; a.in_scale = in_scale; a.in_shift = in_shift; a.dx = (hx_t*)dx; a.stat = stat; a.ws = ws;

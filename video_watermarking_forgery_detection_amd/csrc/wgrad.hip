@@ -42,7 +42,7 @@ static inline bool is16(int dtype) { return dtype == WM_BF16 || dtype == WM_F16;
 #define WM_DECL_BWDWS8(sfx)                                                                                                            \
     void wm_launch_bwd_ws8##sfx(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt,     \
                                 const void* xr, const float* in_scale, const float* in_shift, void* dx, float* stat, float* ws, int B, \
-                                int H, int W, int nwg, int reverse, hipStream_t s, int premasked, const float* gvec, int gv_ld)
+                                int H, int W, int nwg, int reverse, hipStream_t s, int premasked, const float* gvec, int gv_ld, int stamps)
 WM_DECL_BWDWS8(_bf16);
 WM_DECL_BWDWS8(_f16);
 // fused input + weight gradient of an image-fed first layer (bwd_ws16.hip), compiled twice
@@ -540,10 +540,11 @@ extern "C" int wm_conv3x3_bwd_fused(const void* g, const float* gvec, const void
     hipStream_t s = (hipStream_t)stream;
     const int nwg = wm_conv3x3_bwd_fused_nwg(B, H, W);
     // whole-tile shapes with a premasked tensor gradient or a per-sample gradient (all 13 launches of the step): the role-split 8-wave form
-    const bool split = g_bwd_split && (gvec || g_premasked) && H % 8 == 0 && W % 16 == 0 && g_bwd_dbg == 0;
+    const bool split = g_bwd_split && (gvec || g_premasked) && H % 8 == 0 && W % 16 == 0 && (g_bwd_dbg == 0 || g_bwd_dbg == (1 << 21));
+    const int stamps = g_bwd_dbg == (1 << 21);   // debug build: tools/phase_bwd8.py
     if (split) {
-        if (dtype == WM_F16) wm_launch_bwd_ws8_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, 1, gvec, 64);
-        else wm_launch_bwd_ws8_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, 1, gvec, 64);
+        if (dtype == WM_F16) wm_launch_bwd_ws8_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, 1, gvec, 64, stamps);
+        else wm_launch_bwd_ws8_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, 1, gvec, 64, stamps);
     } else if (dtype == WM_F16) wm_launch_bwd_ws_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked, gvec, 64);
     else wm_launch_bwd_ws_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked, gvec, 64);
     WM_LAUNCH_CHECK("wm_conv3x3_bwd_fused");
