@@ -25,7 +25,8 @@ The JSON line carries, besides the driver contract:
                   BatchNorm sums, and the weight gradient, from one staged dy / activation tile.  Its 154.6 GFLOP ride on 4 tensor
                   passes (reads g, y, y of the layer below; writes dx = 537 MB algorithmic per launch at B=16 256x256:
                   288 FLOP/B, just under the 312 FLOP/B ridge), so the bound is HBM: achieved = algorithmic bytes / launch
-                  duration measured live with events on the launch stream inside the timed region; peak = 8 TB/s; `traffic` =
+                  duration measured live with events on the launch stream inside the timed region (every launch of every
+                  `kernel_events_every`-th timed step: an event pair costs ~11 us of idle GPU around its launch); peak = 8 TB/s; `traffic` =
                   HBM bytes / launch from the committed rocprofv3 PMC passes of this round (profiles/r03_pmc_traffic.json;
                   FETCH_SIZE doubled as the gfx950 guide says); `mfma_util_pmc` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x
                   1024 SIMDs) from the committed counter pass (profiles/r03_bench_c2_pmc_mfma.csv); `step_mfma_util_pmc` = the same
@@ -60,6 +61,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--noise", default="Jpeg50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-events-every", type=int, default=5,
+                    help="the roofline kernels are bracketed with HIP events on every n-th timed step only: an event pair idles the GPU for ~11 us "
+                         "around the launch it brackets (28 bracketed launches = 0.31 ms of a 5.5 ms step when every step is instrumented)")
     ap.add_argument("--keep-dead-grads", action="store_true", help="also compute the discriminator weight gradients of the generator pass (the reference's state; nothing reads them)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames per step of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (median reported) after one warm-up step")
@@ -261,12 +265,18 @@ def main():
     timer = ops.KernelTimer(lambda name, i: (name == "conv3x3_bwd_fused" and not i["gvec"]) or
                             (name == "conv3x3_fwd" and i["Cin"] == 64 and i["CoutP"] == 64 and i["xform"]) or
                             name in ("jpeg_fwd", "jpeg_bwd"))
-    ops.set_kernel_timer(timer)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step events on the launch stream (§8d: median)
+    every = max(1, args.kernel_events_every)
     barrier()
     t0 = time.perf_counter()
     host_ms = []
     for i in range(args.steps):
+        # The kernel events are part of the timed region, and they are not free: rocprofv3's kernel trace shows 5.3-6.1 us of idle GPU on
+        # either side of every bracketed launch (the event's marker packet) and none around the launches that are not bracketed -- so the
+        # roofline kernels are bracketed on every `every`-th timed step, all their launches of that step.
+        ops.set_kernel_timer(timer if i % every == 0 else None)
+        if sync is not None:
+            sync.profile = i % every == 0    # (the same for the events around the gradient all-reduces' waits)
         marks[i].record()
         th = time.perf_counter()
         losses, _ = h.train_on_batch([images, messages])
@@ -276,7 +286,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
-    sync_rep = sync.report(args.steps) if sync is not None else None
+    sync_rep = sync.report((args.steps + every - 1) // every) if sync is not None else None
     if sync_rep is not None:   # every rank: its buckets and how long its compute stream stood waiting for them (the exposed part of the all-reduces)
         sys.stderr.write(f"[bench rank {rank}] grad sync: {json.dumps(sync_rep)}\n")
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
@@ -326,6 +336,7 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "ms_per_step_median_events": step_ms[len(step_ms) // 2], "ms_per_step_min_events": step_ms[0], "ms_per_step_max_events": step_ms[-1],
             "host_enqueue_ms_median": host_ms[len(host_ms) // 2], "host_enqueue_ms_max": host_ms[-1],
+            "kernel_events_every": every,
             "roofline": roof,
             "roofline_mfma": mfma,
             "roofline_attack": attack_roofline(timer, B, S, args.noise),
