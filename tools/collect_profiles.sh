@@ -43,5 +43,7 @@ python3 $ROOT/bench.py --no-cpu-baseline --keep-dead-grads 2> /dev/null | tail -
 python3 $ROOT/bench.py --no-cpu-baseline 2> /dev/null | tail -1 > $OUT/bench_c2.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s512_stats -o q -- python3 $ROOT/bench.py --no-cpu-baseline --size 512 --batch 8 --steps 10 --warmup 3 > $OUT/s512_stats.log 2>&1
 bash $ROOT/tools/pmc_bwd.sh > $OUT/bwd_sq_counters.txt 2>&1
+cd $ROOT
+(python3 tools/phase_bwd8.py && python3 tools/phase_bwd8.py gvec) 2>&1 | grep -v amdgpu.ids > $OUT/bwd8_phase_cycles.txt
 echo "widened done"
 ls -R $OUT | head -40

@@ -135,7 +135,8 @@ except (IndexError, OSError) as e:
 for name, out in (("c3_c5_steps.jsonl", f"{tag}_c3_c5_steps.jsonl"), ("literal_steps.jsonl", f"{tag}_literal_steps.jsonl"), ("inn_steps.jsonl", f"{tag}_inn_steps.jsonl"),
                   ("bwd_phase_cycles.txt", f"{tag}_bwd_phase_cycles.txt"), ("mfma_coissue_micro.txt", f"{tag}_mfma_coissue_micro.txt"),
                   ("bench_512_b8.json", f"{tag}_bench_512_b8.json"), ("bench_c2.json", f"{tag}_bench_c2.json"),
-                  ("bench_c2_keep_dead_grads.json", f"{tag}_bench_c2_keep_dead_grads.json"), ("bwd_sq_counters.txt", f"{tag}_bwd_sq_counters.txt")):
+                  ("bench_c2_keep_dead_grads.json", f"{tag}_bench_c2_keep_dead_grads.json"), ("bwd_sq_counters.txt", f"{tag}_bwd_sq_counters.txt"),
+                  ("bwd8_phase_cycles.txt", f"{tag}_bwd8_phase_cycles.txt")):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 0:
         shutil.copy(f, os.path.join(dst, out))
