@@ -142,6 +142,12 @@ for name, out in (("c3_c5_steps.jsonl", f"{tag}_c3_c5_steps.jsonl"), ("literal_s
         shutil.copy(f, os.path.join(dst, out))
     else:
         print("missing:", name)
+# the counter passes of the dominant kernel: the role-split form's (collected now) followed by the single-wave form's (kept from mid-round:
+# the evidence csrc/bwd_ws8.hip's header quotes)
+_sq, _sq1 = os.path.join(dst, f"{tag}_bwd_sq_counters.txt"), os.path.join(dst, f"{tag}_bwd_sq_counters_single_wave.txt")
+if os.path.exists(_sq) and os.path.exists(_sq1):
+    with open(_sq, "a") as g:
+        g.write("\n" + open(_sq1).read())
 for sub, base, steps, cmd in (("lit_stats", f"{tag}_literal_step_kernel_stats", 8.0, "python3 tools/bench_literal.py 4 bf16 6   (8 steps: the reference's literal IRNrhi step, 24 frames 256x256, bf16)"),
                               ("s512_stats", f"{tag}_bench_512_b8_kernel_stats", 13.0, "python3 bench.py --no-cpu-baseline --size 512 --batch 8 --steps 10 --warmup 3   (13 steps of 8 frames 512x512)"),
                               ("c5_stats", f"{tag}_c5_fp16_kernel_stats", 42.0, "python3 tools/bench_c5.py train_hidden_c5_fp16.yml f16 44   (42 steps with work, 16 frames 256x256 each, UNet head, f16 + device GradScaler)")):
