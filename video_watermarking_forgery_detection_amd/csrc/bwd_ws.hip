@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                     d0 = wm_bn_fold_dyg(HX::lo(wy[pq]), HX::lo(w[pq]), ka[0], ka[1], ka[2], ka[3], ka2[0]);
                     d1 = wm_bn_fold_dyg(HX::hi(wy[pq]), HX::hi(w[pq]), kb[0], kb[1], kb[2], kb[3], kb2[0]);
                 }
-                const hx2 pk = {(hx_t)d0, (hx_t)d1};
+                const hx2 pk = HX::pack2(d0, d1);
                 w[pq] = __builtin_bit_cast(unsigned, pk);
                 if constexpr (GVEC) dY[k] = __builtin_bit_cast(hx8, w); else dG[k] = __builtin_bit_cast(hx8, w);
             }
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                 u32x4 w = __builtin_bit_cast(u32x4, dA[k]);
                 const float f0 = __builtin_fmaf(HX::lo(w[pq]), ka2[1], ka2[2]);
                 const float f1 = __builtin_fmaf(HX::hi(w[pq]), kb2[1], kb2[2]);
-                const hx2 pk = {(hx_t)f0, (hx_t)f1};
+                const hx2 pk = HX::pack2(f0, f1);
                 const i16x2 z = {0, 0};
                 w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
                 dA[k] = __builtin_bit_cast(hx8, w);
@@ -386,14 +386,14 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                     d0 = wm_bn_fold_dyg(HX::lo(wy[pq]), HX::lo(w[pq]), pka[0], pka[1], pka[2], pka[3], pka2[0]);
                     d1 = wm_bn_fold_dyg(HX::hi(wy[pq]), HX::hi(w[pq]), pkb[0], pkb[1], pkb[2], pkb[3], pkb2[0]);
                 }
-                const hx2 pk = {(hx_t)d0, (hx_t)d1};
+                const hx2 pk = HX::pack2(d0, d1);
                 w[pq] = __builtin_bit_cast(unsigned, pk);
                 if constexpr (GVEC) dY[k] = __builtin_bit_cast(hx8, w); else dG[k] = __builtin_bit_cast(hx8, w);
             } else {
                 u32x4 w = __builtin_bit_cast(u32x4, dA[k]);
                 const float f0 = __builtin_fmaf(HX::lo(w[pq]), pka2[1], pka2[2]);
                 const float f1 = __builtin_fmaf(HX::hi(w[pq]), pkb2[1], pkb2[2]);
-                const hx2 pk = {(hx_t)f0, (hx_t)f1};
+                const hx2 pk = HX::pack2(f0, f1);
                 const i16x2 z = {0, 0};
                 w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
                 dA[k] = __builtin_bit_cast(hx8, w);
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
                 const int nf = j >> 1, i0 = 2 * (j & 1), jj = j >> 1, jh = j & 1;
                 const float y0 = HX::lo(ryv[ml][j]), y1 = HX::hi(ryv[ml][j]);
                 const float z0 = __builtin_fmaf(rsv[jj][2 * jh], y0, rhv[jj][2 * jh]), z1 = __builtin_fmaf(rsv[jj][2 * jh + 1], y1, rhv[jj][2 * jh + 1]);
-                const hx2 p2v = {(hx_t)(z0 > thr ? acc[ml][nf][i0] : 0.f), (hx_t)(z1 > thr ? acc[ml][nf][i0 + 1] : 0.f)};
+                const hx2 p2v = HX::pack2((z0 > thr ? acc[ml][nf][i0] : 0.f), (z1 > thr ? acc[ml][nf][i0 + 1] : 0.f));
                 pk[j] = __builtin_bit_cast(unsigned, p2v);   // dx leaves masked: gz, not g
                 const float gz0 = HX::lo(pk[j]), gz1 = HX::hi(pk[j]);
                 s1[2 * j] += gz0; s1[2 * j + 1] += gz1;

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void bwd_ws16_kernel(Bwd16Args a) {
                     d0 = wm_bn_fold_dyg(HX::lo(wy[pq]), HX::lo(w[pq]), ka[0], ka[1], ka[2], ka[3], k3a);
                     d1 = wm_bn_fold_dyg(HX::hi(wy[pq]), HX::hi(w[pq]), kb[0], kb[1], kb[2], kb[3], k3b);
                 }
-                const hx2 pk = {(hx_t)d0, (hx_t)d1};
+                const hx2 pk = HX::pack2(d0, d1);
                 w[pq] = __builtin_bit_cast(unsigned, pk);
                 dG[k] = __builtin_bit_cast(hx8, w);
             }
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void bwd_ws16_kernel(Bwd16Args a) {
         const unsigned eb = pix_index(g) * (unsigned)(CX * 2) + eofs;
 #pragma unroll
         for (int ml = 0; ml < 2; ++ml) {
-            const hx2 lo = {(hx_t)acc[ml][0], (hx_t)acc[ml][1]}, hi = {(hx_t)acc[ml][2], (hx_t)acc[ml][3]};
+            const hx2 lo = HX::pack2(acc[ml][0], acc[ml][1]), hi = HX::pack2(acc[ml][2], acc[ml][3]);
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)}, rsD,
                                                   eb + (unsigned)(ml * a.W * CX * 2), 0, 0);
         }

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
             u32x4 w = __builtin_bit_cast(u32x4, dA[k]);
             const float f0 = __builtin_fmaf(HX::lo(w[pq]), kin[0], kin[2]);
             const float f1 = __builtin_fmaf(HX::hi(w[pq]), kin[1], kin[3]);
-            const hx2 pk = {(hx_t)f0, (hx_t)f1};
+            const hx2 pk = HX::pack2(f0, f1);
             const i16x2 z = {0, 0};
             w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
             dA[k] = __builtin_bit_cast(hx8, w);
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
             d0 = wm_bn_fold_dyg(HX::lo(wy[pq]), HX::lo(w[pq]), pka[0], pka[1], pka[2], pka[3], pk3a);
             d1 = wm_bn_fold_dyg(HX::hi(wy[pq]), HX::hi(w[pq]), pkb[0], pkb[1], pkb[2], pkb[3], pk3b);
         }
-        const hx2 pk = {(hx_t)d0, (hx_t)d1};
+        const hx2 pk = HX::pack2(d0, d1);
         w[pq] = __builtin_bit_cast(unsigned, pk);
         if constexpr (GVEC) dY[k] = __builtin_bit_cast(hx8, w); else dG[k] = __builtin_bit_cast(hx8, w);
     };
@@ -496,11 +496,8 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
                 const int nf = j >> 1, i0 = 2 * (j & 1), jj = j >> 1, jh = j & 1;
                 const float y0 = HX::lo(ryv[ml][j]), y1 = HX::hi(ryv[ml][j]);
                 const float z0 = __builtin_fmaf(rsv[jj][2 * jh], y0, rhv[jj][2 * jh]), z1 = __builtin_fmaf(rsv[jj][2 * jh + 1], y1, rhv[jj][2 * jh + 1]);
-                const hx2 p2v = {(hx_t)(z0 > 0.f ? acc[ml][nf][i0] : 0.f), (hx_t)(z1 > 0.f ? acc[ml][nf][i0 + 1] : 0.f)};
+                const hx2 p2v = HX::pack2((z0 > 0.f ? acc[ml][nf][i0] : 0.f), (z1 > 0.f ? acc[ml][nf][i0 + 1] : 0.f));
                 pk[j] = __builtin_bit_cast(unsigned, p2v);   // dx leaves masked: gz, not g
-                // (the compiler converts each value on its own, selects between the converted halves and joins them with a v_perm: 17 VALU per
-                // channel pair.  Pinning the f32 selects and the packed pair with empty asm statements gives the 15 one would write by hand, and
-                // 46 s_nop beside them -- the pins keep the scheduler from interleaving the pairs across the VCC / conversion hazards: no gain)
                 const float gz0 = HX::lo(pk[j]), gz1 = HX::hi(pk[j]);
                 s1[2 * j] += gz0; s1[2 * j + 1] += gz1;
                 s2[2 * j] = __builtin_fmaf(gz0, y0, s2[2 * j]);

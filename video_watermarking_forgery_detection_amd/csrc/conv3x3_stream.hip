@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StArgs a) {
                     for (int pq = 0; pq < 4; ++pq) {
                         const float f0 = __builtin_fmaf(HX::lo(w[pq]), sc[2 * pq], sh[2 * pq]);
                         const float f1 = __builtin_fmaf(HX::hi(w[pq]), sc[2 * pq + 1], sh[2 * pq + 1]);
-                        const hx2 pk = {(hx_t)f0, (hx_t)f1};
+                        const hx2 pk = HX::pack2(f0, f1);
                         const i16x2 z = {0, 0};
                         w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
                     }
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StArgs a) {
                     s2[2 * j] = __builtin_fmaf(t0, v0, s2[2 * j]);
                     s2[2 * j + 1] = __builtin_fmaf(t1, v1, s2[2 * j + 1]);
                 }
-                const hx2 p2 = {(hx_t)v0, (hx_t)v1};
+                const hx2 p2 = HX::pack2(v0, v1);
                 pk[j] = __builtin_bit_cast(unsigned, p2);
             }
             if (inb) {

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                     // scalar v_fma_f32 on purpose: packed f32 VALU beside the partner wave's MFMAs costs far more than two scalar ops
                     const float f0 = __builtin_fmaf(HX::lo(w[pq]), sc2[pq][0], sh2[pq][0]);
                     const float f1 = __builtin_fmaf(HX::hi(w[pq]), sc2[pq][1], sh2[pq][1]);
-                    const hx2 pk = {(hx_t)f0, (hx_t)f1};
+                    const hx2 pk = HX::pack2(f0, f1);
                     const i16x2 z = {0, 0};
                     w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
                 }
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                     const float d0 = wm_bn_fold_dy(HX::lo(w[pq]), kb[0][2 * pq], kb[1][2 * pq], kb[2][2 * pq], kb[3][2 * pq], k3g[2 * pq]);
                     const float d1 = wm_bn_fold_dy(HX::hi(w[pq]), kb[0][2 * pq + 1], kb[1][2 * pq + 1], kb[2][2 * pq + 1],
                                                    kb[3][2 * pq + 1], k3g[2 * pq + 1]);
-                    const hx2 pk = {(hx_t)d0, (hx_t)d1};
+                    const hx2 pk = HX::pack2(d0, d1);
                     w[pq] = __builtin_bit_cast(unsigned, pk);
                 }
             }
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                                                         kb[1][2 * pq], kca[2 * pq], kb[2][2 * pq], kb[3][2 * pq]);
                         const float d1 = wm_bn_fold_dyg(HX::hi(wy[pq]), HX::hi(w[pq]),
                                                         kb[0][2 * pq + 1], kb[1][2 * pq + 1], kca[2 * pq + 1], kb[2][2 * pq + 1], kb[3][2 * pq + 1]);
-                        const hx2 pk = {(hx_t)d0, (hx_t)d1};
+                        const hx2 pk = HX::pack2(d0, d1);
                         w[pq] = __builtin_bit_cast(unsigned, pk);
                     }
                     const unsigned inimg = (ok >> k) & 1u, keep = 0u - inimg;
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                     const float z0 = __builtin_fmaf(rsc[2 * j], y0, rsh[2 * j]), z1 = __builtin_fmaf(rsc[2 * j + 1], y1, rsh[2 * j + 1]);
                     v0 = z0 > d[ml].mk ? v0 : 0.f; v1 = z1 > d[ml].mk ? v1 : 0.f;   // (outside the image the threshold is +inf: zeros for the sums)
                 }
-                const hx2 p2 = {(hx_t)v0, (hx_t)v1};
+                const hx2 p2 = HX::pack2(v0, v1);
                 pk[j] = __builtin_bit_cast(unsigned, p2);
                 if (BWDST) {   // scalar f32, as above
                     const float gz0 = HX::lo(pk[j]), gz1 = HX::hi(pk[j]);
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 s2[nf][j][0] = __builtin_fmaf(t0, v0, s2[nf][j][0]);
                 s2[nf][j][1] = __builtin_fmaf(t1, v1, s2[nf][j][1]);
             }
-            const hx2 p2 = {(hx_t)v0, (hx_t)v1};
+            const hx2 p2 = HX::pack2(v0, v1);
             pk[j] = __builtin_bit_cast(unsigned, p2);
         } else if (d.inb && !(STAMPS && (a.dbg & 2))) {
             *reinterpret_cast<u32x4*>(d.yp + nf * 32) = u32x4{pk[0], pk[1], pk[2], pk[3]};

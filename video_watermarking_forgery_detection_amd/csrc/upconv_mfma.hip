@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void upconv_mfma_kernel(UpArgs a) {
                 for (int pq = 0; pq < 4; ++pq) {
                     const float f0 = __builtin_fmaf(HX::lo(w[pq]), sc[2 * pq], sh[2 * pq]);
                     const float f1 = __builtin_fmaf(HX::hi(w[pq]), sc[2 * pq + 1], sh[2 * pq + 1]);
-                    const hx2 pk = {(hx_t)f0, (hx_t)f1};
+                    const hx2 pk = HX::pack2(f0, f1);
                     const i16x2 z = {0, 0};
                     w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
                 }
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void upconv_mfma_kernel(UpArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int nf = j >> 1, i0 = 2 * (j & 1);
-            const hx2 p2 = {(hx_t)(acc[ml][nf][i0] + bv[2 * j]), (hx_t)(acc[ml][nf][i0 + 1] + bv[2 * j + 1])};
+            const hx2 p2 = HX::pack2((acc[ml][nf][i0] + bv[2 * j]), (acc[ml][nf][i0 + 1] + bv[2 * j + 1]));
             pk[j] = __builtin_bit_cast(unsigned, p2);
         }
         hx_t* o;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void upconv_wgrad_kernel(UpWgArgs a) {
                 for (int pq = 0; pq < 4; ++pq) {
                     const float f0 = __builtin_fmaf(HX::lo(w[pq]), sc[2 * pq], sh[2 * pq]);
                     const float f1 = __builtin_fmaf(HX::hi(w[pq]), sc[2 * pq + 1], sh[2 * pq + 1]);
-                    const hx2 pk = {(hx_t)f0, (hx_t)f1};
+                    const hx2 pk = HX::pack2(f0, f1);
                     const i16x2 z = {0, 0};
                     w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
                 }

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
                 for (int pq = 0; pq < 4; ++pq) {
                     const float f0 = __builtin_fmaf(HX::lo(w[pq]), sc[2 * pq], sh[2 * pq]);
                     const float f1 = __builtin_fmaf(HX::hi(w[pq]), sc[2 * pq + 1], sh[2 * pq + 1]);
-                    const hx2 pk = {(hx_t)f0, (hx_t)f1};
+                    const hx2 pk = HX::pack2(f0, f1);
                     const i16x2 z = {0, 0};
                     w[pq] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), z));
                 }
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
                         const float yy = hlf ? HX::hi(yw[pq]) : HX::lo(yw[pq]);
                         dd[hlf] = wm_bn_fold_dyg(yy, gg, bsc[e], bsh[e], bca[e], bk2[e], bk3[e]);
                     }
-                    const hx2 pk = {(hx_t)dd[0], (hx_t)dd[1]};
+                    const hx2 pk = HX::pack2(dd[0], dd[1]);
                     w[pq] = __builtin_bit_cast(unsigned, pk);
                 }
             }
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws16_kernel(WsWgArgs a) {
                     u32x4 w = __builtin_bit_cast(u32x4, d[k]);
                     const float da = wm_bn_fold_dy(HX::lo(w[pq]), ka[0], ka[1], ka[2], ka[3], k3ga);
                     const float db = wm_bn_fold_dy(HX::hi(w[pq]), kb[0], kb[1], kb[2], kb[3], k3gb);
-                    const hx2 pk = {(hx_t)da, (hx_t)db};
+                    const hx2 pk = HX::pack2(da, db);
                     w[pq] = __builtin_bit_cast(unsigned, pk);
                     d[k] = __builtin_bit_cast(hx8, w);
                 }

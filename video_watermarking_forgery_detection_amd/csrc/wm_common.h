@@ -149,12 +149,17 @@ template <> struct vec16<f16_t> {
 
 // ---- the 16-bit activation type of the MFMA kernels (bf16 = production default, f16 = the reference's autocast dtype, config C5):
 // everything that depends on the bit layout goes through these helpers, so one kernel source serves both
+// pack2(a, b): the pair is converted as a VECTOR (round to nearest even, as the scalar casts).  Written as {(H)a, (H)b}, a pair whose halves are
+// then used as 16-bit integers (the packed ReLU: v_pk_max_i16) or selected between is converted one value at a time and joined with a
+// v_perm_b32 -- three instructions instead of one, beside MFMAs that leave the SIMD's vector port ~2 free slots each
+typedef float f32x2p __attribute__((ext_vector_type(2)));
 template <typename H> struct h16;
 template <> struct h16<bf16_t> {
     typedef bf16x8 x8;
     typedef bf16_t x2 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ float lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }             // low half of a packed pair
     static __device__ __forceinline__ float hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+    static __device__ __forceinline__ x2 pack2(float a, float b) { return __builtin_convertvector(f32x2p{a, b}, x2); }   // ONE v_cvt_pk_bf16_f32 (below)
     static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
@@ -163,13 +168,13 @@ template <> struct h16<f16_t> {
     typedef f16_t x2 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(f16_t, (unsigned short)(w & 0xffffu)); }
     static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(f16_t, (unsigned short)(w >> 16)); }
+    static __device__ __forceinline__ x2 pack2(float a, float b) { return __builtin_convertvector(f32x2p{a, b}, x2); }   // ONE v_cvt_pk_f16_f32
     static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 // two f32 -> one packed pair of H
 template <typename H> __device__ __forceinline__ unsigned h16_pack(float a, float b) {
-    const typename h16<H>::x2 p = {(H)a, (H)b};
-    return __builtin_bit_cast(unsigned, p);
+    return __builtin_bit_cast(unsigned, h16<H>::pack2(a, b));
 }
 
 // wave-level sum (64 lanes)
