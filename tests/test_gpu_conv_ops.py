@@ -339,6 +339,36 @@ def test_ws_conv_mfma_shapes_agree(case, variant, debug_lib):
     torch.testing.assert_close(s[1], (ref * ref).sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 32, 48), (1, 64, 16)])
+def test_ws_conv_whole_tile_form_is_the_masked_form(case, dt, debug_lib):
+    """shapes made of whole 16 x 16 tiles take the forward kernel's form without the inside-the-image mask (conv3x3_ws.hip, WHOLE): the
+    output and the BatchNorm partial sums equal the masked form's (debug knob 11) bit for bit, and conv2d's within the 16-bit bound."""
+    import ctypes
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W = case
+    C = 64
+    x = detgen.normal((B, C, H, W), 71).to(dt).float()
+    w = detgen.normal((C, C, 3, 3), 72, std=(2.0 / (9 * C)) ** 0.5).to(dt).float()
+    bias = detgen.normal((C,), 73, std=0.1)
+    sc = detgen.normal((C,), 74, mean=1.0, std=0.2); sh = detgen.normal((C,), 75, std=0.3)
+    wp = ops.pack_w3x3(w.cuda(), C, C, dt)
+    xin = nhwc(x, dt)
+    L = debug_lib
+    y0, st0 = ops.conv3x3_fwd(xin, wp, bias.cuda(), sc.cuda(), sh.cuda(), True)
+    L.wm_debug_ws_variant(ctypes.c_int(11))
+    try:
+        y1, st1 = ops.conv3x3_fwd(xin, wp, bias.cuda(), sc.cuda(), sh.cuda(), True)
+    finally:
+        L.wm_debug_ws_variant(ctypes.c_int(0))
+    assert torch.equal(y0, y1) and torch.equal(st0, st1)
+    a = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).to(dt).float()
+    ref = F.conv2d(a, w, bias, padding=1)
+    tol = 1.5e-2 if dt == torch.bfloat16 else 2e-3
+    torch.testing.assert_close(nchw(y0, C), ref, rtol=tol, atol=tol)
+    torch.testing.assert_close(st0.sum(0).cpu()[0], ref.sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
+
+
 def test_pack_plan_matches_single_packs():
     """ops.PackPlan (one wm_pack_w3x3_batch launch for a whole network) == wm_pack_w3x3 per conv, including the
     permuted / transposed (dgrad) packs, and follows parameter updates after refresh()."""

@@ -91,7 +91,7 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 // statistics and the pack -- y = conv(x) + addend.  The encoder's after-concat layer (hidden_models/encoder.py:25,40) runs as
 // conv64(features) + [conv(image) + message bias] this way: the 97-channel concat tensor is never built (csrc/concat_side.hip)
 template <int CIN, int COUT, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false, int BNBWD = 0, bool BWDST = false, bool PIN = true,
-          bool ADDIN = false>
+          bool ADDIN = false, bool WHOLE = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned long long* __restrict__ stamps = nullptr) {
     static_assert(!ADDIN || (M16 && !BWDST && BNBWD == 0), "ADDIN: forward form of the 16x16x32 consumers");
     static_assert(CIN == 64 || CIN == 32 || CIN == 16, "input channels");
@@ -520,7 +520,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         auto drain_of = [&](const TileGeo& g, int mf) {
             Drain d;
             const int gy = g.ty0 + wave * 4 + mf, gx = g.tx0 + p;
-            d.inb = gy < a.H && gx < a.W;
+            // WHOLE (the launcher: H and W multiples of the 16 x 16 tile): every pixel of every tile is inside the image -- the mask is the
+            // constant 1 and folds out of the statistics (one multiply per element less), the stores lose their predicate
+            d.inb = WHOLE ? true : (gy < a.H && gx < a.W);
             d.mk = BWDST ? (d.inb ? 0.f : __builtin_inff()) : (d.inb ? 1.f : 0.f);
             d.yp = a.y + (((size_t)g.b * a.H + gy) * a.W + gx) * COUT + CPL * q;
             return d;
@@ -540,7 +542,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                     s2[2 * j + 1] = __builtin_fmaf(t1, v1, s2[2 * j + 1]);
                     // pin: without it instruction selection gathers every one of these sums AFTER the pass's last MFMA (they
                     // are pure arithmetic, the sched_barriers do not hold them), out of the matrix pipe's shadow
-                    if (PIN) asm volatile("" : "+v"(s1[2 * j]), "+v"(s1[2 * j + 1]), "+v"(s2[2 * j]), "+v"(s2[2 * j + 1]));
+                    // (WHOLE: the sched_group_barrier pairing in pass() does it instead -- the asm's tied operands cost 4 v_mov per channel pair;
+                    // measured both ways on both forms: A/B table in DESIGN section 9)
+                    if (PIN && !WHOLE) asm volatile("" : "+v"(s1[2 * j]), "+v"(s1[2 * j + 1]), "+v"(s2[2 * j]), "+v"(s2[2 * j + 1]));
                 }
                 float y0 = 0.f, y1 = 0.f;
                 if (BWDST) {   // The gradient LEAVES multiplied by the ReLU mask of the layer it belongs to (gz, not g: every consumer applies
@@ -609,6 +613,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 if (drain) {
 #pragma unroll
                     for (int m = max(sidx - DS0, 0) * NDR / (NSTEP2 - DS0); m < max(sidx + 1 - DS0, 0) * NDR / (NSTEP2 - DS0); ++m) drain_step(m, dh, d);
+                    if (PIN && STATS && WHOLE) {   // one drain instruction behind each of the step's MFMAs
+#pragma unroll
+                        for (int i = 0; i < 2 * NFR; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -847,7 +855,7 @@ int wm_sweep_dir(int reverse) { return (g_ws_reverse == 0 || g_ws_reverse == 1) 
 #else
 int wm_sweep_dir(int reverse);
 #endif
-// debug build A/B knobs -- 1: 32x32x16 MFMA consumers, 2: no XCD-aware run assignment, 3: producers at s_setprio 3, 8: no halo-edge reuse, 9: statistics sums not pinned, 10: filter committed to LDS before the first tile loads are issued
+// debug build A/B knobs -- 1: 32x32x16 MFMA consumers, 2: no XCD-aware run assignment, 3: producers at s_setprio 3, 8: no halo-edge reuse, 9: statistics sums not pinned, 10: filter committed to LDS before the first tile loads are issued, 11: the masked form for whole-tile shapes too
 #ifndef WM_H16_F16
 WM_KNOB_INT(g_ws_variant, "WM_WS_VARIANT", 0);
 WM_KNOB_SETTER(wm_debug_ws_variant, g_ws_variant)
@@ -914,6 +922,11 @@ int WM_HSYM(wm_launch_conv3x3_ws)(const void* x, int ldx, int Cin, int CoutP, co
     } while (0)
 #define WM_WS_LAUNCH(CIN_, M16_) WM_WS_LAUNCH2(CIN_, 64, M16_)
     // 16x16x32 consumers by default where Cin allows (-4.5 % on the 64->64 conv in the training step, tools/ab_step.py)
+    // whole 16 x 16 tiles (every shape of the benchmarked step): the form without the inside-the-image mask (-1.0 % step time; variant 11 = off)
+    if (Cin == 64 && CoutP == 64 && xf && st && g_ws_variant == 0 && H % TH == 0 && W % TW == 0) {
+        hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, true, true, true, false, 0, false, true, false, true>), grid, block, 0, s, a, nullptr);
+        return WM_OK;
+    }
     if (g_ws_variant == 9 && Cin == 64 && CoutP == 64 && xf && st) {   // knob 9: the statistics sums left to the compiler's placement
         hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, true, true, true, false, 0, false, false>), grid, block, 0, s, a, nullptr);
         return WM_OK;
