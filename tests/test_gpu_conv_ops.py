@@ -369,6 +369,30 @@ def test_ws_conv_whole_tile_form_is_the_masked_form(case, dt, debug_lib):
     torch.testing.assert_close(st0.sum(0).cpu()[0], ref.sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
 
 
+def test_ws_first_layer_whole_tile_form_is_the_masked_form(debug_lib):
+    """the same for the image-fed first layers' forward (16 -> 64 channels, no input transform, statistics)"""
+    import ctypes
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, Cin, C = 2, 48, 32, 16, 64
+    dt = torch.bfloat16
+    x = detgen.normal((B, Cin, H, W), 81).to(dt).float()
+    w = detgen.normal((C, Cin, 3, 3), 82, std=(2.0 / (9 * Cin)) ** 0.5).to(dt).float()
+    bias = detgen.normal((C,), 83, std=0.1)
+    wp = ops.pack_w3x3(w.cuda(), C, Cin, dt)
+    xin = nhwc(x, dt)
+    L = debug_lib
+    y0, st0 = ops.conv3x3_fwd(xin, wp, bias.cuda(), None, None, True)
+    L.wm_debug_ws_variant(ctypes.c_int(11))
+    try:
+        y1, st1 = ops.conv3x3_fwd(xin, wp, bias.cuda(), None, None, True)
+    finally:
+        L.wm_debug_ws_variant(ctypes.c_int(0))
+    assert torch.equal(y0, y1) and torch.equal(st0, st1)
+    ref = F.conv2d(x, w, bias, padding=1)
+    torch.testing.assert_close(nchw(y0, C), ref, rtol=1.5e-2, atol=1.5e-2)
+    torch.testing.assert_close(st0.sum(0).cpu()[1], (ref * ref).sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
+
+
 def test_pack_plan_matches_single_packs():
     """ops.PackPlan (one wm_pack_w3x3_batch launch for a whole network) == wm_pack_w3x3 per conv, including the
     permuted / transposed (dgrad) packs, and follows parameter updates after refresh()."""

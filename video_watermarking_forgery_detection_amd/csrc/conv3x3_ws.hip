@@ -703,7 +703,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
     auto drain_of = [&](const TileGeo& g, int mf) {
         Drain d;
         const int gy = g.ty0 + wave * 4 + mf * 2 + (r >> 4), gx = g.tx0 + (r & 15);
-        d.inb = gy < a.H && gx < a.W;
+        d.inb = WHOLE ? true : (gy < a.H && gx < a.W);
         d.mk = d.inb ? 1.f : 0.f;
         d.yp = a.y + (((size_t)g.b * a.H + gy) * a.W + gx) * C64 + 16 * h;
         return d;
@@ -925,6 +925,10 @@ int WM_HSYM(wm_launch_conv3x3_ws)(const void* x, int ldx, int Cin, int CoutP, co
     // whole 16 x 16 tiles (every shape of the benchmarked step): the form without the inside-the-image mask (-1.0 % step time; variant 11 = off)
     if (Cin == 64 && CoutP == 64 && xf && st && g_ws_variant == 0 && H % TH == 0 && W % TW == 0) {
         hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, true, true, true, false, 0, false, true, false, true>), grid, block, 0, s, a, nullptr);
+        return WM_OK;
+    }
+    if (Cin == 16 && CoutP == 64 && !xf && st && g_ws_variant == 0 && H % TH == 0 && W % TW == 0) {   // the image-fed first layers' forward
+        hipLaunchKernelGGL((conv3x3_ws_kernel<16, 64, false, true, false, false, 0, false, true, false, true>), grid, block, 0, s, a, nullptr);
         return WM_OK;
     }
     if (g_ws_variant == 9 && Cin == 64 && CoutP == 64 && xf && st) {   // knob 9: the statistics sums left to the compiler's placement
