@@ -559,7 +559,8 @@ int wm_bayar_constrain(float* w, int nfilters, void* stream);
  * wm_haar: up 0 (analysis): in [B,2H,2W,CPin] with C channels -> out [B,H,W,CPout], channel 4c+k = fac * (Haar filter k of channel c),
  *          k = 0 sum, 1 horizontal, 2 vertical, 3 diagonal difference; up 1 (synthesis): in [B,H,W,CPin] with 4C channels ->
  *          out [B,2H,2W,CPout] with C channels, scaled by fac.  Each is the other's adjoint (= its backward) for equal fac; padding
- *          channels of `out` are written as zero.
+ *          channels of `out` are written as zero.  Bit 1 of `up` (values 2, 3): HaarDownsampling(order_by_wavelet=True) (:207-218,
+ *          :225-233) -- the 4C channels ordered wavelet-major, k C + c.
  * wm_chan_copy: dst[p][doff + c] = src[p][soff + c] for c < n over npix pixels (strides in elements).
  * wm_coupling_fwd: rev 0: y = e(s) * x + t; rev 1: y = (x - t) / e(s); e(s) = exp(clamp * (2 sigmoid(s) - 1)) + eps.
  * wm_coupling_bwd: gradients wrt x, s, t from g = dL/dy; v = x for rev 0, v = the forward's OUTPUT y for rev 1. */

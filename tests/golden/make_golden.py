@@ -688,6 +688,40 @@ def gen_f2(out):
     _store_grads(out, "dense", net, 97)
 
 
+# --------------------------------------------------------------------------- rows f1 / f2: the two constructor options round 3 added
+def gen_f12x(out):
+    """HaarDownsampling(order_by_wavelet=True) (invertible_net.py:207-233) and QF_predictor(crop_pred=True) (conditional_jpeg_generator.py
+    :772-784, :817-821); a file of its own so that f1.npz / f2.npz stay byte for byte what they were"""
+    from models.invertible_net import HaarDownsampling
+    net = HaarDownsampling([[3, 8, 12]], order_by_wavelet=True, rebalance=0.7)
+    x = detgen.uniform((2, 3, 8, 12), 9700).requires_grad_(True)
+    y = net(x)
+    (y * detgen.normal(tuple(y.shape), 9701)).sum().backward()
+    out["haarw/y"], out["haarw/gx"] = npy(y), npy(x.grad)
+    z = detgen.uniform((2, 12, 4, 6), 9702).requires_grad_(True)
+    r = net(z, rev=True)
+    (r * detgen.normal(tuple(r.shape), 9703)).sum().backward()
+    out["haarw/rev"], out["haarw/rev_gx"] = npy(r), npy(z.grad)
+
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        from models.conditional_jpeg_generator import QF_predictor
+        net = detgen.fill_f1(QF_predictor(nc=[16, 32, 48, 64], nb=2, classes=5, crop_pred=True)).train()
+        out["qfpc/keys"] = np.array([f"{k}:{tuple(v.shape)}" for k, v in net.state_dict().items()])
+        x = detgen.uniform((2, 3, 32, 32), 9800).requires_grad_(True)
+        img, qf = net(x)
+        wimg = detgen.normal((2, 1, 64, 64), 9802).repeat_interleave(8, 2).repeat_interleave(8, 3)     # a 512 x 512 weight field from 64 x 64 draws
+        ((qf * detgen.normal(tuple(qf.shape), 9801)).sum() + 0.05 * (img * wimg).sum()).backward()
+        out["qfpc/img_shape"] = np.array(img.shape)
+        out["qfpc/img_sub"] = npy(img[:, :, ::7, ::5])
+        out["qfpc/img_sum"], out["qfpc/img_abs"] = np.float64(img.double().sum().item()), np.float64(img.double().abs().sum().item())
+        out["qfpc/qf"], out["qfpc/gx"] = npy(qf), npy(x.grad)
+        _store_grads(out, "qfpc", net, 97)
+    finally:
+        torch.Tensor.cuda = _cuda
+
+
 def gen_tfevents():
     """the first records of one of the reference's TensorBoard event files (runs/RHI3: `PSNR Forward` ... scalars written through
     torch.utils.tensorboard at models/IRNcrop_model.py:399-400) -- DATA, kept as a known-answer file for utils/tb_writer.read_events and
@@ -720,6 +754,7 @@ def main():
         "localise": lambda o: gen_localise(o, Cfg),
         "f1": lambda o: gen_f1(o),
         "f2": lambda o: gen_f2(o),
+        "f12x": lambda o: gen_f12x(o),
     }
     which = sys.argv[1:] or list(jobs)
     for name in which:

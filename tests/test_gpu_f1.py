@@ -304,6 +304,24 @@ def test_qf_predictor_against_reference_fixture(golden):
     assert _check_param_grads(g, "qfp", net, 2e-3, 97) > 40
 
 
+def test_qf_predictor_crop_pred_against_reference_fixture(golden):
+    """QF_predictor(crop_pred=True) (conditional_jpeg_generator.py:772-784, :817-821): the 192 -> 1 projection resized to 512 x 512 by the
+    attack set's bicubic kernels, the ResBlock-free head, and every gradient, against tests/golden/f12x.npz (reference-generated)"""
+    _, _, QF_predictor = _nets()
+    g = golden("f12x")
+    net = detgen.fill_f1(QF_predictor(nc=[16, 32, 48, 64], nb=2, classes=5, crop_pred=True)).to(DEV).train()
+    x = detgen.uniform((2, 3, 32, 32), 9800).to(DEV).requires_grad_(True)
+    img, qf = net(x)
+    wimg = detgen.normal((2, 1, 64, 64), 9802).repeat_interleave(8, 2).repeat_interleave(8, 3).to(DEV)
+    ((qf * detgen.normal(tuple(qf.shape), 9801).to(DEV)).sum() + 0.05 * (img * wimg).sum()).backward()
+    assert tuple(img.shape) == (2, 1, 512, 512)
+    assert rel(img[:, :, ::7, ::5], g["qfpc/img_sub"]) < 1e-4
+    assert abs(float(img.double().abs().sum()) - float(g["qfpc/img_abs"])) < 1e-4 * float(g["qfpc/img_abs"])
+    assert rel(qf, g["qfpc/qf"]) < 1e-4
+    assert rel(x.grad, g["qfpc/gx"]) < 1e-3
+    assert _check_param_grads(g, "qfpc", net, 2e-3, 97) > 30
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_networks_in_16_bit_against_the_oracle(dtype):
     Discriminator, FBCNN, QF_predictor = _nets()
@@ -351,8 +369,6 @@ def test_surface_errors_and_state_dict_round_trip():
         net(torch.zeros(1, 3, 32, 32))
     with pytest.raises(ValueError):
         net(torch.zeros(1, 4, 32, 32, device=DEV))
-    with pytest.raises(NotImplementedError):
-        QF_predictor(crop_pred=True)
     with pytest.raises(NotImplementedError):
         FBCNN(downsample_mode="avgpool")
     with pytest.raises(ValueError):

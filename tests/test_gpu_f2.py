@@ -83,6 +83,31 @@ def _check_param_grads(g, key, net, tol, stride=97):
     return n
 
 
+def test_haar_order_by_wavelet_against_reference_fixture(golden):
+    """HaarDownsampling(order_by_wavelet=True, rebalance=0.7) (invertible_net.py:207-233): forward, rev and their gradients against
+    tests/golden/f12x.npz; in 16 bit against the plain order permuted by the reference's index list"""
+    from video_watermarking_forgery_detection_amd import glayers as G
+    from video_watermarking_forgery_detection_amd.models.invertible_net import HaarDownsampling
+    g = golden("f12x")
+    net = HaarDownsampling([[3, 8, 12]], order_by_wavelet=True, rebalance=0.7).to(DEV)
+    x = detgen.uniform((2, 3, 8, 12), 9700).to(DEV).requires_grad_(True)
+    lo = net(G.to_nhwc(x, torch.float32))
+    y = G.to_nchw(lo, 12)
+    (y * detgen.normal(tuple(y.shape), 9701).to(DEV)).sum().backward()
+    assert rel(y, g["haarw/y"]) < 1e-6 and rel(x.grad, g["haarw/gx"]) < 1e-6
+    assert float(lo.detach()[..., 12:].abs().max()) == 0.0
+    z = detgen.uniform((2, 12, 4, 6), 9702).to(DEV).requires_grad_(True)
+    r = G.to_nchw(net(G.to_nhwc(z, torch.float32), rev=True), 3)
+    (r * detgen.normal(tuple(r.shape), 9703).to(DEV)).sum().backward()
+    assert rel(r, g["haarw/rev"]) < 1e-6 and rel(z.grad, g["haarw/rev_gx"]) < 1e-6
+    for dtype in (torch.bfloat16, torch.float16):
+        for C in (4, 20):
+            perm = [i + 4 * j for i in range(4) for j in range(C)]
+            xx = G.to_nhwc(detgen.normal((2, C, 12, 20), C).to(DEV), dtype)
+            plain = G.to_nchw(G.haar_down(xx, C, 0.5), 4 * C)
+            assert torch.equal(G.to_nchw(G.haar_down(xx, C, 0.5, True), 4 * C), plain[:, perm])
+
+
 def test_embedder_against_reference_fixture(golden):
     PAMI, ResBlock, DenseBlock = _mods()
     g = golden("f2")

@@ -435,6 +435,46 @@ def test_f1_qf_predictor_oracle(golden):
     close(f1_ref.symm_pad(detgen.uniform((1, 2, 5, 7), 9400), (2, 3, 4, 1)), g["sympad/y"], rtol=0, atol=0)
 
 
+def test_f1_qf_predictor_crop_pred_oracle(golden):
+    """QF_predictor(crop_pred=True) (conditional_jpeg_generator.py:772-784, :817-821): keys, the 512 x 512 bicubic side image, gradients"""
+    from oracle import f1_ref
+    from video_watermarking_forgery_detection_amd.models.conditional_jpeg_generator import QF_predictor
+    g = golden("f12x")
+    net = QF_predictor(nc=[16, 32, 48, 64], nb=2, classes=5, crop_pred=True)
+    assert sorted(f"{k}:{tuple(v.shape)}" for k, v in net.state_dict().items()) == sorted(str(s) for s in g["qfpc/keys"])
+    sd = f1_ref.params(detgen.fill_f1(net).state_dict())
+    x = detgen.uniform((2, 3, 32, 32), 9800).requires_grad_(True)
+    img, qf = f1_ref.qf_predictor(sd, x, nb=2, crop_pred=True)
+    wimg = detgen.normal((2, 1, 64, 64), 9802).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    ((qf * detgen.normal(tuple(qf.shape), 9801)).sum() + 0.05 * (img * wimg).sum()).backward()
+    assert tuple(img.shape) == tuple(g["qfpc/img_shape"]) == (2, 1, 512, 512)
+    scale = float(np.abs(g["qfpc/img_sub"]).max())
+    close(img[:, :, ::7, ::5], g["qfpc/img_sub"], rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(img.double().abs().sum().item(), float(g["qfpc/img_abs"]), rtol=1e-5)
+    close(qf, g["qfpc/qf"], rtol=1e-4, atol=1e-4 * float(np.abs(g["qfpc/qf"]).max()))
+    close(x.grad, g["qfpc/gx"], rtol=1e-3, atol=1e-4 * float(np.abs(g["qfpc/gx"]).max()))
+    assert _check_grads(g, "qfpc", sd) > 30
+
+
+def test_f2_haar_order_by_wavelet_oracle(golden):
+    """HaarDownsampling(order_by_wavelet=True, rebalance=0.7) (invertible_net.py:207-233): forward, rev and both adjoints"""
+    from oracle import f2_ref
+    g = golden("f12x")
+    x = detgen.uniform((2, 3, 8, 12), 9700).requires_grad_(True)
+    y = f2_ref.haar_analysis(x, 0.5 * 0.7, by_wavelet=True)
+    (y * detgen.normal(tuple(y.shape), 9701)).sum().backward()
+    close(y, g["haarw/y"], rtol=1e-6, atol=1e-6)
+    close(x.grad, g["haarw/gx"], rtol=1e-6, atol=1e-6)
+    z = detgen.uniform((2, 12, 4, 6), 9702).requires_grad_(True)
+    r = f2_ref.haar_synthesis(z, 0.5 / 0.7, by_wavelet=True)
+    (r * detgen.normal(tuple(r.shape), 9703)).sum().backward()
+    close(r, g["haarw/rev"], rtol=1e-6, atol=1e-6)
+    close(z.grad, g["haarw/rev_gx"], rtol=1e-6, atol=1e-6)
+    # and the permutation really is one: plain order -> wavelet order by the reference's index list
+    perm = [i + 4 * j for i in range(4) for j in range(3)]
+    close(f2_ref.haar_analysis(x.detach(), 0.35)[:, perm], y.detach(), rtol=0, atol=0)
+
+
 # ----------------------------------------------------------------------------- SURVEY 8f row 2: the invertible embedder
 def _f2_net(name):
     from video_watermarking_forgery_detection_amd.models.invertible_net import Inveritible_Decolorization_PAMI, ResBlock, DenseBlock

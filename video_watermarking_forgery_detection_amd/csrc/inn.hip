@@ -21,7 +21,7 @@ __device__ __forceinline__ float haar_sign(int k, int dy, int dx) {
 // analysis: in [B,2H,2W,CPin] (C real channels) -> out [B,H,W,CPout], out channel 4c+k = fac * sum_{dy,dx} sign_k * in(2y+dy, 2x+dx, c)
 template <typename T>
 __global__ __launch_bounds__(256) void haar_down_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C, int CPin, int CPout,
-                                                        float fac) {
+                                                        float fac, int bywav) {
     const int CQ = CPout / 4;
     const size_t n = (size_t)B * H * W * CQ;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -39,15 +39,18 @@ __global__ __launch_bounds__(256) void haar_down_kernel(const T* __restrict__ in
             for (int k = 0; k < 4; ++k)
                 o[k] = fac * ((haar_sign(k, 0, 0) * v[0][0] + haar_sign(k, 0, 1) * v[0][1]) + (haar_sign(k, 1, 0) * v[1][0] + haar_sign(k, 1, 1) * v[1][1]));
         }
-        T* op = out + ((b * H + y) * W + x) * CPout + 4 * c;
+        // order_by_wavelet (invertible_net.py:207-218): wavelet k of channel c lands at k C + c instead of 4 c + k (padding groups c >= C
+        // keep their 4 c + k slots, which lie beyond the 4 C real channels either way)
+        T* op = out + ((b * H + y) * W + x) * CPout;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) op[k] = from_f32<T>(o[k]);
+        for (int k = 0; k < 4; ++k) op[(bywav && c < C) ? k * C + c : 4 * c + k] = from_f32<T>(o[k]);
     }
 }
 // synthesis: in [B,H,W,CPin] (4C real channels) -> out [B,2H,2W,CPout], out(2y+dy, 2x+dx, c) = fac * sum_k sign_k(dy,dx) * in(y, x, 4c+k)
+// (bywav: in(y, x, k C + c))
 template <typename T>
 __global__ __launch_bounds__(256) void haar_up_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C, int CPin, int CPout,
-                                                      float fac) {
+                                                      float fac, int bywav) {
     const size_t n = (size_t)B * H * W * CPout;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % CPout);
@@ -55,9 +58,9 @@ __global__ __launch_bounds__(256) void haar_up_kernel(const T* __restrict__ in, 
         const size_t b = i / ((size_t)CPout * W * H);
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (c < C) {
-            const T* ip = in + ((b * H + y) * W + x) * CPin + 4 * c;
+            const T* ip = in + ((b * H + y) * W + x) * CPin;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = to_f32(ip[k]);
+            for (int k = 0; k < 4; ++k) v[k] = to_f32(ip[bywav ? k * C + c : 4 * c + k]);
         }
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
@@ -153,15 +156,17 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(const T* __restrict__ g
 // out [B,2H,2W,CPout] (C = output channels, CPin >= 4C).  The two are each other's adjoint for equal fac.
 extern "C" int wm_haar(const void* in, void* out, int B, int H, int W, int C, int CPin, int CPout, float fac, int up, int dtype, void* stream) {
     WM_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && C > 0, WM_E_BADARG, "wm_haar: bad arguments");
-    WM_REQUIRE(CPin % 4 == 0 && CPout % 4 == 0 && (up ? (CPin >= 4 * C && CPout >= C) : (CPin >= C && CPout >= 4 * C)), WM_E_SHAPE,
+    WM_REQUIRE(up >= 0 && up <= 3, WM_E_BADARG, "wm_haar: up is a 2-bit field (bit 0 synthesis, bit 1 wavelet-major channel order)");
+    WM_REQUIRE(CPin % 4 == 0 && CPout % 4 == 0 && ((up & 1) ? (CPin >= 4 * C && CPout >= C) : (CPin >= C && CPout >= 4 * C)), WM_E_SHAPE,
                "wm_haar: channel strides %d -> %d do not hold %d x4 channels", CPin, CPout, C);
     hipStream_t s = (hipStream_t)stream;
-    if (up) {
+    const int bywav = (up >> 1) & 1;   // bit 1 of `up`: the 4C channels ordered by wavelet (k C + c) instead of by channel (4 c + k)
+    if (up & 1) {
         const size_t n = (size_t)B * H * W * CPout;
-        WM_DISPATCH_DTYPE(dtype, "wm_haar", hipLaunchKernelGGL(haar_up_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, (const T*)in, (T*)out, B, H, W, C, CPin, CPout, fac));
+        WM_DISPATCH_DTYPE(dtype, "wm_haar", hipLaunchKernelGGL(haar_up_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, (const T*)in, (T*)out, B, H, W, C, CPin, CPout, fac, bywav));
     } else {
         const size_t n = (size_t)B * H * W * (CPout / 4);
-        WM_DISPATCH_DTYPE(dtype, "wm_haar", hipLaunchKernelGGL(haar_down_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, (const T*)in, (T*)out, B, H, W, C, CPin, CPout, fac));
+        WM_DISPATCH_DTYPE(dtype, "wm_haar", hipLaunchKernelGGL(haar_down_kernel<T>, dim3(grid1(n)), dim3(256), 0, s, (const T*)in, (T*)out, B, H, W, C, CPin, CPout, fac, bywav));
     }
     WM_LAUNCH_CHECK("wm_haar");
     return WM_OK;

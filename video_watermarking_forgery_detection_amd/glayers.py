@@ -474,14 +474,14 @@ def vector_out(x, F):
 # ----------------------------------------------------------------------------- invertible-embedder pieces (models/invertible_net.py)
 class _HaarFn(Function):
     @staticmethod
-    def forward(ctx, x, C, fac, up):
-        ctx.meta = (C, fac, up)
-        return ops.haar(x, C, fac, up)
+    def forward(ctx, x, C, fac, up, by_wavelet=False):
+        ctx.meta = (C, fac, up, by_wavelet)
+        return ops.haar(x, C, fac, up, by_wavelet)
 
     @staticmethod
     def backward(ctx, g):
-        C, fac, up = ctx.meta
-        return ops.haar(g.contiguous(), C, fac, not up), None, None, None
+        C, fac, up, by_wavelet = ctx.meta
+        return ops.haar(g.contiguous(), C, fac, not up, by_wavelet), None, None, None, None
 
 
 class _ChanSliceFn(Function):
@@ -531,12 +531,12 @@ class _CouplingFn(Function):
         return gx, gs, gt, None, None, None
 
 
-def haar_down(x, C, fac):
-    return _HaarFn.apply(x, C, float(fac), False)
+def haar_down(x, C, fac, by_wavelet=False):
+    return _HaarFn.apply(x, C, float(fac), False, bool(by_wavelet))
 
 
-def haar_up(x, C, fac):
-    return _HaarFn.apply(x, C, float(fac), True)
+def haar_up(x, C, fac, by_wavelet=False):
+    return _HaarFn.apply(x, C, float(fac), True, bool(by_wavelet))
 
 
 def chan_slice(x, off, n):

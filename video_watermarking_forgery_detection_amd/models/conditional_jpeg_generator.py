@@ -180,17 +180,32 @@ def symm_pad(im, padding, dtype=torch.float32):
     return G.to_nchw(x, im.shape[1])
 
 
+class _BicubicTo(torch.autograd.Function):
+    """F.interpolate(x, size=[oh, ow], mode='bicubic') on f32 planes (the attack set's ATen-exact resample kernels, ops.resample_*)"""
+
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        x = x.float().contiguous()
+        ctx.dims = (x.shape[2], x.shape[3])
+        return ops.resample_fwd(x, (0, x.shape[2], 0, x.shape[3]), (oh, ow), ops.BICUBIC)
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W = ctx.dims
+        return ops.resample_bwd(g.float().contiguous(), None, (H, W), (0, H, 0, W), ops.BICUBIC), None, None
+
+
 class QF_predictor(nn.Module):
     """conditional_jpeg_generator.py:697-826: constrained 5x5 Bayar conv on the symmetrically padded image, three
     (nb ResBlocks, stride-2 conv) stages to 192 channels, nb ResBlocks, then nb ResBlocks + global pool + 3 Linear.
-    forward(x [B,3,H,W]) -> (conv_bayar [B,3,H,W], qf [B,classes])."""
+    forward(x [B,3,H,W]) -> (conv_bayar [B,3,H,W], qf [B,classes]).
+    crop_pred=True (:772-784, :817-821): the head is the pool + 3 Linear alone, and the first output is `to_img` (1x1, 192 -> 1, no bias)
+    of the encoder's features resized to 512 x 512 (bicubic): (img [B,1,512,512], qf)."""
 
     def __init__(self, in_nc=3, out_nc=3, nc=[32, 64, 128, 256], nb=4, act_mode="R", downsample_mode="strideconv", classes=5, crop_pred=False,
                  upsample_mode="convtranspose", dtype=torch.float32):
         super().__init__()
         down, _ = _blocks(downsample_mode, upsample_mode)
-        if crop_pred:
-            raise NotImplementedError("QF_predictor(crop_pred=True) (the bicubic 512x512 side image, :817-821) is not built")
         self.in_nc, self.nb, self.nc, self.crop_pred, self.classes, self.dtype = in_nc, nb, nc, crop_pred, classes, dtype
         m = "C" + act_mode + "C"
         self.BayarConv2D = G.Conv2d(3, 3, 5, 1, 0, bias=False)
@@ -200,8 +215,12 @@ class QF_predictor(nn.Module):
         self.m_down2_A = sequential(*[ResBlock(nc[1], nc[1], bias=True, mode=m) for _ in range(nb)], down(nc[1], nc[2], bias=True, mode="2"))
         self.m_down3_A = sequential(*[ResBlock(nc[2], nc[2], bias=True, mode=m) for _ in range(nb)], down(nc[2], 192, bias=True, mode="2"))
         self.m_body_encoder_A = sequential(*[ResBlock(192, 192, bias=True, mode=m) for _ in range(nb)])
-        self.qf_pred = sequential(*[ResBlock(192, 192, bias=True, mode=m) for _ in range(nb)], G.GlobalAvgPool(), G.Flatten(), G.Linear(192, 192),
-                                  G.Act("gelu"), G.Linear(192, 192), G.Act("gelu"), G.Linear(192, classes))
+        head = [G.GlobalAvgPool(), G.Flatten(), G.Linear(192, 192), G.Act("gelu"), G.Linear(192, 192), G.Act("gelu"), G.Linear(192, classes)]
+        if crop_pred:
+            self.to_img = G.Conv2d(192, 1, 1, 1, 0, bias=False)
+            self.qf_pred = sequential(*head)
+        else:
+            self.qf_pred = sequential(*[ResBlock(192, 192, bias=True, mode=m) for _ in range(nb)], *head)
 
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != 3:
@@ -215,4 +234,7 @@ class QF_predictor(nn.Module):
         x4 = self.m_down3_A(x3)
         x_pred = self.m_body_encoder_A(x4)
         qf = self.qf_pred(x_pred)
+        if self.crop_pred:
+            img = _BicubicTo.apply(G.to_nchw(self.to_img(x_pred), 1), 512, 512)
+            return img, G.vector_out(qf, self.classes)
         return G.to_nchw(e0, 3), G.vector_out(qf, self.classes)

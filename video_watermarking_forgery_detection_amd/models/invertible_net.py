@@ -41,12 +41,12 @@ def _kaiming_(convs, scale):
 
 class HaarDownsampling(nn.Module):
     """:178-247.  forward(x [B,H,W,cpad(C)]) -> [B,H/2,W/2,cpad(4C)], channel 4c+k = 0.5 * rebalance * Haar_k(channel c);
-    rev: the synthesis scaled by 0.5 / rebalance."""
+    rev: the synthesis scaled by 0.5 / rebalance.  order_by_wavelet (:207-218, the index permutation out[:, perm] / x[:, perm_inv]):
+    wavelet k of channel c is channel k*C + c -- the kernels write / read that order directly, no gather."""
 
     def __init__(self, dims_in, order_by_wavelet=False, rebalance=1.0):
         super().__init__()
-        if order_by_wavelet:
-            raise NotImplementedError("HaarDownsampling(order_by_wavelet=True) is not built (the embedder does not use it)")
+        self.permute = bool(order_by_wavelet)
         self.in_channels = dims_in[0][0]
         self.fac_fwd = 0.5 * rebalance
         self.fac_rev = 0.5 / rebalance
@@ -54,8 +54,8 @@ class HaarDownsampling(nn.Module):
 
     def forward(self, x, rev=False):
         if not rev:
-            return G.haar_down(x, self.in_channels, self.fac_fwd)
-        return G.haar_up(x, self.in_channels, self.fac_rev)
+            return G.haar_down(x, self.in_channels, self.fac_fwd, self.permute)
+        return G.haar_up(x, self.in_channels, self.fac_rev, self.permute)
 
 
 class HaarUpsampling(nn.Module):

@@ -1462,8 +1462,9 @@ def bayar_constrain_(w):
 
 
 # ----------------------------------------------------------------------------- invertible embedder pieces
-def haar(x, C, fac, up):
-    """up False: [B,2H,2W,cpad(C)] -> [B,H,W,cpad(4C)] (analysis); up True: [B,H,W,cpad(4C)] -> [B,2H,2W,cpad(C)] (synthesis)"""
+def haar(x, C, fac, up, by_wavelet=False):
+    """up False: [B,2H,2W,cpad(C)] -> [B,H,W,cpad(4C)] (analysis); up True: [B,H,W,cpad(4C)] -> [B,2H,2W,cpad(C)] (synthesis).
+    by_wavelet: the 4C channels in wavelet-major order k*C + c (HaarDownsampling(order_by_wavelet=True)) instead of 4*c + k"""
     x = _nhwc(x)
     B, XH, XW, CPin = x.shape
     if up:
@@ -1476,8 +1477,8 @@ def haar(x, C, fac, up):
             raise ValueError(f"haar analysis needs even height / width and {C} channels, got {tuple(x.shape)}")
         H, W = XH // 2, XW // 2
         out = torch.empty(B, H, W, cpad(4 * C), device=x.device, dtype=x.dtype)
-    rc = _lib.lib().wm_haar(_p(x), _p(out), c_int(B), c_int(H), c_int(W), c_int(C), c_int(CPin), c_int(out.shape[3]), c_float(fac), c_int(1 if up else 0),
-                            c_int(dt_id(x.dtype)), _stream())
+    rc = _lib.lib().wm_haar(_p(x), _p(out), c_int(B), c_int(H), c_int(W), c_int(C), c_int(CPin), c_int(out.shape[3]), c_float(fac),
+                            c_int((1 if up else 0) | (2 if by_wavelet else 0)), c_int(dt_id(x.dtype)), _stream())
     _lib.check(rc, "wm_haar")
     return out
 
