@@ -316,6 +316,8 @@ extern "C" int wm_median_bwd(const float* gy, const int8_t* idx, float* gx, int 
     return WM_OK;
 }
 
+namespace {
+
 // ---- the same backward in two separable passes (x then y) through a workspace tmp[N][OH][W]: each pass gathers the ~4 / scale + 3 taps of
 // ONE axis, where the gather form above walks their product for every input pixel (36-64 taps at the Resize attack's 0.7x / 1.43x, behind a
 // 24-wide predicated column loop per candidate row): 83 -> 25 us for bicubic at B=16 3x256x256.  Same weights (axis_weight), a different
@@ -393,6 +395,8 @@ __global__ __launch_bounds__(256) void resample_bwd_y_kernel(const float* __rest
         }
     }
 }
+
+}  // namespace
 
 static int resample_check(const char* name, int N, int H, int W, int h0, int hs, int w0, int ws, int OH, int OW, int kind) {
     WM_REQUIRE(N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, WM_E_BADARG, "%s: bad shape", name);
