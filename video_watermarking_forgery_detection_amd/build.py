@@ -29,8 +29,7 @@ EXTRA = {f: ["-fno-slp-vectorize"] for f in MFMA_FILES}
 # scratch memory FAILS the build: a scratch reload counts in vmcnt and stalls the tile prefetch of the persistent kernels
 NO_SPILL = ("conv3x3_ws.hip", "bwd_ws.hip", "bwd_ws8.hip", "bwd_ws16.hip", "wgrad_ws.hip", "conv3x3_stream.hip", "upconv_mfma.hip", "concat_side.hip")
 # (file, f16 twin?, substring of the mangled kernel name) known and accepted to spill, with the reason
-SPILL_OK = (("wgrad_ws.hip", True, "wgrad_ws16_kernelILi64ELb1ELi2EE"),    # f16 twin of the pooled-layer weight gradient: 11 VGPRs; superseded on the step by bwd_ws<GVEC>
-            ("bwd_ws8.hip", False, "bwd_ws8_kernelILb0ELb1EE"), ("bwd_ws8.hip", True, "bwd_ws8_kernelILb0ELb1EE"))   # per-sample-gradient form: 1-2 loop-invariant LDS offsets, reloaded only in the last two tile bodies of a run (not in the steady-state loop; checked in the ISA)
+SPILL_OK = (("wgrad_ws.hip", True, "wgrad_ws16_kernelILi64ELb1ELi2EE"),)    # f16 twin of the pooled-layer weight gradient: 11 VGPRs; superseded on the step by bwd_ws8<GVEC>
 REMARK = "-Rpass-analysis=kernel-resource-usage"
 
 

@@ -308,16 +308,26 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<hx_t*>(a.y), 0, nbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<hx_t*>(a.xr), 0, nbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(a.dx, 0, nbytes, 0x00020000);
-    int hlds[XV];
-    unsigned hofs[XV], edge = 0;
+    // Slots: k < 5 cover the 10 x 16 pixels of the halo tile's columns 2..17, two rows per slot (slot k = slot 0's pixel, 2 k rows further
+    // down: ONE LDS offset + an immediate, ONE global offset + a wave-uniform addend instead of six of each); k == 5 the two columns 0..1,
+    // live in the first 20 slot rows.  (The split is also what a reuse of the shared columns / rows needs: tools/patches.)
+    int hlds0, hlds5;
+    unsigned hofs0, hofs5, edge = 0;
+    {
+        const int px0 = (slot & 15) + 2, py0 = slot >> 4;
+        hlds0 = (py0 * HW + px0) * 128 + ((vec ^ fsw(px0)) << 4);
+        hofs0 = (unsigned)(((py0 * a.W + px0) * C + vec * 8) * 2);
+        const int e = min(slot, 19), erow = e >> 1, ecol = e & 1;
+        hlds5 = (erow * HW + ecol) * 128 + ((vec ^ fsw(ecol)) << 4);
+        hofs5 = (unsigned)(((erow * a.W + ecol) * C + vec * 8) * 2);
 #pragma unroll
-    for (int k = 0; k < XV; ++k) {
-        const int hp = min(slot + 32 * k, NPX - 1), py = hp / HW, px = hp - py * HW;
-        hlds[k] = hp * 128 + ((vec ^ fsw(px)) << 4);
-        hofs[k] = (unsigned)(((py * a.W + px) * C + vec * 8) * 2);
-        edge |= (py == 0 ? 1u : 0u) << k | (py == HH - 1 ? 1u : 0u) << (k + 6) | (px == 0 ? 1u : 0u) << (k + 12) | (px == HW - 1 ? 1u : 0u) << (k + 18);
+        for (int k = 0; k < XV; ++k) {
+            const int py = k < XV - 1 ? py0 + 2 * k : erow, px = k < XV - 1 ? px0 : ecol;
+            edge |= (py == 0 ? 1u : 0u) << k | (py == HH - 1 ? 1u : 0u) << (k + 6) | (px == 0 ? 1u : 0u) << (k + 12) | (px == HW - 1 ? 1u : 0u) << (k + 18);
+        }
     }
-    const bool last_live = slot + 32 * (XV - 1) < NPX;
+    auto hl = [&](int k) { return k < XV - 1 ? hlds0 + k * (2 * HW * 128) : hlds5; };
+    const bool last_live = slot < 20;
     auto inside_bits = [&](const TileGeo& t) {
         const unsigned sel = (t.ty0 == 0 ? 0x3fu : 0u) | (t.ty0 + TH == a.H ? 0x3fu << 6 : 0u) | (t.tx0 == 0 ? 0x3fu << 12 : 0u) | (t.tx0 + TW == a.W ? 0x3fu << 18 : 0u);
         const unsigned e = edge & sel;
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
     hx8 dG[XV], dY[XV];
     unsigned okh = 0;
     auto load_dy_slot = [&](const TileGeo& t, int k) {
-        const unsigned o = halo_base(t) + hofs[k];
+        const unsigned o = (k < XV - 1 ? hofs0 : hofs5) + (halo_base(t) + (unsigned)(k < XV - 1 ? k * 2 * a.W * C * 2 : 0));
         if constexpr (!GVEC) dG[k] = __builtin_bit_cast(hx8, __builtin_amdgcn_raw_buffer_load_b128(rsG, o, 0, 0));
         dY[k] = __builtin_bit_cast(hx8, __builtin_amdgcn_raw_buffer_load_b128(rsY, o, 0, 0));
     };
@@ -363,7 +373,7 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
         const unsigned keep = 0u - ((okh >> k) & 1u);
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) w[q4] &= keep;
-        if (k + 1 < XV || last_live) *reinterpret_cast<u32x4*>(buf + hlds[k]) = w;
+        if (k + 1 < XV || last_live) *reinterpret_cast<u32x4*>(buf + hl(k)) = w;
     };
     // input-gradient fragments: tile rows 2*wave, 2*wave + 1; lane (p, q): pixel column p, 16 channels [16q, 16q + 16)
     const int p = lane & 15, q = lane >> 4;
@@ -559,8 +569,7 @@ void WM_HSYM(wm_launch_bwd_ws8)(const void* g, const void* y, const float* stats
     a.mX = magic(a.tilesX); a.mY = magic(a.tilesY); a.m2X = magic(2 * a.tilesX);
     a.reverse = wm_sweep_dir(reverse);
     // (the unmasked-gradient form is not instantiated: it needs ~15 registers more than a two-waves-per-SIMD kernel has and stays on
-    // bwd_ws.hip -- wgrad.hip dispatches.  The per-sample-gradient form parks ONE loop-invariant LDS offset in scratch, reloaded only in the
-    // bodies of a run's last two tiles, never in the steady-state loop: build.py's SPILL_OK names it)
+    // bwd_ws.hip -- wgrad.hip dispatches.  Both instantiated forms: 250 registers, no scratch)
     (void)premasked;
     if (gvec) hipLaunchKernelGGL((bwd_ws8_kernel<false, true>), dim3((unsigned)nwg), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((bwd_ws8_kernel<true, false>), dim3((unsigned)nwg), dim3(512), 0, s, a);
