@@ -65,6 +65,8 @@ def parse():
                     help="the roofline kernels are bracketed with HIP events on every n-th timed step only: an event pair idles the GPU for ~11 us "
                          "around the launch it brackets (28 bracketed launches = 0.31 ms of a 5.5 ms step when every step is instrumented)")
     ap.add_argument("--keep-dead-grads", action="store_true", help="also compute the discriminator weight gradients of the generator pass (the reference's state; nothing reads them)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the two secondary timed regions (reference_state, c4_shard_512)")
+    ap.add_argument("--extra-steps", type=int, default=25, help="timed steps of each secondary region (after 5 warm-up steps)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames per step of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (median reported) after one warm-up step")
     return ap.parse_args()
@@ -191,6 +193,36 @@ def pmc_traffic(args, S, B, key="hbm_bytes_per_launch"):
         return None
 
 
+def file_sha16(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def timed_steps(h, batch, steps, warmup, barrier, world, dev, timer=None, every=5):
+    """`warmup` untimed steps, then `steps` steps bracketed like the headline region (barrier + synchronize on both sides, wall clock, MAX
+    over ranks) -> seconds.  timer: an ops.KernelTimer switched on for every `every`-th timed step"""
+    import torch.distributed as dist
+    from video_watermarking_forgery_detection_amd import ops
+    for _ in range(warmup):
+        h.train_on_batch(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ops.set_kernel_timer(timer if (timer is not None and i % every == 0) else None)
+        h.train_on_batch(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) without a launcher: start N fresh ranks with torch.distributed.run as a CHILD process --
     this parent has not touched the GPU (no HIP call, no torch.cuda.is_available()) and never replaces itself -- and pass the
@@ -229,7 +261,7 @@ def main():
         dist.init_process_group(os.environ.get("WM_DIST_BACKEND", "nccl"))
 
     import video_watermarking_forgery_detection_amd as wm
-    from video_watermarking_forgery_detection_amd import ops
+    from video_watermarking_forgery_detection_amd import _lib as _wm_lib, ops
     from video_watermarking_forgery_detection_amd.distributed import GradSync, broadcast_parameters
     from video_watermarking_forgery_detection_amd.hidden_models import Hidden
     from video_watermarking_forgery_detection_amd import noise_layers as NL
@@ -296,6 +328,47 @@ def main():
         dt = float(t.item())
     kms = timer.elapsed_ms("conv3x3_fwd")
     dms = timer.elapsed_ms("conv3x3_bwd_fused")
+    # ---- two more timed regions of the SAME invocation (secondary keys of the line; north_star asks for 256x256 AND 512x512, and the headline
+    # workload drops three dead weight-gradient GEMMs the reference executes): every rank runs them, bracketed exactly like the headline region
+    extra = {}
+    if sync is not None:
+        sync.profile = False
+    peak_tf = 2500.0 if dtype == torch.bfloat16 else 157.3
+    if not args.no_extra and not args.keep_dead_grads and S == 256:
+        # (1) the reference's exact .grad state: g_loss.backward() (hidden.py:101) also leaves its gradients in the discriminator's parameters
+        h.keep_dead_discriminator_grads = True
+        dte = timed_steps(h, [images, messages], args.extra_steps, 5, barrier, world, dev)
+        h.keep_dead_discriminator_grads = False
+        gf = 249.0
+        extra["reference_state"] = {
+            "workload": f"the same step with the discriminator's dead weight gradients of the generator pass computed (the reference's .grad state, hidden.py:67,101), {S}x{S}, batch {B}/GPU",
+            "steps": args.extra_steps, "warmup": 5, "ms_per_step": 1e3 * dte / args.extra_steps, "value": world * B * args.extra_steps / dte, "unit": "frames/s",
+            "step_gflop_per_frame": gf, "step_flops_frac_of_peak": gf * 1e9 * B * args.extra_steps / dte / (peak_tf * 1e12)}
+    if not args.no_extra and S == 256 and dtype == torch.bfloat16:
+        # (2) BASELINE.json configs[3]'s per-GPU shard: 512x512, 8 frames per GPU
+        S2, B2 = 512, 8
+        torch.manual_seed(10)
+        h2 = Hidden(HiDDenConfiguration(H=S2, W=S2), dev, noise, None, compute_dtype=dtype, grad_sync=sync, keep_dead_discriminator_grads=args.keep_dead_grads)
+        broadcast_parameters([h2.encoder_decoder.encoder, h2.encoder_decoder.decoder, h2.discriminator])
+        torch.manual_seed(10 + rank)
+        im2 = torch.rand(B2, 3, S2, S2, device=dev)
+        ms2 = torch.randint(0, 2, (B2, 30), device=dev).float()
+        timer2 = ops.KernelTimer(lambda name, i: name == "conv3x3_bwd_fused" and not i["gvec"])
+        dt2 = timed_steps(h2, [im2, ms2], args.extra_steps, 5, barrier, world, dev, timer2, every)
+        d2 = timer2.elapsed_ms("conv3x3_bwd_fused")
+        gf2 = (249.0 if args.keep_dead_grads else 249.0 - 2 * 4.8318 - 0.2265) * 4.0
+        c4 = {"workload": f"C4's per-GPU shard: the headline step at {S2}x{S2}, batch {B2}/GPU", "steps": args.extra_steps, "warmup": 5,
+              "ms_per_step": 1e3 * dt2 / args.extra_steps, "value": world * B2 * args.extra_steps / dt2, "unit": "frames/s",
+              "step_gflop_per_frame": gf2, "step_flops_frac_of_peak": gf2 * 1e9 * B2 * args.extra_steps / dt2 / (peak_tf * 1e12)}
+        if d2:
+            a2 = sum(d2) / len(d2)
+            by2 = 4.0 * B2 * S2 * S2 * 64 * 2
+            c4["roofline"] = {"bound": "hbm", "kernel": "bwd_ws8_kernel", "achieved": by2 / (a2 * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                              "frac": by2 / (a2 * 1e-3) / 1e9 / 8000.0, "avg_launch_ms": a2, "launches_timed": len(d2), "algorithmic_bytes_per_launch": by2}
+        extra["c4_shard_512"] = c4
+        del h2, im2, ms2
+    if sync is not None:
+        sync.report()
     if rank == 0:
         fps = world * B * args.steps / dt
         esz = 2 if dtype == torch.bfloat16 else 4
@@ -344,9 +417,11 @@ def main():
             "step_gflop_per_frame": step_gflop,
             "step_flops_frac_of_peak": (step_gflop * 1e9 * world * B * args.steps / dt) / (peak * 1e12 * world),
             "pmc_stale": bool(_pmc.get("stale", True)),
+            "kernel_sources_sha": kernel_sources_sha(), "library": os.path.relpath(_wm_lib.loaded_path(), ROOT), "library_sha16": file_sha16(_wm_lib.loaded_path()),
             "grad_sync": sync_rep,
             "last_losses": {k.strip(): v for k, v in losses.items()},
         }
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, args.cpu_frames, args.cpu_steps)
         print(json.dumps(out))

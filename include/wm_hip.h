@@ -249,6 +249,9 @@ int wm_conv3x3_bwd_fused_supported(int dtype);
 int wm_conv3x3_bwd_fused_supported_shape(int B, int H, int W, int dtype);   /* ... and B*H*W*64 < 2^31 (32-bit element offsets) */
 int wm_conv3x3_bwd_fused_nwg(int B, int H, int W);
 int wm_conv3x3_bwd_fused_gvec_max_batch(void);
+/* which kernel wm_conv3x3_bwd_fused launches for these arguments: 8 = the role-split 8-wave form (csrc/bwd_ws8.hip: whole 8x16 tiles and a
+ * premasked tensor gradient or a per-sample gradient), 1 = the single-role form (csrc/bwd_ws.hip: everything else) */
+int wm_conv3x3_bwd_fused_kernel(int H, int W, int g_premasked, int has_gvec);
 int wm_conv3x3_bwd_fused(const void* g, const float* gvec, const void* y, const float* stats4, const float* coef, const void* wpt,
                          const void* xr, const float* in_scale, const float* in_shift, void* dx, float* partials, float* ws, int B,
                          int H, int W, int dtype, int g_premasked, int sweep_reverse, void* stream);

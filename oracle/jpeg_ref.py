@@ -12,8 +12,10 @@ Follows /root/reference/noise_layers/jpeg.py:
 
 Written with plain reshape + einsum on [B,3,H/8,8,W/8,8] blocks instead of the
 reference's split/cat reshuffle; identical for every shape where that reshuffle
-is self-consistent (padded H == padded W), and the natural block semantics for
-non-square images (where the reference's `chunk(split_num)` mis-assembles).
+is self-consistent (padded H == padded W).  For padded H != padded W the reference
+RAISES (jpeg.py:123-127 reuses one `split_num` for both axes; run on 16x32, 24x40 and
+100x200 inputs it fails in its cat/chunk): there the natural block semantics used here
+are an EXTENSION of this build, not parity with a reference result.
 """
 import math
 

@@ -89,8 +89,9 @@ def _operands(B, H, W, dt, seed):
 @pytest.mark.parametrize("case", [(16, 256, 256, torch.bfloat16, "premasked"), (16, 256, 256, torch.float16, "premasked"),
                                   (2, 64, 48, torch.bfloat16, "unmasked"), (2, 40, 64, torch.float16, "unmasked")])
 def test_bwd_ws_against_fp64_autograd(case):
-    from video_watermarking_forgery_detection_amd import ops
+    from video_watermarking_forgery_detection_amd import _lib, ops
     B, H, W, dt, form = case
+    assert _lib.lib().wm_conv3x3_bwd_fused_kernel(H, W, int(form == "premasked"), 0) == (8 if form == "premasked" and H % 8 == 0 and W % 16 == 0 else 1)
     o = _operands(B, H, W, dt, 4100)
     u = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11        # unit round-off of the storage type: half an ulp at 1.0 (bf16 keeps 8 significant bits, f16 11)
     R = 0.43                                                     # rms of one rounding's relative error, in units of u (measured: 0.425)
@@ -165,12 +166,14 @@ def test_bwd_ws_against_fp64_autograd(case):
     assert relB < 1e-4 and dB.max().item() < 2e-4 * o["dwB"].abs().max().item()
 
 
-@pytest.mark.parametrize("case", [(4, 64, 64, torch.bfloat16), (3, 40, 56, torch.float16)])
+@pytest.mark.parametrize("case", [(4, 64, 64, torch.bfloat16), (4, 64, 64, torch.float16), (3, 40, 56, torch.float16)])
 def test_bwd_ws_gvec_form_against_fp64_autograd(case):
     """the same for a globally pooled block (decoder.py:24-26, discriminator.py:16-17): the gradient wrt the ReLU output is one row per
     sample, gvec[b, c] = d loss / d mean_hw -- already divided by H*W"""
-    from video_watermarking_forgery_detection_amd import ops
+    from video_watermarking_forgery_detection_amd import _lib, ops
     B, H, W, dt = case
+    # whole 8x16 tiles go to the role-split kernel (csrc/bwd_ws8.hip, both dtypes' twins), ragged shapes to csrc/bwd_ws.hip
+    assert _lib.lib().wm_conv3x3_bwd_fused_kernel(H, W, 0, 1) == (8 if H % 8 == 0 and W % 16 == 0 else 1)
     q = lambda t: t.to(dt).double()
     seed = 4300
     xr = q(detgen.normal((B, C, H, W), seed + 1, mean=0.1))

@@ -1054,7 +1054,7 @@ def test_fused_backward_kernel_against_the_two_kernel_form(case):
     assert (dw1 - ref).abs().max().item() <= 2e-4 * dw0.abs().max().item()
 
 
-@pytest.mark.parametrize("case", [(4, 64, 64, torch.bfloat16), (3, 40, 56, torch.float16), (16, 128, 128, torch.bfloat16)])
+@pytest.mark.parametrize("case", [(4, 64, 64, torch.bfloat16), (4, 64, 64, torch.float16), (3, 40, 56, torch.float16), (16, 128, 128, torch.bfloat16)])
 def test_fused_backward_kernel_gvec_form(case):
     """the one-kernel backward of a globally pooled layer (one gradient row per sample) against wm_conv3x3_dgrad_bwdstats(gvec) +
     wm_conv3x3_wgrad_gvfused"""

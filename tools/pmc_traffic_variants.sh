@@ -2,17 +2,16 @@
 # ON THE GPU BOX: L2-miss traffic (FETCH_SIZE, WRITE_SIZE; separate passes) of the one-pass backward kernel alone, for several BUILDS of the
 # library (tools/micro/ab/libwm_hip_<name>.so, tools/build_variant.sh).  usage: bash tools/pmc_traffic_variants.sh A B ...
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-L=$ROOT/video_watermarking_forgery_detection_amd/lib/libwm_hip.so
 OUT=$ROOT/gpurun_out/pmc_var
 rm -rf $OUT; mkdir -p $OUT
-cp $L /tmp/libwm_hip_saved.so
+# (the variant is chosen through WM_LIB_VARIANT, _lib.py: the release library file is never touched)
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
-  cp $ROOT/tools/micro/ab/libwm_hip_$v.so $L
+  export WM_LIB_VARIANT=$v
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/$v/f -o f -- python3 $ROOT/tools/run_bwd_fused.py 6 > $OUT/$v.f.log 2>&1 || echo "$v fetch failed"
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/$v/w -o w -- python3 $ROOT/tools/run_bwd_fused.py 6 > $OUT/$v.w.log 2>&1 || echo "$v write failed"
 done
-cp /tmp/libwm_hip_saved.so $L
+unset WM_LIB_VARIANT
 python3 - "$@" <<PY
 import csv, glob, sys
 for v in sys.argv[1:]:

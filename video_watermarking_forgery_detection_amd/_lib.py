@@ -13,6 +13,11 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libwm_hip.so")
+# tools/ only (same-box A/B of two BUILDS, tools/ab_libs.sh): WM_LIB_VARIANT=<name> loads tools/micro/ab/libwm_hip_<name>.so in place of the
+# release file -- the release file is never overwritten, so an interrupted A/B cannot leave a variant installed.  loaded_path() says which
+_VARIANT = os.environ.get("WM_LIB_VARIANT")
+if _VARIANT:
+    LIB_PATH = os.path.join(os.path.dirname(_PKG), "tools", "micro", "ab", f"libwm_hip_{_VARIANT}.so")
 DEBUG_LIB_PATH = os.path.join(_PKG, "lib", "libwm_hip_dbg.so")
 _lib = None
 _release = None
@@ -37,6 +42,11 @@ def lib():
             _release = _load(LIB_PATH)
         _lib = _release
     return _lib
+
+
+def loaded_path():
+    """path of the library lib() loads (bench.py reports its hash next to the kernel sources' hash)"""
+    return LIB_PATH
 
 
 def debug_lib():

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
 
 }  // namespace
 
-void WM_HSYM(wm_launch_bwd_ws8)(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt, const void* xr,
+int WM_HSYM(wm_launch_bwd_ws8)(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt, const void* xr,
                                 const float* in_scale, const float* in_shift, void* dx, float* stat, float* ws, int B, int H, int W, int nwg,
                                 int reverse, hipStream_t s, int premasked, const float* gvec, int gv_ld, int stamps) {
     Bwd8Args a;
@@ -569,8 +569,10 @@ void WM_HSYM(wm_launch_bwd_ws8)(const void* g, const void* y, const float* stats
     a.mX = magic(a.tilesX); a.mY = magic(a.tilesY); a.m2X = magic(2 * a.tilesX);
     a.reverse = wm_sweep_dir(reverse);
     // (the unmasked-gradient form is not instantiated: it needs ~15 registers more than a two-waves-per-SIMD kernel has and stays on
-    // bwd_ws.hip -- wgrad.hip dispatches.  Both instantiated forms: 250 registers, no scratch)
-    (void)premasked;
+    // bwd_ws.hip -- wgrad.hip dispatches.  Both instantiated forms: 250 registers, no scratch.)  An unmasked tensor gradient handed to
+    // this launcher would be staged WITHOUT its ReLU mask: refused here, whatever the caller's dispatch condition says
+    if (!gvec && !premasked) return WM_E_SHAPE;
     if (gvec) hipLaunchKernelGGL((bwd_ws8_kernel<false, true>), dim3((unsigned)nwg), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((bwd_ws8_kernel<true, false>), dim3((unsigned)nwg), dim3(512), 0, s, a);
+    return WM_OK;
 }

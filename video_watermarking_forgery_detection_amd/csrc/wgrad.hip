@@ -40,7 +40,7 @@ template <typename... A> static inline void wm_launch_wgrad_ws(int dtype, A... a
 static inline bool is16(int dtype) { return dtype == WM_BF16 || dtype == WM_F16; }
 // the same with the two GEMMs on different waves (bwd_ws8.hip: whole-tile shapes, premasked gradient), compiled twice
 #define WM_DECL_BWDWS8(sfx)                                                                                                            \
-    void wm_launch_bwd_ws8##sfx(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt,     \
+    int wm_launch_bwd_ws8##sfx(const void* g, const void* y, const float* stats4, int st_ld, const float* coef, const void* wpt,     \
                                 const void* xr, const float* in_scale, const float* in_shift, void* dx, float* stat, float* ws, int B, \
                                 int H, int W, int nwg, int reverse, hipStream_t s, int premasked, const float* gvec, int gv_ld, int stamps)
 WM_DECL_BWDWS8(_bf16);
@@ -525,6 +525,11 @@ extern "C" int wm_conv3x3_bwd_fused_nwg(int B, int H, int W) {
     return (int)(n < 256 ? n : 256);
 }
 extern "C" int wm_conv3x3_bwd_fused_gvec_max_batch(void) { return wm_bwd_ws_gvec_max_batch_bf16(); }
+// whole-tile shapes with a premasked tensor gradient or a per-sample gradient (all 13 launches of the step): the role-split 8-wave form
+static bool bwd_split(int H, int W, int g_premasked, bool has_gvec) {
+    return g_bwd_split && (has_gvec || g_premasked) && H % 8 == 0 && W % 16 == 0 && (g_bwd_dbg == 0 || g_bwd_dbg == (1 << 21));
+}
+extern "C" int wm_conv3x3_bwd_fused_kernel(int H, int W, int g_premasked, int has_gvec) { return bwd_split(H, W, g_premasked, has_gvec != 0) ? 8 : 1; }
 extern "C" int wm_conv3x3_bwd_fused(const void* g, const float* gvec, const void* y, const float* stats4, const float* coef, const void* wpt,
                                     const void* xr, const float* in_scale, const float* in_shift, void* dx, float* partials, float* ws, int B,
                                     int H, int W, int dtype, int g_premasked, int sweep_reverse, void* stream) {
@@ -539,12 +544,13 @@ extern "C" int wm_conv3x3_bwd_fused(const void* g, const float* gvec, const void
                "wm_conv3x3_bwd_fused: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int nwg = wm_conv3x3_bwd_fused_nwg(B, H, W);
-    // whole-tile shapes with a premasked tensor gradient or a per-sample gradient (all 13 launches of the step): the role-split 8-wave form
-    const bool split = g_bwd_split && (gvec || g_premasked) && H % 8 == 0 && W % 16 == 0 && (g_bwd_dbg == 0 || g_bwd_dbg == (1 << 21));
+    const bool split = bwd_split(H, W, g_premasked, gvec != nullptr);
     const int stamps = g_bwd_dbg == (1 << 21);   // debug build: tools/phase_bwd8.py
     if (split) {
-        if (dtype == WM_F16) wm_launch_bwd_ws8_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, 1, gvec, 64, stamps);
-        else wm_launch_bwd_ws8_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, 1, gvec, 64, stamps);
+        const int rc8 = dtype == WM_F16
+            ? wm_launch_bwd_ws8_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_premasked, gvec, 64, stamps)
+            : wm_launch_bwd_ws8_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_premasked, gvec, 64, stamps);
+        WM_REQUIRE(rc8 == WM_OK, rc8, "wm_conv3x3_bwd_fused: the role-split kernel takes a premasked tensor gradient or a per-sample gradient only");
     } else if (dtype == WM_F16) wm_launch_bwd_ws_f16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked, gvec, 64);
     else wm_launch_bwd_ws_bf16(g, y, stats4, 64, coef, wpt, xr, in_scale, in_shift, dx, partials, ws, B, H, W, nwg, sweep_reverse ? 1 : 0, s, g_bwd_dbg, g_premasked, gvec, 64);
     WM_LAUNCH_CHECK("wm_conv3x3_bwd_fused");

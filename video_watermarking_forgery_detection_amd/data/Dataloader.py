@@ -38,20 +38,25 @@ def _resize(t, size):
 
 
 def _decode_clip(clip, root_path, sub, mode, clip_length):
-    """the clip's frames decoded on the host: uint8 [T,H,W,C] (C = 3 for "RGB", 1 for "L")"""
+    """the clip's frames decoded on the host: uint8 [T,H,W,C] (C = 3 for "RGB", 1 for "L") when every frame has the same size (DAVIS
+    480p does), else a list of [H_i,W_i,C] arrays -- the host path resizes frame by frame and never needed equal sizes"""
     d = os.path.join(root_path, sub, clip)
     names = sorted(os.listdir(d), key=_frame_key)
     if clip_length:
         names = names[:clip_length]
     frames = [np.asarray(Image.open(os.path.join(d, n)).convert(mode), dtype=np.uint8) for n in names]
-    a = np.stack(frames)
-    return a if a.ndim == 4 else a[..., None]
+    frames = [f if f.ndim == 3 else f[..., None] for f in frames]
+    if len({f.shape for f in frames}) > 1:
+        return frames
+    return np.stack(frames)
 
 
 def resize_clip_device(frames_u8, size, device="cuda"):
     """uint8 [T,H,W,C] (numpy or tensor) -> float32 [C,T,size,size] in [0,1] on the GPU: one conversion launch and one bilinear launch for
-    the whole clip (Dataloader.py:27-35 per frame on the host)"""
+    the whole clip (Dataloader.py:27-35 per frame on the host).  A list of frames of unequal sizes is resized frame by frame."""
     from .. import ops
+    if isinstance(frames_u8, (list, tuple)):
+        return torch.cat([resize_clip_device(f[None], size, device) for f in frames_u8], dim=1)
     t = torch.as_tensor(frames_u8).to(device, non_blocking=True)
     planes = ops.u8_hwc_to_planes(t, 1.0 / 255.0)                                   # [T,C,H,W]
     T, C, H, W = planes.shape
@@ -132,8 +137,10 @@ class DVDataset(data.Dataset):
                 rd_img, rd_mask = (read_img_device, read_mask_device) if self.resize_on == "device" else (read_img, read_mask)
                 Video_GT = rd_img(clip, self.root_path, self.videopath, self.image_size, self.clip_length)
                 Mask_GT, rate = rd_mask(clip, self.root_path, self.maskpath, self.image_size, self.clip_length)
-            except Exception:
-                raise IOError("Load {} Error".format(clip))
+            except (OSError, ValueError) as e:
+                # the reference's message (Dataloader.py:86-88) for what it is about: a frame that cannot be read or decoded.  Anything else --
+                # a HIP / runtime error of the device resize, out of memory -- is not a file error and propagates as what it is
+                raise IOError("Load {} Error".format(clip)) from e
             if rate < self.max_mask_rate:
                 return Video_GT, Mask_GT
             self.skip_list.append(index)

@@ -5,7 +5,16 @@ vertex: angle, length, brush width), strokes accumulated until the covered fract
 The reference rasterises with cv2.line / cv2.circle, which this image does not have; the strokes are rasterised here as the set of pixels
 within brushWidth/2 of the segment (a thick line with round ends) plus the one-pixel circle outlines of radius brushWidth//2 the
 reference draws at the joints.  Pixel-exact agreement with cv2's Bresenham-style thick lines is not claimed (parity unpinned: cv2 absent);
-what is kept is the sampling procedure, value range {0,1} and the coverage statistics."""
+what is kept is the sampling procedure, value range {0,1} and the coverage statistics.
+
+Contract restated (not the reference's text): `generate_stroke_mask(im_size)` draws, from numpy's GLOBAL RNG and in this order,
+  1. one uniform u -> the target coverage  lo + (hi - lo) * u  of `percent_range`;
+  2. then polylines until the covered fraction of the image reaches the target, each polyline drawing
+     a. its number of segments  ~ randint(1, maxVertex + 1),
+     b. its first joint (two randint: first axis h, second axis w),
+     c. per segment: a turn in whole degrees ~ randint(maxAngle + 1) (mirrored on even segments), a length ~ randint(8, S + 1) and an even
+        brush width = randint(8, S + 1) rounded down to even, with S = im_size[0] // 5; the next joint is the clamped end point.
+The joints are handed to the rasteriser as the reference hands them to cv2 (first coordinate as cv2's x)."""
 import numpy as np
 import torch
 
@@ -38,42 +47,47 @@ def _circle_outline(mask, c, radius, value):
     mask[lo_y:hi_y + 1, lo_x:hi_x + 1][np.abs(d - radius) <= 0.5] = value
 
 
-def np_free_form_mask(mask_re, maxVertex, maxLength, maxBrushWidth, maxAngle, h, w):
-    """IRNrhi_model.py:1173-1193 (cv2 points are (x, y); the reference passes (startY, startX) as such, kept)"""
-    mask = np.zeros_like(mask_re)
-    numVertex = np.random.randint(1, maxVertex + 1)
-    startY = np.random.randint(h)
-    startX = np.random.randint(w)
-    brushWidth = 0
-    for i in range(numVertex):
-        angle = np.random.randint(maxAngle + 1)
-        angle = angle / 360.0 * 2 * np.pi
-        if i % 2 == 0:
-            angle = 2 * np.pi - angle
-        length = np.random.randint(8, maxLength + 1)
-        brushWidth = np.random.randint(8, maxBrushWidth + 1) // 2 * 2
-        nextY = startY + length * np.cos(angle)
-        nextX = startX + length * np.sin(angle)
-        nextY = int(np.maximum(np.minimum(nextY, h - 1), 0))
-        nextX = int(np.maximum(np.minimum(nextX, w - 1), 0))
-        _line(mask, (startY, startX), (nextY, nextX), brushWidth)
-        _circle_outline(mask, (startY, startX), brushWidth // 2, 2)
-        startY, startX = nextY, nextX
-    _circle_outline(mask, (startY, startX), brushWidth // 2, 2)
-    return mask
+def _polyline(h, w, max_segments, max_step, max_turn_deg):
+    """one polyline of the contract above: yields (joint, next joint, even brush width) per segment, drawing from np.random in the
+    contract's order; the joints are (first-axis, second-axis) integer pairs clamped to the image"""
+    n = np.random.randint(1, max_segments + 1)
+    joint = (np.random.randint(h), np.random.randint(w))
+    for seg in range(n):
+        turn = np.deg2rad(float(np.random.randint(max_turn_deg + 1)))
+        if seg % 2 == 0:
+            turn = 2.0 * np.pi - turn
+        step = np.random.randint(8, max_step + 1)
+        brush = (np.random.randint(8, max_step + 1) // 2) * 2
+        nxt = (int(min(max(joint[0] + step * np.cos(turn), 0), h - 1)), int(min(max(joint[1] + step * np.sin(turn), 0), w - 1)))
+        yield joint, nxt, brush
+        joint = nxt
 
 
-def generate_stroke_mask(im_size, parts=5, parts_square=2, maxVertex=4, maxLength=64, maxBrushWidth=32, maxAngle=360, percent_range=(0.0, 0.5)):
-    """IRNrhi_model.py:1147-1171 -> (mask tensor [H,W] in {0,1}, covered fraction)"""
-    maxLength = int(im_size[0] / 5)
-    maxBrushWidth = int(im_size[0] / 5)
-    mask = np.zeros((im_size[0], im_size[1]), dtype=np.float32)
-    lower_bound_percent = percent_range[0] + (percent_range[1] - percent_range[0]) * np.random.rand()
+def _draw_polyline(h, w, max_segments, max_step, max_turn_deg):
+    """a fresh [h,w] canvas with one polyline: thick segments of value 1, joint outlines (radius brush // 2) of value 2 -- the
+    outlines saturate to 1 with everything else when the caller clips the accumulated canvas"""
+    canvas = np.zeros((h, w), dtype=np.float32)
+    end, brush = None, 0
+    for a, b, brush in _polyline(h, w, max_segments, max_step, max_turn_deg):
+        _line(canvas, a, b, brush)
+        _circle_outline(canvas, a, brush // 2, 2)
+        end = b
+    if end is not None:
+        _circle_outline(canvas, end, brush // 2, 2)
+    return canvas
+
+
+def generate_stroke_mask(im_size, maxVertex=4, maxAngle=360, percent_range=(0.0, 0.5), **unused):
+    """-> (mask tensor [H,W] float32 in {0,1}, covered fraction).  Reference: models/IRNrhi_model.py:1147-1193 (the keyword names it
+    passes are accepted; `parts`, `parts_square`, `maxLength`, `maxBrushWidth` never had an effect there -- the two sizes are
+    overwritten by im_size[0] / 5 -- and are swallowed by **unused)."""
+    h, w = int(im_size[0]), int(im_size[1])
+    reach = int(h / 5)
+    lo, hi = percent_range
+    target = lo + (hi - lo) * np.random.rand()
+    covered = np.zeros((h, w), dtype=np.float32)
     while True:
-        mask = mask + np_free_form_mask(mask, maxVertex, maxLength, maxBrushWidth, maxAngle, im_size[0], im_size[1])
-        mask = np.minimum(mask, 1.0)
-        percent = np.mean(mask)
-        if percent >= lower_bound_percent:
+        np.minimum(covered + _draw_polyline(h, w, maxVertex, reach, maxAngle), 1.0, out=covered)
+        if covered.mean() >= target:
             break
-    mask = np.maximum(mask, 0.0)
-    return torch.from_numpy(mask).contiguous(), float(np.mean(mask))
+    return torch.from_numpy(covered).contiguous(), float(covered.mean())
