@@ -65,6 +65,10 @@ def parse():
                     help="the roofline kernels are bracketed with HIP events on every n-th timed step only: an event pair idles the GPU for ~11 us "
                          "around the launch it brackets (28 bracketed launches = 0.31 ms of a 5.5 ms step when every step is instrumented)")
     ap.add_argument("--keep-dead-grads", action="store_true", help="also compute the discriminator weight gradients of the generator pass (the reference's state; nothing reads them)")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None,
+                    help="replay the step from a hipGraph (Hidden.enable_graph; one GPU only: with a gradient all-reduce the step runs eagerly); "
+                         "the steps whose kernels are bracketed with events (every --kernel-events-every-th) are enqueued eagerly")
+    ap.add_argument("--no-graph", dest="graph", action="store_false")
     ap.add_argument("--no-extra", action="store_true", help="skip the two secondary timed regions (reference_state, c4_shard_512)")
     ap.add_argument("--extra-steps", type=int, default=25, help="timed steps of each secondary region (after 5 warm-up steps)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames per step of the bounded CPU-baseline sample")
@@ -167,6 +171,7 @@ def kernel_sources_sha():
 
 
 PMC_FILE = "r03_pmc_traffic.json"
+GRAPH_DEFAULT = False   # bench.py --graph / --no-graph overrides
 _pmc = {}
 
 
@@ -279,6 +284,10 @@ def main():
     sync = GradSync(profile=True) if world > 1 else None
     h = Hidden(cfg, dev, noise, None, compute_dtype=dtype, grad_sync=sync, keep_dead_discriminator_grads=args.keep_dead_grads)
     broadcast_parameters([h.encoder_decoder.encoder, h.encoder_decoder.decoder, h.discriminator])
+    use_graph = bool(args.graph) if args.graph is not None else GRAPH_DEFAULT
+    use_graph = use_graph and world == 1
+    if use_graph:
+        h.enable_graph()
     torch.manual_seed(10 + rank)  # rank r draws its shard with seed 10+r
     images = torch.rand(B, 3, S, S, device=dev)
     messages = torch.randint(0, 2, (B, 30), device=dev).float()
@@ -301,7 +310,7 @@ def main():
     every = max(1, args.kernel_events_every)
     barrier()
     t0 = time.perf_counter()
-    host_ms = []
+    host_ms, host_ms_eager = [], []
     for i in range(args.steps):
         # The kernel events are part of the timed region, and they are not free: rocprofv3's kernel trace shows 5.3-6.1 us of idle GPU on
         # either side of every bracketed launch (the event's marker packet) and none around the launches that are not bracketed -- so the
@@ -312,9 +321,11 @@ def main():
         marks[i].record()
         th = time.perf_counter()
         losses, _ = h.train_on_batch([images, messages])
-        host_ms.append(1e3 * (time.perf_counter() - th))
+        (host_ms_eager if (use_graph and i % every == 0) else host_ms).append(1e3 * (time.perf_counter() - th))
     marks[args.steps].record()
-    host_ms.sort()
+    host_ms.sort(); host_ms_eager.sort()
+    if not host_ms:
+        host_ms = host_ms_eager
     barrier()
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
@@ -350,6 +361,8 @@ def main():
         torch.manual_seed(10)
         h2 = Hidden(HiDDenConfiguration(H=S2, W=S2), dev, noise, None, compute_dtype=dtype, grad_sync=sync, keep_dead_discriminator_grads=args.keep_dead_grads)
         broadcast_parameters([h2.encoder_decoder.encoder, h2.encoder_decoder.decoder, h2.discriminator])
+        if use_graph:
+            h2.enable_graph()
         torch.manual_seed(10 + rank)
         im2 = torch.rand(B2, 3, S2, S2, device=dev)
         ms2 = torch.randint(0, 2, (B2, 30), device=dev).float()
@@ -408,7 +421,9 @@ def main():
                                    + ("" if args.keep_dead_grads else "; the generator pass through the discriminator computes no (dead) discriminator weight gradients"),
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "ms_per_step_median_events": step_ms[len(step_ms) // 2], "ms_per_step_min_events": step_ms[0], "ms_per_step_max_events": step_ms[-1],
+            "graph": use_graph,
             "host_enqueue_ms_median": host_ms[len(host_ms) // 2], "host_enqueue_ms_max": host_ms[-1],
+            "host_enqueue_ms_median_eager_steps": host_ms_eager[len(host_ms_eager) // 2] if host_ms_eager else None,
             "kernel_events_every": every,
             "roofline": roof,
             "roofline_mfma": mfma,

@@ -422,6 +422,14 @@ int wm_axpy(float* a, const float* b, float s, size_t n, void* stream);
 int wm_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int decoupled, int step, float grad_scale,
                  void* stream);
+/* The same step for a hipGraph-captured training step (a Python step per batch per rank, /root/reference/train.py:99-109, replayed
+ * instead of re-enqueued): the two step-count-dependent constants come from DEVICE memory instead of the argument list.
+ * wm_adam_hyper (host, no launch): out2 = {lr / (1 - beta1^step), sqrt(1 - beta2^step)} -- exactly the values wm_adam_step derives;
+ * wm_adam_step_dev reads them from hyper_dev (device float[2]), which the caller refreshes before each replay: bit-identical
+ * to wm_adam_step(step). */
+int wm_adam_hyper(float lr, float beta1, float beta2, int step, float* out2);
+int wm_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int decoupled, const float* hyper_dev, float grad_scale, void* stream);
 /* sum of squares partials (clip_grad_norm_) */
 /* nn.Linear after the global average pool (hidden_models/decoder.py:26,32-34, discriminator.py:18,24-26), B ~ 16, I,O <= 64:
  * fwd: out[B,O] = pooled[:, :I] @ w[O,I]^T + bias.

@@ -81,6 +81,7 @@ def check_against_oracle(h32, hbf, ref, images, messages, tag):
                     continue
                 gl2[f"{k}.{n}"] = rel_l2(p.grad, rgrads[k][n])
         report[name]["grad_l2_max"] = max(gl2.values())
+        report[name]["grad_l2_argmax"] = max(gl2, key=gl2.get)
         report[name]["grad_l2_median"] = float(np.median(list(gl2.values())))
     print(tag, report)
     f, b = report["f32"], report["bf16"]
@@ -96,6 +97,13 @@ def check_against_oracle(h32, hbf, ref, images, messages, tag):
     assert all(v < 2e-2 for v in b["loss"].values()), b
     assert b["w_mean"] < 6e-4 and b["w_max"] <= 2.1e-3, b
     assert b["grad_l2_median"] < 8e-2, b
+    # ... and NO single parameter's gradient may be badly off (round 3's verdict: a median alone would let one through).  Measured maxima of
+    # the relative L2 error over all encoder / decoder parameters (round 4, MI355X): C2 (Jpeg50) 0.122, C4 shard (JpegSS50, 512^2) 0.065,
+    # full-size C3 under Resize(0.7) 0.109, under GaussianBlur 0.059 (the report names the parameter: grad_l2_argmax).  Bound: 2.5 x the
+    # largest of them.  (The f32 path's maximum on the same steps is 1e-3..3e-3: the bf16 figure is rounding noise of gradients that
+    # are sums of ~1e6 bf16-rounded terms which largely cancel, not an error of the arithmetic -- tests/test_gpu_bwd_oracle.py
+    # bounds that noise per kernel.)
+    assert b["grad_l2_max"] < 0.3, b
     return report
 
 
@@ -119,6 +127,22 @@ def test_c4_shard_512_vs_oracle():
     messages = detgen.bits((B, 30), 9201)
     ref = make_ref(S, lambda x: jpeg_ref.jpeg_layer(x, 50, "ss"))
     check_against_oracle(make_hidden(S, JpegSS(50), torch.float32), make_hidden(S, JpegSS(50), torch.bfloat16), ref, images, messages, "C4")
+
+
+@pytest.mark.parametrize("nname", ["Resize0.7", "GaussianBlur"])
+def test_c3_full_size_step_vs_oracle(nname):
+    """config C3 at FULL size (B=16, 256x256) for two attacks of the cycle, f32 parity path and bf16 production path against one oracle
+    step (the oracle's attack ops are pinned by tests/golden/attacks.npz, its step by step_c3.npz at 32x32): the fixture-size tests
+    above cannot see a full-size-only failure of the separable resample backward or the stencil (tile seams, 32-bit offsets)."""
+    S, B = 256, 16
+    images = detgen.uniform((B, 3, S, S), 9300)
+    messages = detgen.bits((B, 30), 9301)
+    fn = {"Resize0.7": lambda x: attacks_ref.resize(x, 0.7), "GaussianBlur": lambda x: attacks_ref.gaussian_blur(x)}[nname]
+    ref = make_ref(S, fn)
+    rep = check_against_oracle(make_hidden(S, _c3_layers()[nname], torch.float32), make_hidden(S, _c3_layers()[nname], torch.bfloat16), ref,
+                               images, messages, f"C3/{nname}")
+    # a smooth attack has no rounding decisions: `noised` itself must agree, not just a bounded fraction of it
+    assert rep["f32"]["noised_flip"] == 0.0, rep["f32"]
 
 
 class _Fixed:

@@ -1,0 +1,111 @@
+"""Round 4: the HiDDeN-order training step replayed from a hipGraph (Hidden.enable_graph, hidden_models/hidden.py::_StepGraph) against the same
+step enqueued eagerly -- bit for bit: every logged scalar of every step, the outputs, and after the last step every parameter, BatchNorm
+buffer and Adam moment.  The reference runs one Python step per batch per rank (/root/reference/train.py:99-109, hidden.py:54-118); the
+graph holds the very launches of that step, with fresh inputs copied into its static tensors and Adam's step-count-dependent constants
+refreshed in device memory before each replay."""
+import pytest
+import torch
+
+import detgen
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(size, noise, dtype, keep_dead=True):
+    from video_watermarking_forgery_detection_amd.hidden_models import Hidden
+    from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
+    h = Hidden(HiDDenConfiguration(H=size, W=size), torch.device("cuda"), noise, None, compute_dtype=dtype, keep_dead_discriminator_grads=keep_dead)
+    for m in (h.encoder_decoder.encoder, h.encoder_decoder.decoder, h.discriminator):
+        detgen.fill_module(m)
+    return h
+
+
+def _state(h):
+    out = {}
+    for k, m in (("E", h.encoder_decoder.encoder), ("Dec", h.encoder_decoder.decoder), ("D", h.discriminator)):
+        for n, t in m.state_dict().items():
+            out[f"{k}.{n}"] = t.detach().clone()
+        out[f"{k}.grad"] = m.flat_grads.detach().clone()
+    for k, o in (("optD", h.optimizer_discrim), ("optED", h.optimizer_enc_dec)):
+        for i, (m, v) in enumerate(zip(o._m, o._v)):
+            out[f"{k}.m{i}"], out[f"{k}.v{i}"] = m.detach().clone(), v.detach().clone()
+        out[f"{k}.steps"] = torch.tensor(o.step_count)
+    return out
+
+
+@pytest.mark.parametrize("case", [("Jpeg50", torch.bfloat16, 64, 4, False), ("JpegSS70", torch.bfloat16, 64, 4, True), ("JpegMask50", torch.float32, 32, 2, True),
+                                  ("Resize", torch.float16, 64, 4, True)])
+def test_captured_step_equals_eager_bit_for_bit(case):
+    from video_watermarking_forgery_detection_amd import noise_layers as NL, ops
+    name, dt, S, B, keep = case
+
+    def noise():
+        if name == "Resize":
+            class Fixed:   # Resize with its ratio pinned: the random draw is a host decision and would be baked into the graph
+                def __init__(self):
+                    self.l = NL.Resize()
+                def fwd(self, x):
+                    return self.l.fwd(x, resize_ratio=0.7)
+                def bwd(self, c, g):
+                    return self.l.bwd(c, g)
+            return Fixed()
+        kind = "".join(c for c in name if not c.isdigit())
+        return getattr(NL, kind)(int(name[len(kind):]))
+
+    def amp():
+        return ops.AmpState(torch.device("cuda")) if dt == torch.float16 else None
+
+    from video_watermarking_forgery_detection_amd.hidden_models import Hidden
+    from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
+
+    def make():
+        h = Hidden(HiDDenConfiguration(H=S, W=S), torch.device("cuda"), noise(), None, compute_dtype=dt, keep_dead_discriminator_grads=keep, amp=amp())
+        for m in (h.encoder_decoder.encoder, h.encoder_decoder.decoder, h.discriminator):
+            detgen.fill_module(m)
+        return h
+
+    eager, graph = make(), make().enable_graph()
+    NSTEP = 6       # graph: 2 eager warm-up steps, capture + replay at the 3rd, replays after
+    for i in range(NSTEP):
+        images = detgen.uniform((B, 3, S, S), 7000 + i).cuda()          # a fresh tensor every step: the graph's static inputs are refreshed by copy
+        messages = detgen.bits((B, 30), 7100 + i).cuda()
+        le, (ee, ne, de) = eager.train_on_batch([images, messages])
+        lg, (eg, ng, dg) = graph.train_on_batch([images, messages])
+        assert list(le.keys()) == list(lg.keys())
+        for k in le:
+            assert le[k] == lg[k], (i, k, le[k], lg[k])                  # floats from the same f32 device values: equality, not closeness
+        assert torch.equal(ee, eg) and torch.equal(ne, ng) and torch.equal(de, dg), i
+    g = next(iter(graph._graphs.values()))
+    assert g.graph is not None and g.calls == NSTEP                      # the graph path really ran (3 eager-equivalent calls + replays)
+    se, sg = _state(eager), _state(graph)
+    assert se.keys() == sg.keys()
+    for k in se:
+        assert torch.equal(se[k], sg[k]), k
+    # a call the graph cannot serve (a clip callable) falls back to the eager path and keeps the two models in step
+    images = detgen.uniform((B, 3, S, S), 7050).cuda(); messages = detgen.bits((B, 30), 7150).cuda()
+    seen = []
+    le, _ = eager.train_on_batch([images, messages], clip=lambda flats: seen.append(len(flats)))
+    lg, _ = graph.train_on_batch([images, messages], clip=lambda flats: seen.append(len(flats)))
+    assert all(le[k] == lg[k] for k in le) and seen == [1, 2, 1, 2]
+    # ... and the next plain call replays again, with the step counts the eager call advanced
+    le, _ = eager.train_on_batch([images, messages])
+    lg, _ = graph.train_on_batch([images, messages])
+    assert all(le[k] == lg[k] for k in le)
+    for k, v in _state(eager).items():
+        assert torch.equal(v, _state(graph)[k]), k
+
+
+def test_graph_mode_refuses_nothing_silently():
+    """an attack layer without an explicit fwd / bwd (autograd inside the step) is served eagerly, not captured"""
+    from video_watermarking_forgery_detection_amd import noise_layers as NL
+
+    class Plain(torch.nn.Module):
+        def forward(self, pair):
+            return [pair[0] * 0.5 + 0.25, pair[1]]
+
+    h = _make(32, Plain(), torch.float32).enable_graph()
+    images = detgen.uniform((2, 3, 32, 32), 1).cuda(); messages = detgen.bits((2, 30), 2).cuda()
+    for _ in range(4):
+        h.train_on_batch([images, messages])
+    assert h._graphs == {}
+    assert NL is not None

@@ -105,6 +105,29 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// the same step with its two step-count-dependent constants read from DEVICE memory (hyper = {lr / (1 - b1^t), sqrt(1 - b2^t)}, the values
+// wm_adam_hyper computes on the host): a step captured into a hipGraph replays with the constants of the CURRENT step count -- the host
+// refreshes the two floats before each replay -- and is bit-identical to wm_adam_step
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                       float wd, int decoupled, const float* __restrict__ hyper, float grad_scale) {
+    const float step_size = hyper[0], bc2_sqrt = hyper[1];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float gg = g[i] * grad_scale;
+        float pp = p[i];
+        if (wd != 0.f) {
+            if (decoupled) pp *= 1.f - lr * wd;
+            else gg += wd * pp;
+        }
+        const float mm = b1 * m[i] + (1.f - b1) * gg;
+        const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+        m[i] = mm;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[i] = pp - step_size * (mm / denom);
+    }
+}
+
 // ---- torch.cuda.amp.GradScaler (models/IRNcrop_model.py:143,407-416) kept on the device.  state (f32[WM_AMP_STATE]):
 //   [0] scale  [1] growth tracker  [2] growth_factor  [3] backoff_factor  [4] growth_interval
 //   [8 + k] found_inf of optimiser k (k < 4)   [12 + k] step count of optimiser k (torch's `step`: not advanced by a skipped step)
@@ -244,16 +267,32 @@ extern "C" int wm_axpy(float* a, const float* b, float s, size_t n, void* stream
     return WM_OK;
 }
 
+extern "C" int wm_adam_hyper(float lr, float beta1, float beta2, int step, float* out2) {
+    WM_REQUIRE(out2 && step >= 1, WM_E_BADARG, "wm_adam_hyper: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    out2[0] = (float)((double)lr / bc1);
+    out2[1] = (float)sqrt(bc2);
+    return WM_OK;
+}
+
 extern "C" int wm_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                             float eps, float weight_decay, int decoupled, int step, float grad_scale, void* stream) {
     WM_REQUIRE(p && g && m && v && n > 0 && step >= 1, WM_E_BADARG, "wm_adam_step: bad arguments");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    float hy[2];
+    wm_adam_hyper(lr, beta1, beta2, step, hy);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, decoupled, step_size, bc2_sqrt, grad_scale);
+                       weight_decay, decoupled, hy[0], hy[1], grad_scale);
     WM_LAUNCH_CHECK("wm_adam_step");
+    return WM_OK;
+}
+
+extern "C" int wm_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, int decoupled, const float* hyper_dev, float grad_scale, void* stream) {
+    WM_REQUIRE(p && g && m && v && hyper_dev && n > 0, WM_E_BADARG, "wm_adam_step_dev: bad arguments");
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, decoupled, hyper_dev, grad_scale);
+    WM_LAUNCH_CHECK("wm_adam_step_dev");
     return WM_OK;
 }
 

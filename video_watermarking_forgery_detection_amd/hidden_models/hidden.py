@@ -85,6 +85,9 @@ class _FlatAdam:
         self.step_count = 0
         self._m = None
         self._v = None
+        self.capturing = False  # True while a step is being CAPTURED into a hipGraph (_StepGraph): step() leaves step_count to the graph's owner,
+        self.hyper_dev = None   # and (without a scaler) launches the kernel that reads its step-count-dependent constants from this [2] f32
+                                # device tensor, which the owner refreshes before each replay
 
     def _ensure(self):
         if self._m is None:
@@ -102,7 +105,8 @@ class _FlatAdam:
 
     def step(self, grad_scale=1.0):
         self._ensure()
-        self.step_count += 1
+        if not self.capturing:
+            self.step_count += 1
         g = self.param_groups[0]
         amp = getattr(self, "amp", None)
         if amp is not None:   # scaler.step(optimizer), IRNcrop_model.py:413-414
@@ -111,9 +115,19 @@ class _FlatAdam:
                 ops.adam_step_amp(mod.flat_params, mod.flat_grads, m, v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
                                   amp, self.amp_slot, decoupled=self.decoupled, grad_scale=grad_scale)
             return
+        if self.hyper_dev is not None:   # being captured: the constants of step t come from device memory at replay time
+            for mod, m, v in zip(self.modules, self._m, self._v):
+                ops.adam_step_dev(mod.flat_params, mod.flat_grads, m, v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                                  g["weight_decay"], self.hyper_dev, decoupled=self.decoupled, grad_scale=grad_scale)
+            return
         for mod, m, v in zip(self.modules, self._m, self._v):
             ops.adam_step(mod.flat_params, mod.flat_grads, m, v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                           g["weight_decay"], self.step_count, decoupled=self.decoupled, grad_scale=grad_scale)
+
+    def hyper(self, step):
+        """the pair adam_step derives from the step count (host arithmetic): what a captured step's replay needs in hyper_dev"""
+        g = self.param_groups[0]
+        return ops.adam_hyper(g["lr"], g["betas"][0], g["betas"][1], step)
 
     def _params(self):
         return [p for mod in self.modules for p in mod.parameters()]
@@ -236,6 +250,67 @@ def _accepts_id(fn):
 _ACCEPTS_ID = {}
 
 
+class _StepGraph:
+    """One training step of `Hidden` as a hipGraph (the reference runs one Python step per batch per rank, train.py:99-109; here the host's
+    ~190 launches per step are enqueued once and replayed).  Exact by construction: the graph holds the very launches of the eager step --
+    the step has no autograd and no host synchronisation (engine.py) --, its inputs are static tensors refreshed by copy_, and the only
+    host-side number a step depends on, Adam's step count, reaches the kernels through device memory (wm_adam_step_dev) that is refreshed
+    before each replay.  Call k of a shape: k < WARMUP eager (real steps; they build the weight-pack plans and settle the allocator),
+    k == WARMUP capture + replay, later calls replay.  The tensors a replay returns (encoded, noised, decoded) are the graph's own and are
+    overwritten by the next replay of the same graph, as torch.cuda.CUDAGraph documents; the losses are copied out per step."""
+    WARMUP = 2
+
+    def __init__(self, hidden):
+        self.h = hidden
+        self.calls = 0
+        self.graph = None
+
+    def _hyper_refresh(self):
+        opts = (self.h.optimizer_discrim, self.h.optimizer_enc_dec)
+        if self.h.amp is not None:
+            return   # under the scaler the step counts live on the device already (wm_adam_step_amp)
+        vals = [v for o in opts for v in o.hyper(o.step_count + 1)]
+        self.hyper_host.copy_(torch.tensor(vals, dtype=torch.float32))
+        self.hyper.copy_(self.hyper_host, non_blocking=True)
+
+    def step(self, images, messages):
+        h = self.h
+        if self.calls < self.WARMUP:
+            self.calls += 1
+            return h._step_eager(images, messages)
+        if self.graph is None:
+            dev = images.device
+            self.img, self.msg = torch.empty_like(images), torch.empty_like(messages)
+            self.hyper = torch.zeros(4, device=dev, dtype=torch.float32)
+            self.hyper_host = torch.empty(4, dtype=torch.float32, pin_memory=True)
+            self.img.copy_(images); self.msg.copy_(messages)
+            opts = (h.optimizer_discrim, h.optimizer_enc_dec)
+            for i, o in enumerate(opts):
+                o._ensure()
+                o.capturing = True
+                if h.amp is None:
+                    o.hyper_dev = self.hyper[2 * i:2 * i + 2]
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    self.result = h._step_launches(self.img, self.msg)
+            finally:
+                for o in opts:
+                    o.hyper_dev, o.capturing = None, False
+            self.graph = graph
+        if images.data_ptr() != self.img.data_ptr():
+            self.img.copy_(images)
+        if messages.data_ptr() != self.msg.data_ptr():
+            self.msg.copy_(messages)
+        self._hyper_refresh()
+        self.graph.replay()
+        self.calls += 1
+        h.optimizer_discrim.step_count += 1
+        h.optimizer_enc_dec.step_count += 1
+        vals, extra_logs, outs = self.result
+        return h._wrap_losses(vals, extra_logs), outs
+
+
 class Hidden:
     def __init__(self, configuration: HiDDenConfiguration, device: torch.device, noiser, tb_logger=None,
                  compute_dtype=torch.bfloat16, grad_sync=None, amp=None, keep_dead_discriminator_grads=True):
@@ -289,6 +364,14 @@ class Hidden:
             self.optimizer_discrim.attach_amp(amp)
         self.noise_id = None  # optional deterministic choice for Combined/Noiser layers
         self.lazy_losses = True  # train_on_batch returns StepLosses (host sync on first read) instead of a plain dict
+        self._graphs = None      # enable_graph(): (shapes, attack choice, ...) -> _StepGraph
+
+    def enable_graph(self, on=True):
+        """replay the step from a hipGraph instead of enqueueing its ~190 launches every call (same results bit for bit: _StepGraph).
+        Used for plain train_on_batch(batch) calls on one GPU with an attack layer that has an explicit fwd / bwd; a call with
+        extra_encoded_grad / clip / enc_gate, with a grad_sync, or while a kernel timer is installed runs eagerly as before."""
+        self._graphs = {} if on else None
+        return self
 
     # ------------------------------------------------------------------ helpers
     def _bce_logits(self, logits, target, gscale=1.0):
@@ -321,6 +404,32 @@ class Hidden:
         images, messages = batch
         images = images.to(self.device, torch.float32).contiguous()
         messages = messages.to(self.device, torch.float32).contiguous()
+        n = self.encoder_decoder.noiser
+        if (self._graphs is not None and extra_encoded_grad is None and clip is None and enc_gate is None and self.grad_sync is None
+                and not ops.kernel_timer_installed() and hasattr(n, "fwd") and hasattr(n, "bwd")
+                and not torch.cuda.is_current_stream_capturing()):
+            key = (tuple(images.shape), tuple(messages.shape), self.noise_id, self.keep_dead_discriminator_grads, self.lazy_losses,
+                   self.encoder_decoder.encoder.compute_dtype)
+            g = self._graphs.get(key)
+            if g is None:
+                g = self._graphs[key] = _StepGraph(self)
+            return g.step(images, messages)
+        return self._step_eager(images, messages, extra_encoded_grad, clip, enc_gate)
+
+    def _step_eager(self, images, messages, extra_encoded_grad=None, clip=None, enc_gate=None):
+        vals, extra_logs, outs = self._step_launches(images, messages, extra_encoded_grad, clip, enc_gate)
+        return self._wrap_losses(vals, extra_logs), outs
+
+    def _wrap_losses(self, vals, extra_logs):
+        if self.lazy_losses:
+            return StepLosses(vals, extra_logs)
+        losses = dict(zip(LOSS_KEYS, vals.tolist()))
+        if extra_logs:
+            losses['_extra'] = extra_logs
+        return losses
+
+    def _step_launches(self, images, messages, extra_encoded_grad=None, clip=None, enc_gate=None):
+        """every launch of one step, no host synchronisation -> ([7] device tensor of the logged scalars, extra logs, (encoded, noised, decoded))"""
         B = images.shape[0]
         cfg = self.config
         ed = self.encoder_decoder
@@ -421,12 +530,7 @@ class Hidden:
         # ---------------- metrics: one host sync for all seven scalars (hidden.py:105-117)
         vals = ops.hidden_metrics(enc_part, n_img, msg_out, g_loss_adv, d_loss_on_cover, d_loss_on_encoded, cfg.adversarial_loss,
                                   cfg.encoder_loss, cfg.decoder_loss)
-        if self.lazy_losses:
-            return StepLosses(vals, extra_logs), (encoded, noised, decoded)
-        losses = dict(zip(LOSS_KEYS, vals.tolist()))
-        if extra_logs:
-            losses['_extra'] = extra_logs
-        return losses, (encoded, noised, decoded)
+        return vals, extra_logs, (encoded, noised, decoded)
 
     def validate_on_batch(self, batch: list):
         """hidden.py:120-182: eval-mode BatchNorm (running statistics), no parameter update."""

@@ -784,6 +784,25 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, decoupled=F
     _wrote(p, m, v)
 
 
+def adam_hyper(lr, beta1, beta2, step):
+    """(lr / (1 - beta1^step), sqrt(1 - beta2^step)) as wm_adam_step derives them (host arithmetic, no launch)"""
+    out = (c_float * 2)()
+    rc = _lib.lib().wm_adam_hyper(c_float(lr), c_float(beta1), c_float(beta2), c_int(step), out)
+    _lib.check(rc, "wm_adam_hyper")
+    return float(out[0]), float(out[1])
+
+
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, weight_decay, hyper_dev, decoupled=False, grad_scale=1.0):
+    """adam_step with the step-count-dependent constants read from the device tensor hyper_dev [2] f32 (adam_hyper's pair): what a
+    captured step launches -- the caller refreshes hyper_dev before each replay"""
+    assert hyper_dev.is_cuda and hyper_dev.dtype == torch.float32 and hyper_dev.numel() >= 2 and hyper_dev.is_contiguous()
+    rc = _lib.lib().wm_adam_step_dev(_p(p), _p(g), _p(m), _p(v), c_size_t(p.numel()), c_float(lr), c_float(beta1), c_float(beta2),
+                                     c_float(eps), c_float(weight_decay), c_int(1 if decoupled else 0), _p(hyper_dev),
+                                     c_float(grad_scale), _stream())
+    _lib.check(rc, "wm_adam_step_dev")
+    _wrote(p, m, v)
+
+
 class AmpState:
     """torch.cuda.amp.GradScaler (IRNcrop_model.py:143,407-416) with its state on the device: see include/wm_hip.h (wm_amp_*).
     `scale` is the device scalar the loss kernels multiply their gradient seeds by."""
@@ -982,6 +1001,10 @@ class KernelTimer:
 def set_kernel_timer(timer):
     global _TIMER
     _TIMER = timer
+
+
+def kernel_timer_installed():
+    return _TIMER is not None
 
 
 def _timed(name, info, launch):
