@@ -69,6 +69,9 @@ def parse():
                     help="replay the step from a hipGraph (Hidden.enable_graph; one GPU only: with a gradient all-reduce the step runs eagerly); "
                          "the steps whose kernels are bracketed with events (every --kernel-events-every-th) are enqueued eagerly")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
+    ap.add_argument("--two-streams", dest="two_streams", action="store_true", default=None,
+                    help="the step's two independent chains (discriminator passes | encoder -> attack -> decoder) on two streams (Hidden.two_streams)")
+    ap.add_argument("--one-stream", dest="two_streams", action="store_false")
     ap.add_argument("--no-extra", action="store_true", help="skip the two secondary timed regions (reference_state, c4_shard_512)")
     ap.add_argument("--extra-steps", type=int, default=25, help="timed steps of each secondary region (after 5 warm-up steps)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames per step of the bounded CPU-baseline sample")
@@ -172,6 +175,7 @@ def kernel_sources_sha():
 
 PMC_FILE = "r03_pmc_traffic.json"
 GRAPH_DEFAULT = False   # bench.py --graph / --no-graph overrides
+TWO_STREAMS_DEFAULT = False   # --two-streams / --one-stream
 _pmc = {}
 
 
@@ -284,6 +288,7 @@ def main():
     sync = GradSync(profile=True) if world > 1 else None
     h = Hidden(cfg, dev, noise, None, compute_dtype=dtype, grad_sync=sync, keep_dead_discriminator_grads=args.keep_dead_grads)
     broadcast_parameters([h.encoder_decoder.encoder, h.encoder_decoder.decoder, h.discriminator])
+    h.two_streams = (bool(args.two_streams) if args.two_streams is not None else TWO_STREAMS_DEFAULT) and world == 1
     use_graph = bool(args.graph) if args.graph is not None else GRAPH_DEFAULT
     use_graph = use_graph and world == 1
     if use_graph:
@@ -361,6 +366,7 @@ def main():
         torch.manual_seed(10)
         h2 = Hidden(HiDDenConfiguration(H=S2, W=S2), dev, noise, None, compute_dtype=dtype, grad_sync=sync, keep_dead_discriminator_grads=args.keep_dead_grads)
         broadcast_parameters([h2.encoder_decoder.encoder, h2.encoder_decoder.decoder, h2.discriminator])
+        h2.two_streams = h.two_streams
         if use_graph:
             h2.enable_graph()
         torch.manual_seed(10 + rank)
@@ -421,7 +427,7 @@ def main():
                                    + ("" if args.keep_dead_grads else "; the generator pass through the discriminator computes no (dead) discriminator weight gradients"),
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "ms_per_step_median_events": step_ms[len(step_ms) // 2], "ms_per_step_min_events": step_ms[0], "ms_per_step_max_events": step_ms[-1],
-            "graph": use_graph,
+            "graph": use_graph, "two_streams": bool(h.two_streams),
             "host_enqueue_ms_median": host_ms[len(host_ms) // 2], "host_enqueue_ms_max": host_ms[-1],
             "host_enqueue_ms_median_eager_steps": host_ms_eager[len(host_ms_eager) // 2] if host_ms_eager else None,
             "kernel_events_every": every,

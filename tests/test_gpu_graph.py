@@ -109,3 +109,48 @@ def test_graph_mode_refuses_nothing_silently():
         h.train_on_batch([images, messages])
     assert h._graphs == {}
     assert NL is not None
+
+
+@pytest.mark.parametrize("case", [("Jpeg50", torch.bfloat16, 256, 16), ("Identity", torch.bfloat16, 128, 8), ("JpegSS50", torch.float32, 64, 4),
+                                  ("Crop", torch.bfloat16, 64, 4)])
+def test_two_chain_step_equals_one_stream_bit_for_bit(case):
+    """Hidden.two_streams: the discriminator's passes and encoder -> attack -> decoder as two chains on two streams (hidden.py:54-118 has no
+    dependency between them until the encoder's backward) -- the same launches, so the same bits, eagerly and replayed from a hipGraph; at the
+    benchmark's full size too, where a missing cross-stream dependency would show (the kernels run for hundreds of microseconds)."""
+    from video_watermarking_forgery_detection_amd import noise_layers as NL
+    name, dt, S, B = case
+
+    def noise():
+        if name == "Identity":
+            return NL.Identity()
+        if name == "Crop":
+            class Fixed:
+                def __init__(self):
+                    self.l = NL.Crop()
+                def fwd(self, x):
+                    H, W = x.shape[2], x.shape[3]
+                    return self.l.fwd(x, apex=(H // 8, H // 8 + int(0.75 * H), W // 8, W // 8 + int(0.75 * W)))
+                def bwd(self, c, g):
+                    return self.l.bwd(c, g)
+            return Fixed()
+        kind = "".join(c for c in name if not c.isdigit())
+        return getattr(NL, kind)(int(name[len(kind):]))
+
+    one = _make(S, noise(), dt, keep_dead=False)
+    two = _make(S, noise(), dt, keep_dead=False); two.two_streams = True
+    twog = _make(S, noise(), dt, keep_dead=False).enable_graph(); twog.two_streams = True
+    for i in range(5):
+        images = detgen.uniform((B, 3, S, S), 7300 + i).cuda()
+        messages = detgen.bits((B, 30), 7400 + i).cuda()
+        l1, o1 = one.train_on_batch([images, messages])
+        for h in (two, twog):
+            l2, o2 = h.train_on_batch([images, messages])
+            for k in l1:
+                assert l1[k] == l2[k], (i, k, l1[k], l2[k])
+            assert all(torch.equal(a, b) for a, b in zip(o1, o2)), i
+    s1 = _state(one)
+    for h in (two, twog):
+        s2 = _state(h)
+        for k in s1:
+            assert torch.equal(s1[k], s2[k]), k
+    assert next(iter(twog._graphs.values())).graph is not None

@@ -107,11 +107,24 @@ __global__ __launch_bounds__(256, 1) void bwd_ws_kernel(BwdArgs a) {
 
     // ---- filter -> LDS, laid out for the 16x16x32 consumers of conv3x3_ws.hip (a lane ends with 16 adjacent channels of its pixel)
     {
+        // (in two batches of 9 loads in flight: a `load, wait, store` loop runs its 18 trips one L2 round trip after the other)
         constexpr int NV = 9 * C * 8;
-        for (int i = tid; i < NV; i += 256) {
-            const int row = i >> 3, tap = row / C, n = row % C;
-            const int lrow = tap * C + ((n >> 2) & 3) * 16 + 4 * (n >> 4) + (n & 3);
-            *reinterpret_cast<hx8*>(sW + lrow * C + swzw(lrow, i & 7) * 8) = *reinterpret_cast<const hx8*>(a.wpt + (size_t)row * C + (i & 7) * 8);
+        static_assert(NV == 18 * 256, "18 vectors per thread");
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            hx8 wv[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int i = tid + 256 * (9 * half + k);
+                wv[k] = *reinterpret_cast<const hx8*>(a.wpt + (size_t)(i >> 3) * C + (i & 7) * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int i = tid + 256 * (9 * half + k);
+                const int row = i >> 3, tap = row / C, n = row % C;
+                const int lrow = tap * C + ((n >> 2) & 3) * 16 + 4 * (n >> 4) + (n & 3);
+                *reinterpret_cast<hx8*>(sW + lrow * C + swzw(lrow, i & 7) * 8) = wv[k];
+            }
         }
     }
     // ---- run of tiles (XCD-aware: workgroups b and b+8 share an L2, give each XCD consecutive runs)

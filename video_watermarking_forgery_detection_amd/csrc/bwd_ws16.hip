@@ -81,9 +81,20 @@ __global__ __launch_bounds__(256, 2) void bwd_ws16_kernel(Bwd16Args a) {
         for (int i = 0; i < 8; ++i) sK[tid * 8 + (tid >> 3) * 4 + i] = v[i];   // (8-channel blocks shifted by 16 B: bwd_ws.hip's bank spread)
     }
     // ---- filter -> LDS: row = tap * 16 + image channel, 64 dy channels = 8 sixteen-byte slots, slot XORed with swzw(row)
-    for (int i = tid; i < 9 * CX * 8; i += 256) {
-        const int row = i >> 3;
-        *reinterpret_cast<hx8*>(sW + row * C + swzw(row, i & 7) * 8) = *reinterpret_cast<const hx8*>(a.wpt + (size_t)row * C + (i & 7) * 8);
+    // (all loads in flight, then the stores: a `load, wait, store` loop runs its trips one L2 round trip after the other)
+    {
+        constexpr int NV = 9 * CX * 8, WV = (NV + 255) / 256;
+        hx8 wv[WV];
+#pragma unroll
+        for (int k = 0; k < WV; ++k) {
+            const int i = min(tid + 256 * k, NV - 1);
+            wv[k] = *reinterpret_cast<const hx8*>(a.wpt + (size_t)(i >> 3) * C + (i & 7) * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < WV; ++k) {
+            const int i = tid + 256 * k, row = i >> 3;
+            if (i < NV) *reinterpret_cast<hx8*>(sW + row * C + swzw(row, i & 7) * 8) = wv[k];
+        }
     }
     const int G = gridDim.x;
     const int run = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;   // XCD-aware: consecutive runs per XCD

@@ -53,6 +53,7 @@ struct Bwd8Args {
     float* stat;                                           // [gridDim.x][2][64]
     float* ws;                                             // [gridDim.x][9][64][64]
     int B, H, W, tilesX, tilesY, ntiles, reverse;
+    int tq, trem;                                          // ntiles / gridDim.x, ntiles % gridDim.x
     unsigned mX, mY, m2X;
     int stamps;                                            // debug build: per-wave phase cycle sums instead of the partial rows
 };
@@ -93,22 +94,42 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
 #ifdef WM_DEBUG
     long long tacc[4] = {0, 0, 0, 0}, tprev = a.stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;   // [3]: everything outside the tile loop
 #endif
+    // ---- prologue (round 4): EVERY global load of the prologue is issued before anything waits -- the constants (wave 0), the filter
+    // (9 vectors per thread; round 3's loop `load, wait, write` ran its 9 trips one L2 round trip after the other: ~4 us of every launch)
+    // and, further down, the role's first tile; the LDS commits follow in issue order (vmcnt retires in order), one barrier for all
+    float cst[9];
     if (tid < C) {
-        sTab[tid] = a.in_scale[tid]; sTab[C + tid] = a.in_shift[tid];
-        float k2, k3;
-        wm_bn_fold(a.stats4[2 * a.st_ld + tid], a.stats4[3 * a.st_ld + tid], a.coef[tid], a.coef[a.st_ld + tid], a.coef[2 * a.st_ld + tid], k2, k3);
-        const float v[8] = {a.stats4[tid], a.stats4[a.st_ld + tid], a.coef[tid], k2, k3, a.in_scale[tid], a.in_shift[tid], 0.f};
+        cst[0] = a.stats4[tid]; cst[1] = a.stats4[a.st_ld + tid]; cst[2] = a.stats4[2 * a.st_ld + tid]; cst[3] = a.stats4[3 * a.st_ld + tid];
+        cst[4] = a.coef[tid]; cst[5] = a.coef[a.st_ld + tid]; cst[6] = a.coef[2 * a.st_ld + tid];
+        cst[7] = a.in_scale[tid]; cst[8] = a.in_shift[tid];
+    }
+    hx8 wv[9];   // filter rows, permuted for the 16x16x32 consumers when committed (bwd_ws.hip)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sK[tid * 8 + (tid >> 3) * 4 + i] = v[i];
+    for (int k = 0; k < 9; ++k) {
+        const int i = tid + 512 * k;
+        wv[k] = *reinterpret_cast<const hx8*>(a.wpt + (size_t)(i >> 3) * C + (i & 7) * 8);
     }
-    for (int i = tid; i < 9 * C * 8; i += 512) {   // filter -> LDS, rows permuted for the 16x16x32 consumers (bwd_ws.hip)
-        const int row = i >> 3, tap = row / C, n = row % C;
-        const int lrow = tap * C + ((n >> 2) & 3) * 16 + 4 * (n >> 4) + (n & 3);
-        *reinterpret_cast<hx8*>(sW + lrow * C + swzw(lrow, i & 7) * 8) = *reinterpret_cast<const hx8*>(a.wpt + (size_t)row * C + (i & 7) * 8);
-    }
+    auto commit_prologue = [&]() {
+        if (tid < C) {
+            sTab[tid] = cst[7]; sTab[C + tid] = cst[8];
+            float k2, k3;
+            wm_bn_fold(cst[2], cst[3], cst[4], cst[5], cst[6], k2, k3);
+            const float v[8] = {cst[0], cst[1], cst[4], k2, k3, cst[7], cst[8], 0.f};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sK[tid * 8 + (tid >> 3) * 4 + i] = v[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int i = tid + 512 * k;
+            const int row = i >> 3, tap = row / C, n = row % C;
+            const int lrow = tap * C + ((n >> 2) & 3) * 16 + 4 * (n >> 4) + (n & 3);
+            *reinterpret_cast<hx8*>(sW + lrow * C + swzw(lrow, i & 7) * 8) = wv[k];
+        }
+    };
     const int G = gridDim.x;
     const int run = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    const int t_begin = (int)(((long)run * a.ntiles) / G), t_end = (int)(((long)(run + 1) * a.ntiles) / G);
+    // run r takes tiles [r q + min(r, rem), ...): q = ntiles / G, rem = ntiles % G from the host (no 64-bit division in the prologue)
+    const int t_begin = run * a.tq + min(run, a.trem), t_end = t_begin + a.tq + (run < a.trem ? 1 : 0);
     struct TileGeo { int b, ty0, tx0; };
     auto fdiv = [](int t, int d, unsigned m) { return d == 1 ? t : (int)__umulhi((unsigned)t, m); };
     auto geo = [&](int tile) {
@@ -132,15 +153,19 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
     typedef std::integral_constant<bool, true> yes;
     typedef std::integral_constant<bool, false> no;
 
-    __syncthreads();   // the constant table
-    if constexpr (GVEC) {
-        for (int i = tid; i < a.B * C; i += 512) {
-            const int b = i / C, c = i - b * C;
-            const float* kc = sK + c * 8 + (c >> 3) * 4;
-            sG[i] = wm_bn_fold_g(kc[2], a.gvec[(size_t)b * a.gv_ld + c], kc[4]);
+    // after the role's first-tile loads are in flight: commit constants + filter, barrier; GVEC: the per-sample table needs the constants
+    auto finish_prologue = [&]() {
+        commit_prologue();
+        __syncthreads();   // the constant table + the filter
+        if constexpr (GVEC) {
+            for (int i = tid; i < a.B * C; i += 512) {
+                const int b = i / C, c = i - b * C;
+                const float* kc = sK + c * 8 + (c >> 3) * 4;
+                sG[i] = wm_bn_fold_g(kc[2], a.gvec[(size_t)b * a.gv_ld + c], kc[4]);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
+    };
 
     if (wrole) {
         // ============================================================================================================ W role
@@ -196,10 +221,13 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) wacc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        if (t_begin < t_end) {   // first tile: load, transform, publish
+        if (t_begin < t_end) {   // first tile: load ...
             const TileGeo g0 = geo(t_begin);
 #pragma unroll
             for (int k = 0; k < AV; ++k) load_a_slot(g0, k);
+        }
+        finish_prologue();
+        if (t_begin < t_end) {   // ... transform, publish
 #pragma unroll
             for (int pq = 0; pq < 4; ++pq) {
                 a_consts(pq);
@@ -209,7 +237,7 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
 #pragma unroll
             for (int k = 0; k < AV; ++k) a_publish(sBuf, k);
         }
-        __syncthreads();   // filter + first tile visible
+        __syncthreads();   // first tile visible
         if (t_begin + 1 < t_end) {
             const TileGeo g1 = geo(t_begin + 1);
 #pragma unroll
@@ -395,6 +423,9 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
         for (int k = 0; k < XV; ++k) load_dy_slot(g0, k);
         okh = inside_bits(g0);
         if constexpr (GVEC) bpub = g0.b;
+    }
+    finish_prologue();
+    if (t_begin < t_end) {
 #pragma unroll
         for (int pq = 0; pq < 4; ++pq) {
             d_consts(pq);
@@ -404,7 +435,7 @@ __global__ __launch_bounds__(512, 1) void bwd_ws8_kernel(Bwd8Args a) {
 #pragma unroll
         for (int k = 0; k < XV; ++k) d_publish(sBuf, k);
     }
-    __syncthreads();   // filter + first tile visible
+    __syncthreads();   // first tile visible
     if (t_begin + 1 < t_end) {
         const TileGeo g1 = geo(t_begin + 1);
 #pragma unroll
@@ -567,6 +598,7 @@ int WM_HSYM(wm_launch_bwd_ws8)(const void* g, const void* y, const float* stats4
     a.B = B; a.H = H; a.W = W; a.tilesX = W / TW; a.tilesY = H / TH; a.ntiles = B * a.tilesX * a.tilesY;
     auto magic = [](int d) { return d == 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
     a.mX = magic(a.tilesX); a.mY = magic(a.tilesY); a.m2X = magic(2 * a.tilesX);
+    a.tq = a.ntiles / nwg; a.trem = a.ntiles % nwg;
     a.reverse = wm_sweep_dir(reverse);
     // (the unmasked-gradient form is not instantiated: it needs ~15 registers more than a two-waves-per-SIMD kernel has and stays on
     // bwd_ws.hip -- wgrad.hip dispatches.  Both instantiated forms: 250 registers, no scratch.)  An unmasked tensor gradient handed to

@@ -259,7 +259,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs<T> a) {
     }
 }
 
-constexpr int WS_MAX_WGS = 256;  // one persistent workgroup per CU
+#ifndef WM_MAX_WGS
+#define WM_MAX_WGS 256           // (tools/build_variant.sh -DWM_MAX_WGS=128: half-chip grids, the two-chains-side-by-side experiment of round 4)
+#endif
+constexpr int WS_MAX_WGS = WM_MAX_WGS;  // one persistent workgroup per CU
 inline bool is16(int dtype) { return dtype == WM_BF16 || dtype == WM_F16; }   // the two 16-bit activation dtypes share every MFMA kernel
 inline bool use_ws(int Cin, int CoutP, int dtype) {
     static const bool off = WM_ENV_FLAG("WM_NO_WS");  // diagnostic knob (debug build): force the generic kernel

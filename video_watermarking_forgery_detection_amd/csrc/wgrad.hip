@@ -372,9 +372,12 @@ static int launch_wgrad_reduce(float* ws, int nslabs, int CinP, int CoutP, float
 // wide layers run (input blocks x output blocks) workgroups per slab: fewer slabs fill the chip as well, and the slab traffic (9 x CinP x
 // CoutP floats each, written once and read once by the reduction) shrinks with them -- 151 MB per 128 x 128 layer at 256 slabs
 inline int nslabs_ch(int B, int H, int W, int CinX, int CoutY);
+#ifndef WM_MAX_WGS
+#define WM_MAX_WGS 256           // as conv3x3.hip
+#endif
 inline int nslabs_for(int B, int H, int W) {
     const long n = (long)B * wm_cdiv(H, 16) * wm_cdiv(W, 16);
-    return (int)(n < 256 ? n : 256);
+    return (int)(n < WM_MAX_WGS ? n : WM_MAX_WGS);
 }
 
 inline int nslabs_ch(int B, int H, int W, int CinX, int CoutY) {
@@ -522,7 +525,7 @@ extern "C" int wm_conv3x3_bwd_fused_supported_shape(int B, int H, int W, int dty
 }
 extern "C" int wm_conv3x3_bwd_fused_nwg(int B, int H, int W) {
     const long n = (long)B * wm_cdiv(H, 8) * wm_cdiv(W, 16);
-    return (int)(n < 256 ? n : 256);
+    return (int)(n < WM_MAX_WGS ? n : WM_MAX_WGS);
 }
 extern "C" int wm_conv3x3_bwd_fused_gvec_max_batch(void) { return wm_bwd_ws_gvec_max_batch_bf16(); }
 // whole-tile shapes with a premasked tensor gradient or a per-sample gradient (all 13 launches of the step): the role-split 8-wave form
@@ -565,7 +568,7 @@ extern "C" int wm_conv3x3_bwd_fused16_supported(int B, int H, int W, int dtype) 
 }
 extern "C" int wm_conv3x3_bwd_fused16_nwg(int B, int H, int W) {
     const long n = (long)B * (H / 8) * (W / 16);
-    return (int)(n < 512 ? n : 512);   // two workgroups per CU
+    return (int)(n < 2 * WM_MAX_WGS ? n : 2 * WM_MAX_WGS);   // two workgroups per CU
 }
 extern "C" int wm_conv3x3_bwd_fused16(const void* g, const void* y, const float* stats4, const float* coef, const void* wpt, const void* x,
                                       void* dx, float* ws, float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, int dtype,

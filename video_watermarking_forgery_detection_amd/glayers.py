@@ -726,8 +726,17 @@ class CapturedStep:
                 "attribute).  Return such tensors from fn (step.result) or .detach() them; capturing this fn can crash the process inside "
                 "hipStreamEndCapture")
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.result = fn()
+        # (the cyclic collector stays off while the stream captures: a dead cycle it frees may own device memory or another hipGraph, and
+        # releasing those is illegal during a capture -- hidden_models/hidden.py::_StepGraph)
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.result = fn()
+        finally:
+            if gc_was_on:
+                gc.enable()
 
     def replay(self):
         self.graph.replay()

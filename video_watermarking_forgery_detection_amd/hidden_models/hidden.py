@@ -261,9 +261,15 @@ class _StepGraph:
     WARMUP = 2
 
     def __init__(self, hidden):
-        self.h = hidden
+        import weakref
+        self._h = weakref.ref(hidden)   # (no Hidden <-> _StepGraph cycle: a dropped model must die by reference count, taking its hipGraph
+                                        # with it THEN -- not whenever the cyclic collector next runs, which may be inside another capture)
         self.calls = 0
         self.graph = None
+
+    @property
+    def h(self):
+        return self._h()
 
     def _hyper_refresh(self):
         opts = (self.h.optimizer_discrim, self.h.optimizer_enc_dec)
@@ -291,10 +297,19 @@ class _StepGraph:
                 if h.amp is None:
                     o.hyper_dev = self.hyper[2 * i:2 * i + 2]
             graph = torch.cuda.CUDAGraph()
+            # Python's cyclic collector must not run inside the capture: whatever dead cycle it finds may own device memory, events or
+            # another hipGraph, and releasing those calls HIP functions that are illegal while a stream captures (the process aborts --
+            # seen in round 4 with the previous test's model in a cycle).  torch 2.10's graph.__enter__ no longer collects first.
+            import gc
+            gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
             try:
                 with torch.cuda.graph(graph):
                     self.result = h._step_launches(self.img, self.msg)
             finally:
+                if gc_was_on:
+                    gc.enable()
                 for o in opts:
                     o.hyper_dev, o.capturing = None, False
             self.graph = graph
@@ -365,6 +380,8 @@ class Hidden:
         self.noise_id = None  # optional deterministic choice for Combined/Noiser layers
         self.lazy_losses = True  # train_on_batch returns StepLosses (host sync on first read) instead of a plain dict
         self._graphs = None      # enable_graph(): (shapes, attack choice, ...) -> _StepGraph
+        self.two_streams = False  # the step's two independent chains on two streams (_train_step_two_chains); same results bit for bit
+        self._streams = None
 
     def enable_graph(self, on=True):
         """replay the step from a hipGraph instead of enqueueing its ~190 launches every call (same results bit for bit: _StepGraph).
@@ -408,7 +425,7 @@ class Hidden:
         if (self._graphs is not None and extra_encoded_grad is None and clip is None and enc_gate is None and self.grad_sync is None
                 and not ops.kernel_timer_installed() and hasattr(n, "fwd") and hasattr(n, "bwd")
                 and not torch.cuda.is_current_stream_capturing()):
-            key = (tuple(images.shape), tuple(messages.shape), self.noise_id, self.keep_dead_discriminator_grads, self.lazy_losses,
+            key = (tuple(images.shape), tuple(messages.shape), self.noise_id, self.keep_dead_discriminator_grads, self.lazy_losses, self.two_streams,
                    self.encoder_decoder.encoder.compute_dtype)
             g = self._graphs.get(key)
             if g is None:
@@ -452,6 +469,9 @@ class Hidden:
                 n.invalidate_packs()
 
     def _train_step(self, images, messages, B, cfg, ed, enc_net, dec_net, D, gD, gE, gDec, extra_encoded_grad, clip, enc_gate=None):
+        if (self.two_streams and self.grad_sync is None and extra_encoded_grad is None and clip is None and enc_gate is None
+                and hasattr(ed.noiser, "fwd") and hasattr(ed.noiser, "bwd")):
+            return self._train_step_two_chains(images, messages, B, cfg, ed, enc_net, dec_net, D, gD, gE, gDec)
         # ---------------- train the discriminator (hidden.py:68-83)
         d_on_cover, c = D.fwd(images)
         d_loss_on_cover, g = self._bce_logits(d_on_cover, self.cover_label)
@@ -531,6 +551,73 @@ class Hidden:
         vals = ops.hidden_metrics(enc_part, n_img, msg_out, g_loss_adv, d_loss_on_cover, d_loss_on_encoded, cfg.adversarial_loss,
                                   cfg.encoder_loss, cfg.decoder_loss)
         return vals, extra_logs, (encoded, noised, decoded)
+
+    def _train_step_two_chains(self, images, messages, B, cfg, ed, enc_net, dec_net, D, gD, gE, gDec):
+        """The same step, same launches, same arithmetic -- enqueued as the TWO independent chains hidden.py:54-118 consists of until the encoder's
+        backward: the discriminator's passes (stream A) beside encoder -> attack -> decoder forward and the decoder's backward (stream B).
+
+            A: D(cover) fwd/bwd . . . . . . | wait encoded | D(enc.detach()) fwd/bwd, Adam(D), D(enc) fwd, dgrad to the image, + MSE gradient
+            B: encoder fwd | attack fwd, decoder fwd, message loss, decoder bwd, attack bwd
+            join: g_enc += attack gradient; encoder bwd; Adam(enc + dec); the seven scalars
+
+        Why: every persistent kernel spends a fixed part of its launch outside its tile loop (filter -> LDS, first HBM round trip, for the
+        one-pass backward the weight-gradient slabs) and the chip idles through each launch's ramp and tail; a second, independent launch fills
+        those: 24 launches of the forward 64 -> 64 kernel take 1.78 ms from two streams against 1.96 ms from one, of the one-pass backward 4.00
+        against 4.24 (tools/bench_two_chains.py, profiles/r04_two_chains.txt).  Results are bit-identical to the one-stream order: no kernel's
+        inputs or reduction order change, only when it runs."""
+        main = torch.cuda.current_stream()
+        sA, sB = self._chain_streams()
+        dts = {D.compute_dtype, enc_net.compute_dtype}
+        for dt in dts:
+            engine.image_to_act(images, dt)              # converted once, before the fork: both chains read it
+        sA.wait_stream(main); sB.wait_stream(main)
+        with torch.cuda.stream(sA):
+            d_on_cover, c = D.fwd(images)
+            d_loss_on_cover, g = self._bce_logits(d_on_cover, self.cover_label)
+            D.bwd(c, g, gD, accumulate=False, need_input_grad=False)
+        with torch.cuda.stream(sB):
+            encoded, cE = enc_net.fwd(images, messages)
+            for dt in {D.compute_dtype, dec_net.compute_dtype}:
+                engine.image_to_act(encoded, dt)         # (on the producing stream: chain A and -- under an Identity attack -- the decoder read it)
+            ev_enc = torch.cuda.Event()
+            ev_enc.record(sB)
+            noised, cN = self._run_noiser(encoded, images)
+            decoded, cDec = dec_net.fwd(noised)
+            msg_out, g_dec = ops.message_loss(decoded, messages, 2.0 * cfg.decoder_loss / decoded.numel(), gscale_dev=self._gsd())
+            g_dec = g_dec.view_as(decoded)
+            g_noised = dec_net.bwd(cDec, g_dec, gDec, accumulate=False, need_input_grad=True)
+            g_from_noise = _noise_bwd(ed.noiser, cN, g_noised).contiguous()
+        with torch.cuda.stream(sA):
+            sA.wait_event(ev_enc)
+            d_on_encoded, c = D.fwd(encoded)
+            d_loss_on_encoded, g = self._bce_logits(d_on_encoded, self.encoded_label)
+            D.bwd(c, g, gD, accumulate=True, need_input_grad=False)
+            self.optimizer_discrim.step(grad_scale=1.0)
+            D.refresh_packs()
+            d_on_encoded_for_enc, c = D.fwd(encoded)
+            g_loss_adv, g = self._bce_logits(d_on_encoded_for_enc, self.cover_label, cfg.adversarial_loss)
+            g_enc = D.bwd(c, g, gD, accumulate=True, need_input_grad=True, weight_grads=self.keep_dead_discriminator_grads)
+            n_img = encoded.numel()
+            enc_part, g_mse = ops.mse_fwd_bwd(encoded, images, 2.0 * cfg.encoder_loss / n_img, gscale_dev=self._gsd())
+            ops.axpy_(g_enc, g_mse)
+        main.wait_stream(sA); main.wait_stream(sB)
+        ops.axpy_(g_enc, g_from_noise)
+        enc_net.bwd(cE, g_enc, gE, accumulate=False)
+        self.optimizer_enc_dec.step(grad_scale=1.0)
+        if self.amp is not None and self.amp_owner:
+            self.amp.update()
+        vals = ops.hidden_metrics(enc_part, n_img, msg_out, g_loss_adv, d_loss_on_cover, d_loss_on_encoded, cfg.adversarial_loss,
+                                  cfg.encoder_loss, cfg.decoder_loss)
+        # Memory: the caching allocator hands a freed block back to the pool of the stream that allocated it.  Every tensor one stream
+        # allocates and ANOTHER reads (encoded and its NHWC form, g_enc, g_from_noise, the encoder's activations in cE, the loss scalars) is
+        # referenced until this function returns, and a side stream is given work only between a fork (wait_stream(main)) and the join
+        # above -- so a block that returns to a side stream's pool is not handed out again before main's readers of it are ordered ahead
+        return vals, [], (encoded, noised, decoded)
+
+    def _chain_streams(self):
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+        return self._streams
 
     def validate_on_batch(self, batch: list):
         """hidden.py:120-182: eval-mode BatchNorm (running statistics), no parameter update."""
