@@ -232,6 +232,24 @@ def timed_steps(h, batch, steps, warmup, barrier, world, dev, timer=None, every=
     return dt
 
 
+def zero_attack(args):
+    """does the configured attack pass back an identically zero gradient (Jpeg: torch.round)?"""
+    return args.noise.startswith("Jpeg") and not args.noise.startswith(("JpegSS", "JpegMask"))
+
+
+def step_gflop_per_frame(args, S, reference_state=False):
+    """GFLOP per frame AS EXECUTED.  The reference autograd's step is 249.0 GFLOP per 256x256 frame; not executed, hence not
+    counted, unless --keep-dead-grads / reference_state: (1) the generator pass's three discriminator weight-gradient GEMMs, whose results
+    nothing reads (2 x 4.832 + 0.226); (2) under an attack with an identically zero gradient (Jpeg), the decoder's gradient wrt its
+    input image (the 3 <- 64 input-gradient GEMM of its first layer, 0.226), whose result is multiplied by zero"""
+    g = 249.0
+    if not (reference_state or args.keep_dead_grads):
+        g -= 2 * 4.8318 + 0.2265
+        if zero_attack(args):
+            g -= 0.2265
+    return g * (S / 256.0) ** 2
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) without a launcher: start N fresh ranks with torch.distributed.run as a CHILD process --
     this parent has not touched the GPU (no HIP call, no torch.cuda.is_available()) and never replaces itself -- and pass the
@@ -287,6 +305,7 @@ def main():
     cfg = HiDDenConfiguration(H=S, W=S)
     sync = GradSync(profile=True) if world > 1 else None
     h = Hidden(cfg, dev, noise, None, compute_dtype=dtype, grad_sync=sync, keep_dead_discriminator_grads=args.keep_dead_grads)
+    h.skip_zero_attack_gradient = not args.keep_dead_grads
     broadcast_parameters([h.encoder_decoder.encoder, h.encoder_decoder.decoder, h.discriminator])
     h.two_streams = (bool(args.two_streams) if args.two_streams is not None else TWO_STREAMS_DEFAULT) and world == 1
     use_graph = bool(args.graph) if args.graph is not None else GRAPH_DEFAULT
@@ -353,11 +372,13 @@ def main():
     if not args.no_extra and not args.keep_dead_grads and S == 256:
         # (1) the reference's exact .grad state: g_loss.backward() (hidden.py:101) also leaves its gradients in the discriminator's parameters
         h.keep_dead_discriminator_grads = True
+        h.skip_zero_attack_gradient = False
         dte = timed_steps(h, [images, messages], args.extra_steps, 5, barrier, world, dev)
         h.keep_dead_discriminator_grads = False
+        h.skip_zero_attack_gradient = True
         gf = 249.0
         extra["reference_state"] = {
-            "workload": f"the same step with the discriminator's dead weight gradients of the generator pass computed (the reference's .grad state, hidden.py:67,101), {S}x{S}, batch {B}/GPU",
+            "workload": f"the same step with EVERY launch of the reference's autograd: the discriminator's dead weight gradients of the generator pass (the reference's .grad state, hidden.py:67,101) and the decoder's input gradient under Jpeg's zero-gradient rounding, {S}x{S}, batch {B}/GPU",
             "steps": args.extra_steps, "warmup": 5, "ms_per_step": 1e3 * dte / args.extra_steps, "value": world * B * args.extra_steps / dte, "unit": "frames/s",
             "step_gflop_per_frame": gf, "step_flops_frac_of_peak": gf * 1e9 * B * args.extra_steps / dte / (peak_tf * 1e12)}
     if not args.no_extra and S == 256 and dtype == torch.bfloat16:
@@ -365,6 +386,7 @@ def main():
         S2, B2 = 512, 8
         torch.manual_seed(10)
         h2 = Hidden(HiDDenConfiguration(H=S2, W=S2), dev, noise, None, compute_dtype=dtype, grad_sync=sync, keep_dead_discriminator_grads=args.keep_dead_grads)
+        h2.skip_zero_attack_gradient = not args.keep_dead_grads
         broadcast_parameters([h2.encoder_decoder.encoder, h2.encoder_decoder.decoder, h2.discriminator])
         h2.two_streams = h.two_streams
         if use_graph:
@@ -375,7 +397,7 @@ def main():
         timer2 = ops.KernelTimer(lambda name, i: name == "conv3x3_bwd_fused" and not i["gvec"])
         dt2 = timed_steps(h2, [im2, ms2], args.extra_steps, 5, barrier, world, dev, timer2, every)
         d2 = timer2.elapsed_ms("conv3x3_bwd_fused")
-        gf2 = (249.0 if args.keep_dead_grads else 249.0 - 2 * 4.8318 - 0.2265) * 4.0
+        gf2 = step_gflop_per_frame(args, S2)
         c4 = {"workload": f"C4's per-GPU shard: the headline step at {S2}x{S2}, batch {B2}/GPU", "steps": args.extra_steps, "warmup": 5,
               "ms_per_step": 1e3 * dt2 / args.extra_steps, "value": world * B2 * args.extra_steps / dt2, "unit": "frames/s",
               "step_gflop_per_frame": gf2, "step_flops_frac_of_peak": gf2 * 1e9 * B2 * args.extra_steps / dt2 / (peak_tf * 1e12)}
@@ -404,7 +426,7 @@ def main():
                 "flops_per_launch": flops_per_launch, "hbm_algorithmic_bytes_per_launch": 2.0 * tensor_bytes}
         # FLOPs per frame as executed: the reference autograd's 249.0 GFLOP at 256x256 minus, unless --keep-dead-grads, the
         # two 64->64 and the 3->64 discriminator weight-gradient GEMMs of the generator pass (2 x 4.832 + 0.226 GFLOP)
-        step_gflop = (249.0 if args.keep_dead_grads else 249.0 - 2 * 4.8318 - 0.2265) * (S / 256.0) ** 2
+        step_gflop = step_gflop_per_frame(args, S)
         if dms:   # bf16: the one-pass backward kernel is the dominant one; 288 FLOP/B sits just under the ridge: HBM-bound
             davg = sum(dms) / len(dms)
             dbytes = 4.0 * tensor_bytes   # reads g, y, y of the layer below; writes dx
@@ -424,7 +446,9 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"C2: HiDDeN GAN step enc(4x64)->{args.noise}->dec(7x64)+disc(3x64), L=30, {S}x{S}, batch {B}/GPU"
-                                   + ("" if args.keep_dead_grads else "; the generator pass through the discriminator computes no (dead) discriminator weight gradients"),
+                                   + ("" if args.keep_dead_grads else "; not launched (results identical): the generator pass's dead discriminator weight gradients"
+                                      + (", the decoder's input gradient that Jpeg's zero-gradient rounding multiplies by 0" if zero_attack(args) else "")
+                                      + " -- reference_state times the step with them"),
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "ms_per_step_median_events": step_ms[len(step_ms) // 2], "ms_per_step_min_events": step_ms[0], "ms_per_step_max_events": step_ms[-1],
             "graph": use_graph, "two_streams": bool(h.two_streams),

@@ -137,8 +137,10 @@ def test_two_chain_step_equals_one_stream_bit_for_bit(case):
         return getattr(NL, kind)(int(name[len(kind):]))
 
     one = _make(S, noise(), dt, keep_dead=False)
+    one.skip_zero_attack_gradient = False            # the plain order with everything launched, as the reference's autograd runs it
     two = _make(S, noise(), dt, keep_dead=False); two.two_streams = True
     twog = _make(S, noise(), dt, keep_dead=False).enable_graph(); twog.two_streams = True
+    assert two.skip_zero_attack_gradient             # (default: Jpeg50's zero gradient is not computed, and the encoder's backward joins chain A)
     for i in range(5):
         images = detgen.uniform((B, 3, S, S), 7300 + i).cuda()
         messages = detgen.bits((B, 30), 7400 + i).cuda()
@@ -152,5 +154,36 @@ def test_two_chain_step_equals_one_stream_bit_for_bit(case):
     for h in (two, twog):
         s2 = _state(h)
         for k in s1:
-            assert torch.equal(s1[k], s2[k]), k
+            assert torch.equal(s1[k], s2[k]), k          # parameters, BatchNorm buffers, EVERY .grad buffer, Adam moments and step counts
     assert next(iter(twog._graphs.values())).graph is not None
+
+
+def test_zero_attack_gradient_shortcut_leaves_no_trace():
+    """Hidden.skip_zero_attack_gradient on the one-stream path: Jpeg(Q)'s torch.round passes back zeros (reference noise_layers/jpeg.py:226-240),
+    so the decoder's gradient wrt its input, the attack's backward and the addition of its zeros are not launched -- and nothing differs:
+    losses, outputs, parameters, all three networks' .grad buffers, optimiser state.  JpegSS (a real gradient) is never short-cut."""
+    from video_watermarking_forgery_detection_amd import noise_layers as NL, ops
+    S, B = 64, 4
+    for layer, zero in ((NL.Jpeg(50), True), (NL.JpegSS(50), False), (NL.Combined([NL.JpegSS(50), NL.Jpeg(70)]), True)):
+        full = _make(S, layer, torch.bfloat16); full.skip_zero_attack_gradient = False
+        short = _make(S, layer, torch.bfloat16)
+        full.noise_id = short.noise_id = 1
+        calls = {"n": 0}
+        orig = ops.jpeg_bwd
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return orig(*a, **k)
+        for i in range(3):
+            images = detgen.uniform((B, 3, S, S), 7500 + i).cuda(); messages = detgen.bits((B, 30), 7600 + i).cuda()
+            lf, of = full.train_on_batch([images, messages])
+            ops.jpeg_bwd = counting
+            try:
+                ls, os_ = short.train_on_batch([images, messages])
+            finally:
+                ops.jpeg_bwd = orig
+            assert all(lf[k] == ls[k] for k in lf) and all(torch.equal(a, b) for a, b in zip(of, os_))
+        assert (calls["n"] == 0) == zero, (type(layer).__name__, calls)
+        sf, ss = _state(full), _state(short)
+        for k in sf:
+            assert torch.equal(sf[k], ss[k]), k

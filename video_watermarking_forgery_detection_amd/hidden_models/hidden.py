@@ -231,6 +231,13 @@ def _noise_bwd(noiser, ctx, g):
     return gx if gx is not None else torch.zeros_like(g)
 
 
+def _noise_bwd_is_zero(noiser, ctx):
+    """does the attack layer declare the gradient of THIS forward call identically zero (noise_layers.Jpeg: torch.round)?"""
+    kind, c = ctx
+    f = getattr(noiser, "bwd_is_zero", None)
+    return bool(kind == "explicit" and f is not None and f(c))
+
+
 def _accepts_id(fn):
     """does fn(image, id=...) exist?  Looked up from the signature (cached per function), never by catching TypeError around
     the call -- that would hide a TypeError raised inside the attack and run it twice."""
@@ -380,6 +387,12 @@ class Hidden:
         self.noise_id = None  # optional deterministic choice for Combined/Noiser layers
         self.lazy_losses = True  # train_on_batch returns StepLosses (host sync on first read) instead of a plain dict
         self._graphs = None      # enable_graph(): (shapes, attack choice, ...) -> _StepGraph
+        # An attack whose backward is identically zero (Jpeg: torch.round) makes the decoder's gradient wrt its input a value nothing depends
+        # on: with this switch on (default) the step does not compute it (the decoder's first layer runs its weight gradient alone, the
+        # attack's backward and the addition of its zeros are not launched).  Unlike keep_dead_discriminator_grads this leaves NO trace: every
+        # loss, output, parameter, .grad and optimiser state is bit-identical either way (tests/test_gpu_configs.py); False = launch it all,
+        # as the reference's autograd does
+        self.skip_zero_attack_gradient = True
         self.two_streams = False  # the step's two independent chains on two streams (_train_step_two_chains); same results bit for bit
         self._streams = None
 
@@ -425,7 +438,7 @@ class Hidden:
         if (self._graphs is not None and extra_encoded_grad is None and clip is None and enc_gate is None and self.grad_sync is None
                 and not ops.kernel_timer_installed() and hasattr(n, "fwd") and hasattr(n, "bwd")
                 and not torch.cuda.is_current_stream_capturing()):
-            key = (tuple(images.shape), tuple(messages.shape), self.noise_id, self.keep_dead_discriminator_grads, self.lazy_losses, self.two_streams,
+            key = (tuple(images.shape), tuple(messages.shape), self.noise_id, self.keep_dead_discriminator_grads, self.lazy_losses, self.two_streams, self.skip_zero_attack_gradient,
                    self.encoder_decoder.encoder.compute_dtype)
             g = self._graphs.get(key)
             if g is None:
@@ -516,11 +529,13 @@ class Hidden:
         ops.axpy_(g_enc, g_mse)
         msg_out, g_dec = ops.message_loss(decoded, messages, 2.0 * cfg.decoder_loss / decoded.numel(), gscale_dev=self._gsd())   # mse, bit error, grad
         g_dec = g_dec.view_as(decoded)
-        g_noised = dec_net.bwd(cDec, g_dec, gDec, accumulate=False, need_input_grad=True)
+        zero_attack = self.skip_zero_attack_gradient and _noise_bwd_is_zero(ed.noiser, cN)
+        g_noised = dec_net.bwd(cDec, g_dec, gDec, accumulate=False, need_input_grad=not zero_attack)
         # data parallel: the decoder's bucket goes out now and travels while the attack and the encoder run their backward
         pending = [gs.start(dec_net.flat_grads)] if gs is not None else []
-        g_from_noise = _noise_bwd(ed.noiser, cN, g_noised)
-        ops.axpy_(g_enc, g_from_noise.contiguous())
+        if not zero_attack:
+            g_from_noise = _noise_bwd(ed.noiser, cN, g_noised)
+            ops.axpy_(g_enc, g_from_noise.contiguous())
         extra_logs = []
         if extra_encoded_grad is not None:
             extra_logs = extra_encoded_grad(encoded, images, g_enc)
@@ -559,6 +574,8 @@ class Hidden:
             A: D(cover) fwd/bwd . . . . . . | wait encoded | D(enc.detach()) fwd/bwd, Adam(D), D(enc) fwd, dgrad to the image, + MSE gradient
             B: encoder fwd | attack fwd, decoder fwd, message loss, decoder bwd, attack bwd
             join: g_enc += attack gradient; encoder bwd; Adam(enc + dec); the seven scalars
+        (an attack that passes back zeros -- Jpeg's torch.round, skip_zero_attack_gradient -- leaves chain B without a successor in the
+        encoder: the encoder's backward then runs on chain A right behind the discriminator's, beside the decoder's backward)
 
         Why: every persistent kernel spends a fixed part of its launch outside its tile loop (filter -> LDS, first HBM round trip, for the
         one-pass backward the weight-gradient slabs) and the chip idles through each launch's ramp and tail; a second, independent launch fills
@@ -585,8 +602,9 @@ class Hidden:
             decoded, cDec = dec_net.fwd(noised)
             msg_out, g_dec = ops.message_loss(decoded, messages, 2.0 * cfg.decoder_loss / decoded.numel(), gscale_dev=self._gsd())
             g_dec = g_dec.view_as(decoded)
-            g_noised = dec_net.bwd(cDec, g_dec, gDec, accumulate=False, need_input_grad=True)
-            g_from_noise = _noise_bwd(ed.noiser, cN, g_noised).contiguous()
+            zero_attack = self.skip_zero_attack_gradient and _noise_bwd_is_zero(ed.noiser, cN)
+            g_noised = dec_net.bwd(cDec, g_dec, gDec, accumulate=False, need_input_grad=not zero_attack)
+            g_from_noise = None if zero_attack else _noise_bwd(ed.noiser, cN, g_noised).contiguous()
         with torch.cuda.stream(sA):
             sA.wait_event(ev_enc)
             d_on_encoded, c = D.fwd(encoded)
@@ -600,9 +618,14 @@ class Hidden:
             n_img = encoded.numel()
             enc_part, g_mse = ops.mse_fwd_bwd(encoded, images, 2.0 * cfg.encoder_loss / n_img, gscale_dev=self._gsd())
             ops.axpy_(g_enc, g_mse)
+            if zero_attack:
+                # nothing of chain B reaches the encoder's gradient (the attack passes back zeros): the encoder's backward continues chain A,
+                # beside the decoder's backward on chain B, and the chains meet only at the optimiser step
+                enc_net.bwd(cE, g_enc, gE, accumulate=False)
         main.wait_stream(sA); main.wait_stream(sB)
-        ops.axpy_(g_enc, g_from_noise)
-        enc_net.bwd(cE, g_enc, gE, accumulate=False)
+        if not zero_attack:
+            ops.axpy_(g_enc, g_from_noise)
+            enc_net.bwd(cE, g_enc, gE, accumulate=False)
         self.optimizer_enc_dec.step(grad_scale=1.0)
         if self.amp is not None and self.amp_owner:
             self.amp.update()

@@ -65,6 +65,12 @@ class JpegBasic(nn.Module):
     def bwd(self, ctx, g):
         return ops.jpeg_bwd(ctx, g, self._mode, self._tables, self.subsample)
 
+    def bwd_is_zero(self, ctx):
+        """is the gradient this layer passes back identically zero?  Jpeg: yes -- torch.round has zero gradient (jpeg.py:226-240 of the
+        reference: autograd multiplies by 0 at every coefficient), so bwd() returns zeros whatever g is.  A training step may then skip
+        producing g (the decoder's gradient wrt its input) and the addition of this layer's zeros (hidden_models/hidden.py)"""
+        return self._mode == ops.JPEG_ROUND
+
 
 class Jpeg(JpegBasic):
     """torch.round quantisation: zero gradient, like the reference."""

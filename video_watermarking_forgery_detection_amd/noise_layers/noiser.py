@@ -37,3 +37,7 @@ class Noiser(nn.Module):
     def bwd(self, ctx, g):
         sel, c = ctx
         return sel.bwd(c, g)
+
+    def bwd_is_zero(self, ctx):
+        sel, c = ctx
+        return bool(getattr(sel, "bwd_is_zero", lambda _c: False)(c))
