@@ -174,8 +174,8 @@ def kernel_sources_sha():
 
 
 PMC_FILE = "r03_pmc_traffic.json"
-GRAPH_DEFAULT = False   # bench.py --graph / --no-graph overrides
-TWO_STREAMS_DEFAULT = False   # --two-streams / --one-stream
+GRAPH_DEFAULT = True          # --graph / --no-graph: the step replayed from a hipGraph (one GPU; N > 1 runs eagerly around the all-reduces)
+TWO_STREAMS_DEFAULT = True    # --two-streams / --one-stream: the step's two independent chains on two streams
 _pmc = {}
 
 
@@ -219,12 +219,16 @@ def timed_steps(h, batch, steps, warmup, barrier, world, dev, timer=None, every=
         h.train_on_batch(batch)
     barrier()
     t0 = time.perf_counter()
+    ts = h.two_streams
     for i in range(steps):
-        ops.set_kernel_timer(timer if (timer is not None and i % every == 0) else None)
+        bracket = timer is not None and i % every == 0
+        ops.set_kernel_timer(timer if bracket else None)
+        h.two_streams = ts and not bracket      # (a bracketed step runs its kernels one after the other: see the headline loop)
         h.train_on_batch(batch)
     barrier()
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
+    h.two_streams = ts
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -307,7 +311,8 @@ def main():
     h = Hidden(cfg, dev, noise, None, compute_dtype=dtype, grad_sync=sync, keep_dead_discriminator_grads=args.keep_dead_grads)
     h.skip_zero_attack_gradient = not args.keep_dead_grads
     broadcast_parameters([h.encoder_decoder.encoder, h.encoder_decoder.decoder, h.discriminator])
-    h.two_streams = (bool(args.two_streams) if args.two_streams is not None else TWO_STREAMS_DEFAULT) and world == 1
+    two_streams = (bool(args.two_streams) if args.two_streams is not None else TWO_STREAMS_DEFAULT) and world == 1
+    h.two_streams = two_streams
     use_graph = bool(args.graph) if args.graph is not None else GRAPH_DEFAULT
     use_graph = use_graph and world == 1
     if use_graph:
@@ -340,6 +345,9 @@ def main():
         # either side of every bracketed launch (the event's marker packet) and none around the launches that are not bracketed -- so the
         # roofline kernels are bracketed on every `every`-th timed step, all their launches of that step.
         ops.set_kernel_timer(timer if i % every == 0 else None)
+        # a bracketed step runs its launches ONE AFTER THE OTHER (one stream, eagerly): beside a launch of the other chain a kernel's event
+        # pair would time the sharing of the chip, not the kernel (178 us instead of 149 for the dominant one)
+        h.two_streams = two_streams and i % every != 0
         if sync is not None:
             sync.profile = i % every == 0    # (the same for the events around the gradient all-reduces' waits)
         marks[i].record()
@@ -353,6 +361,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
+    h.two_streams = two_streams
     sync_rep = sync.report((args.steps + every - 1) // every) if sync is not None else None
     if sync_rep is not None:   # every rank: its buckets and how long its compute stream stood waiting for them (the exposed part of the all-reduces)
         sys.stderr.write(f"[bench rank {rank}] grad sync: {json.dumps(sync_rep)}\n")
@@ -388,7 +397,7 @@ def main():
         h2 = Hidden(HiDDenConfiguration(H=S2, W=S2), dev, noise, None, compute_dtype=dtype, grad_sync=sync, keep_dead_discriminator_grads=args.keep_dead_grads)
         h2.skip_zero_attack_gradient = not args.keep_dead_grads
         broadcast_parameters([h2.encoder_decoder.encoder, h2.encoder_decoder.decoder, h2.discriminator])
-        h2.two_streams = h.two_streams
+        h2.two_streams = two_streams
         if use_graph:
             h2.enable_graph()
         torch.manual_seed(10 + rank)
@@ -451,7 +460,8 @@ def main():
                                       + " -- reference_state times the step with them"),
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "ms_per_step_median_events": step_ms[len(step_ms) // 2], "ms_per_step_min_events": step_ms[0], "ms_per_step_max_events": step_ms[-1],
-            "graph": use_graph, "two_streams": bool(h.two_streams),
+            "graph": use_graph, "two_streams": bool(two_streams),
+            "kernel_events_note": "the steps whose kernels are bracketed with events run on one stream, eagerly (every kernel alone on the chip): avg_launch_ms is the kernel's own duration; the other steps run as two chains" + (" replayed from a hipGraph" if use_graph else "") if two_streams or use_graph else None,
             "host_enqueue_ms_median": host_ms[len(host_ms) // 2], "host_enqueue_ms_max": host_ms[-1],
             "host_enqueue_ms_median_eager_steps": host_ms_eager[len(host_ms_eager) // 2] if host_ms_eager else None,
             "kernel_events_every": every,

@@ -389,9 +389,10 @@ class Hidden:
         self._graphs = None      # enable_graph(): (shapes, attack choice, ...) -> _StepGraph
         # An attack whose backward is identically zero (Jpeg: torch.round) makes the decoder's gradient wrt its input a value nothing depends
         # on: with this switch on (default) the step does not compute it (the decoder's first layer runs its weight gradient alone, the
-        # attack's backward and the addition of its zeros are not launched).  Unlike keep_dead_discriminator_grads this leaves NO trace: every
-        # loss, output, parameter, .grad and optimiser state is bit-identical either way (tests/test_gpu_configs.py); False = launch it all,
-        # as the reference's autograd does
+        # attack's backward and the addition of its zeros are not launched).  Every loss and output is bit-identical either way, and so is
+        # every parameter, .grad and optimiser state except ONE tensor's rounding: the decoder's first-layer weight gradient is then summed
+        # by the weight-gradient-only kernel instead of the one-pass kernel -- the same sum in another order (tests/test_gpu_graph.py).
+        # False = launch it all, as the reference's autograd does
         self.skip_zero_attack_gradient = True
         self.two_streams = False  # the step's two independent chains on two streams (_train_step_two_chains); same results bit for bit
         self._streams = None
