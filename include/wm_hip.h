@@ -67,6 +67,10 @@ typedef struct WmBnBwdFin {
 #define WM_JPEG_MASK 2
 int wm_jpeg_fwd(const float* x, float* y, int B, int H, int W, int mode, const float* tables,
                 int subsample, void* stream);
+/* ... and, act16 non-NULL, the attacked image a second time as [B][H][W][16] pixels of dtype act_dtype (channels 0..2, zero tail): the
+ * input of the decoder's image-fed first layer (hidden_models/decoder.py:15), without wm_nchw_to_nhwc's launch. */
+int wm_jpeg_fwd_act(const float* x, float* y, void* act16, int act_dtype, int B, int H, int W, int mode, const float* tables,
+                    int subsample, void* stream);
 /* gx = d(sum(gy*y))/dx.  x is read only for mode 1 (derivative of round_ss needs the
  * pre-rounding coefficient); mode 0 writes zeros (torch.round has zero gradient). */
 int wm_jpeg_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int mode,
@@ -356,6 +360,12 @@ int wm_pool_stats_enabled(void);
 int wm_conv1x1_head_fwd(const void* y, int ldy, const float* scale, const float* shift, const float* w,
                         const float* bias, float* out, int B, size_t hw, int Cin, int Cout, int act,
                         int dtype, void* stream);
+/* ... and, act16 non-NULL (act == 0): the result a second time as [B][HW][16] pixels of the activation dtype (channels 0..Cout-1, zero
+ * tail) -- the tensor the image-fed first layers of the decoder / discriminator read (hidden_models/decoder.py:15, discriminator.py:12),
+ * which wm_nchw_to_nhwc would otherwise make from `out` in a launch of its own. */
+int wm_conv1x1_head_fwd_act(const void* y, int ldy, const float* scale, const float* shift, const float* w,
+                            const float* bias, float* out, void* act16, int B, size_t hw, int Cin, int Cout, int act,
+                            int dtype, void* stream);
 /* backward: gout f32 NCHW [B,Cout,H,W] (for act=1 the caller passes the gradient wrt the
  * pre-sigmoid logits) -> g NHWC dtype [B,H,W,Cin] (gradient wrt the ReLU output), and
  * partial sums for dw[Cout,Cin], dbias[Cout]: partials f32[nparts][Cout*(Cin+1)].
@@ -414,6 +424,12 @@ int wm_upconv2x2_wgrad_mfma(const void* x, int ldx, const float* scale, const fl
  * scalar multiplied into gscale -- the loss scale of mixed-precision training (wm_amp_*), which lives on the device. */
 int wm_mse_fwd_bwd(const float* a, const float* b, float* grad_a, float gscale, const float* gscale_dev, float* loss_partials,
                    int nparts, size_t n, void* stream);
+/* hidden.py:85-101 at the encoded image, one pass: out [B][C][HW] f32 = (f32)g[b][q][c0 + c] + gscale * (a - b), with g the NHWC input
+ * gradient of the discriminator's first layer (dtype, pixel stride ld; C <= 4 real channels from c0), a = encoded, b = cover (f32 NCHW);
+ * loss_partials [nparts] = partial sums of (a - b)^2 over the blocks (wm_hidden_metrics adds them).  Same values as wm_nhwc_to_nchw +
+ * wm_mse_fwd_bwd + wm_axpy(1.0). */
+int wm_image_grad_mse(const void* g, int ld, int c0, const float* a, const float* b, float* out, float gscale, const float* gscale_dev,
+                      float* loss_partials, int nparts, int B, int C, int H, int W, int dtype, void* stream);
 /* y = a + s*b (f32), used to combine image-space gradients. */
 int wm_axpy(float* a, const float* b, float s, size_t n, void* stream);
 /* Adam / AdamW step over one flat f32 parameter buffer (torch.optim.Adam semantics,

@@ -1,0 +1,55 @@
+"""Round 4: three launches of layout glue folded into their producers / consumers, each checked BIT FOR BIT against the launches it replaces:
+  * the encoder's 1x1 head (reference hidden_models/encoder.py:28,42) and the block-JPEG attack (noise_layers/jpeg.py:226-306) also write
+    the 16-channel NHWC form of their result (the input of the next network's image-fed first layer) = wm_nchw_to_nhwc of that result;
+  * wm_image_grad_mse = wm_nhwc_to_nchw (the discriminator's input gradient) + wm_mse_fwd_bwd + wm_axpy (hidden.py:85-101)."""
+import pytest
+import torch
+
+import detgen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+def test_head_fwd_writes_the_next_layers_input(dt):
+    from video_watermarking_forgery_detection_amd import ops
+    B, H, W, C = 3, 24, 40, 64
+    y = detgen.normal((B, H, W, C), 81).to(dt).cuda()
+    scale = detgen.normal((C,), 82, mean=1.0, std=0.3).cuda(); shift = detgen.normal((C,), 83, std=0.3).cuda()
+    w = detgen.normal((3, C), 84, std=0.2).cuda(); bias = detgen.normal((3,), 85, std=0.1).cuda()
+    out0 = ops.conv1x1_head_fwd(y, scale, shift, w, bias)
+    out1, a16 = ops.conv1x1_head_fwd(y, scale, shift, w, bias, want_act16=True)
+    ref = torch.full((B, H, W, 16), 7.0, device="cuda", dtype=dt)
+    ops.nchw_to_nhwc(out0, ref, 0, 13)
+    assert torch.equal(out0, out1) and a16.dtype == dt and torch.equal(a16, ref)
+
+
+@pytest.mark.parametrize("case", [(0, 50, 0, torch.bfloat16, 64, 64), (1, 70, 2, torch.float16, 32, 48), (2, 90, 0, torch.float32, 30, 43)])
+def test_jpeg_fwd_writes_the_decoders_input(case):
+    from video_watermarking_forgery_detection_amd import noise_layers as NL, ops
+    mode, Q, sub, dt, H, W = case
+    layer = (NL.Jpeg, NL.JpegSS, NL.JpegMask)[mode](Q, subsample=sub)
+    x = detgen.uniform((2, 3, H, W), 91).cuda()
+    y0 = ops.jpeg_fwd(x, layer._mode, layer._tables, layer.subsample)
+    y1, a16 = ops.jpeg_fwd(x, layer._mode, layer._tables, layer.subsample, act16_dtype=dt)
+    ref = torch.full((2, H, W, 16), 7.0, device="cuda", dtype=dt)
+    ops.nchw_to_nhwc(y0, ref, 0, 13)
+    assert torch.equal(y0, y1) and torch.equal(a16, ref)
+
+
+@pytest.mark.parametrize("case", [(torch.bfloat16, 32, 0.7e-5), (torch.float16, 16, 1.0), (torch.float32, 16, 3e-3)])
+def test_image_grad_mse_equals_the_three_launches(case):
+    from video_watermarking_forgery_detection_amd import ops
+    dt, ld, gs = case
+    B, H, W = 4, 40, 56
+    g = detgen.normal((B, H, W, ld), 71, std=1e-3).to(dt).cuda()
+    a = detgen.uniform((B, 3, H, W), 72).cuda(); b = detgen.uniform((B, 3, H, W), 73).cuda()
+    scale_dev = torch.tensor([128.0], device="cuda")
+    for dev in (None, scale_dev):
+        ref = ops.nhwc_to_nchw(g, 3, 0)
+        part0, gm = ops.mse_fwd_bwd(a, b, gs, gscale_dev=dev)
+        ops.axpy_(ref, gm)
+        out, part1 = ops.image_grad_mse(g, a, b, gs, gscale_dev=dev)
+        assert torch.equal(out, ref)
+        assert abs(part0.double().sum().item() - part1.double().sum().item()) <= 1e-6 * part0.double().sum().item()
+        assert abs(part1.double().sum().item() - ((a - b).double() ** 2).sum().item()) <= 1e-6 * part0.double().sum().item()

@@ -12,7 +12,7 @@ template <typename T, int COUT>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, size_t npix,
-                                                       size_t hw, int Cin, int act) {
+                                                       size_t hw, int Cin, int act, T* __restrict__ act16) {
     constexpr int VE = vec16<T>::N;
     const int VPP = Cin / VE, PPB = 256 / VPP;
     const int vv = threadIdx.x % VPP, ps = threadIdx.x / VPP;
@@ -60,6 +60,22 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, 
                 if (act == 1) v = 1.f / (1.f + __expf(-v));
                 const size_t b = p / hw, q = p - b * hw;
                 out[(b * COUT + vv) * hw + q] = v;
+            }
+            // act16 (round 4): the same pixel once more as the 16-channel NHWC pixel the image-fed first layers read (channels 0..COUT-1,
+            // zero tail) -- what wm_nchw_to_nhwc would make of `out` in a launch of its own; every lane of the pixel's group holds all sums
+            if (act16 && valid[u] && vv == 0) {
+#pragma unroll
+                for (int k = 0; k < 16 / VE; ++k) {
+                    vec16<T> o;
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) {
+                        float val = 0.f;
+#pragma unroll
+                        for (int co = 0; co < COUT; ++co) val = (k * VE + e == co) ? part[co] + bias[co] : val;
+                        o.set(e, val);
+                    }
+                    *reinterpret_cast<vec16<T>*>(act16 + p * 16 + k * VE) = o;
+                }
             }
         }
     }
@@ -171,7 +187,14 @@ inline int head_parts(size_t npix) {
 extern "C" int wm_conv1x1_head_fwd(const void* y, int ldy, const float* scale, const float* shift, const float* w,
                                    const float* bias, float* out, int B, size_t hw, int Cin, int Cout, int act, int dtype,
                                    void* stream) {
+    return wm_conv1x1_head_fwd_act(y, ldy, scale, shift, w, bias, out, nullptr, B, hw, Cin, Cout, act, dtype, stream);
+}
+
+extern "C" int wm_conv1x1_head_fwd_act(const void* y, int ldy, const float* scale, const float* shift, const float* w,
+                                       const float* bias, float* out, void* act16, int B, size_t hw, int Cin, int Cout, int act, int dtype,
+                                       void* stream) {
     WM_REQUIRE(y && w && bias && out, WM_E_BADARG, "wm_conv1x1_head_fwd: null pointer");
+    WM_REQUIRE(!act16 || (act == 0 && ((uintptr_t)act16 & 15) == 0), WM_E_BADARG, "wm_conv1x1_head_fwd_act: act16 goes with act == 0 and a 16-byte aligned pointer");
     WM_REQUIRE((scale == nullptr) == (shift == nullptr), WM_E_BADARG, "wm_conv1x1_head_fwd: scale/shift must come together");
     WM_REQUIRE(cin_ok(Cin, dtype), WM_E_SHAPE, "wm_conv1x1_head_fwd: unsupported Cin=%d", Cin);
     WM_REQUIRE(Cout == 1 || Cout == 3, WM_E_SHAPE, "wm_conv1x1_head_fwd: Cout must be 1 or 3 (got %d)", Cout);
@@ -179,8 +202,8 @@ extern "C" int wm_conv1x1_head_fwd(const void* y, int ldy, const float* scale, c
     const int grid = (int)((npix + 127) / 128 > 2048 ? 2048 : (npix + 127) / 128);
     hipStream_t s = (hipStream_t)stream;
     WM_DISPATCH_DTYPE(dtype, "wm_conv1x1_head_fwd",
-        if (Cout == 3) hipLaunchKernelGGL((head_fwd_kernel<T, 3>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, scale, shift, w, bias, out, npix, hw, Cin, act);
-        else hipLaunchKernelGGL((head_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, scale, shift, w, bias, out, npix, hw, Cin, act));
+        if (Cout == 3) hipLaunchKernelGGL((head_fwd_kernel<T, 3>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, scale, shift, w, bias, out, npix, hw, Cin, act, (T*)act16);
+        else hipLaunchKernelGGL((head_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, scale, shift, w, bias, out, npix, hw, Cin, act, (T*)act16));
     WM_LAUNCH_CHECK("wm_conv1x1_head_fwd");
     return WM_OK;
 }

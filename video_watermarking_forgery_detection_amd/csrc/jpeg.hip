@@ -233,9 +233,36 @@ __device__ __forceinline__ void load_tables(const JpegTables& tb, float* s_tbl) 
     __syncthreads();
 }
 
+// act16 (round 4): the attacked image a second time as [B][H][W][16] pixels of the activation dtype (channels 0..2, zero tail): the tensor
+// the decoder's image-fed first layer reads, which wm_nchw_to_nhwc would otherwise make from y in a launch of its own.  A lane holds 8
+// adjacent pixels of one row: 8 x 32 (16-bit) or 8 x 64 (f32) contiguous bytes
+template <typename T>
+__device__ __forceinline__ void store_act16_t(T* __restrict__ a, const Task& t, int H, int W, const float (&v)[3][8]) {
+    if (!(t.valid && t.y < H)) return;
+    constexpr int VE = vec16<T>::N;
+    T* p = a + (((size_t)t.b * H + t.y) * W + t.x0) * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (t.x0 + j < W) {
+#pragma unroll
+            for (int k = 0; k < 16 / VE; ++k) {
+                vec16<T> o;
+#pragma unroll
+                for (int e = 0; e < VE; ++e) o.set(e, (k == 0 && e < 3) ? v[e][j] : 0.f);
+                *reinterpret_cast<vec16<T>*>(p + j * 16 + k * VE) = o;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void store_act16(void* a, int dtype, const Task& t, int H, int W, const float (&v)[3][8]) {
+    if (dtype == WM_BF16) store_act16_t(reinterpret_cast<bf16_t*>(a), t, H, W, v);
+    else if (dtype == WM_F16) store_act16_t(reinterpret_cast<f16_t*>(a), t, H, W, v);
+    else store_act16_t(reinterpret_cast<float*>(a), t, H, W, v);
+}
+
 template <int MODE, int SUB>
 __global__ __launch_bounds__(256) void jpeg_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                        int B, int H, int W, JpegTables tb) {
+                                                        int B, int H, int W, JpegTables tb, void* __restrict__ act16, int act_dtype) {
     __shared__ __attribute__((aligned(16))) float s_lds[4 * LDS_WAVE];
     __shared__ float s_tbl[128];
     if (MODE != WM_JPEG_MASK) load_tables(tb, s_tbl);
@@ -277,6 +304,7 @@ __global__ __launch_bounds__(256) void jpeg_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[c][j] = v[c][j] / 255.f;
     store_rows(y, t, H, W, v);
+    if (act16) store_act16(act16, act_dtype, t, H, W, v);
 }
 
 template <int MODE, int SUB>
@@ -621,13 +649,20 @@ inline unsigned jpeg_grid(int B, int H, int W) {
 
 extern "C" int wm_jpeg_fwd(const float* x, float* y, int B, int H, int W, int mode, const float* tables,
                            int subsample, void* stream) {
+    return wm_jpeg_fwd_act(x, y, nullptr, WM_F32, B, H, W, mode, tables, subsample, stream);
+}
+
+extern "C" int wm_jpeg_fwd_act(const float* x, float* y, void* act16, int act_dtype, int B, int H, int W, int mode, const float* tables,
+                               int subsample, void* stream) {
     int rc = check_args("wm_jpeg_fwd", x, y, B, H, W, mode, tables, subsample);
     if (rc) return rc;
+    WM_REQUIRE(!act16 || (((uintptr_t)act16 & 15) == 0 && (act_dtype == WM_F32 || act_dtype == WM_BF16 || act_dtype == WM_F16)), WM_E_BADARG,
+               "wm_jpeg_fwd_act: act16 must be 16-byte aligned, its dtype f32 / bf16 / f16");
     JpegTables tb;
     for (int i = 0; i < 128; ++i) tb.t[i] = tables ? tables[i] : 1.f;
     const dim3 grid(jpeg_grid(B, H, W)), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define L(M, S) hipLaunchKernelGGL((jpeg_fwd_kernel<M, S>), grid, block, 0, s, x, y, B, H, W, tb)
+#define L(M, S) hipLaunchKernelGGL((jpeg_fwd_kernel<M, S>), grid, block, 0, s, x, y, B, H, W, tb, act16, act_dtype)
     if (subsample == 0) {
         if (mode == 0) L(0, 0); else if (mode == 1) L(1, 0); else L(2, 0);
     } else {

@@ -25,6 +25,36 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, c
     if (threadIdx.x == 0 && partials) partials[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
+// The gradient wrt the encoded image at the point where hidden.py:85-101's three terms meet, in ONE pass (round 4; it was three launches:
+// the NHWC -> NCHW conversion of the discriminator's input gradient, wm_mse_fwd_bwd and wm_axpy):
+//   out[b][c][q] = float(g[b][q][c0 + c]) + gscale * (a - b),   partials[block] = sum (a - b)^2
+// g: the NHWC input gradient the discriminator's first layer wrote (16-bit or f32, pixel stride ld); a = encoded, b = cover: f32 NCHW planes.
+// The two roundings of the separate kernels are kept (product, then sum: no contraction into an fma), so the values are the same.
+template <typename T>
+__global__ __launch_bounds__(256) void image_grad_mse_kernel(const T* __restrict__ g, int ld, int c0, const float* __restrict__ a,
+                                                            const float* __restrict__ b, float* __restrict__ out, float gscale,
+                                                            const float* __restrict__ gscale_dev, float* __restrict__ partials, int B,
+                                                            int C, size_t hw) {
+    if (gscale_dev) gscale *= gscale_dev[0];
+    float acc = 0.f;
+    const size_t total = (size_t)B * hw;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t bi = p / hw, q = p - bi * hw;
+        const T* gp = g + p * ld + c0;
+        for (int c = 0; c < C; ++c) {
+            const size_t i = (bi * C + c) * hw + q;
+            const float d = a[i] - b[i];
+            acc += d * d;
+            out[i] = __fadd_rn(to_f32(gp[c]), __fmul_rn(gscale, d));
+        }
+    }
+    acc = wave_sum(acc);
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
 // nn.BCEWithLogitsLoss (mean) of a small logit vector against a constant label, value and gradient in one launch
 // (hidden_models/hidden.py:68-97: three of them per step on [B,1] tensors)
 __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ x, float target, int n, float gscale,
@@ -202,6 +232,18 @@ extern "C" int wm_mse_fwd_bwd(const float* a, const float* b, float* grad_a, flo
     WM_REQUIRE(nparts > 0 && nparts <= 2048, WM_E_BADARG, "wm_mse_fwd_bwd: nparts must be in 1..2048");
     hipLaunchKernelGGL(mse_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, a, b, grad_a, gscale, loss_partials, n, gscale_dev);
     WM_LAUNCH_CHECK("wm_mse_fwd_bwd");
+    return WM_OK;
+}
+
+extern "C" int wm_image_grad_mse(const void* g, int ld, int c0, const float* a, const float* b, float* out, float gscale, const float* gscale_dev,
+                                 float* loss_partials, int nparts, int B, int C, int H, int W, int dtype, void* stream) {
+    WM_REQUIRE(g && a && b && out && loss_partials, WM_E_BADARG, "wm_image_grad_mse: null pointer");
+    WM_REQUIRE(B > 0 && C > 0 && C <= 4 && H > 0 && W > 0 && c0 >= 0 && ld >= c0 + C && nparts > 0 && nparts <= 2048, WM_E_BADARG, "wm_image_grad_mse: bad shape");
+    const size_t hw = (size_t)H * W;
+    hipStream_t s = (hipStream_t)stream;
+    WM_DISPATCH_DTYPE(dtype, "wm_image_grad_mse",
+        hipLaunchKernelGGL((image_grad_mse_kernel<T>), dim3(nparts), dim3(256), 0, s, (const T*)g, ld, c0, a, b, out, gscale, gscale_dev, loss_partials, B, C, hw));
+    WM_LAUNCH_CHECK("wm_image_grad_mse");
     return WM_OK;
 }
 

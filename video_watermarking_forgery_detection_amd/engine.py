@@ -50,18 +50,21 @@ _tls = threading.local()   # per host thread: .image_acts = id(image) -> (image,
 
 
 @contextlib.contextmanager
-def share_image_acts():
+def share_image_acts(dtype=None):
     """inside the block, image_to_act converts an image tensor once: a training step feeds `images` to the discriminator and the
     encoder and `encoded` to two discriminator passes (the images are not modified in between -- checked through their
-    version counters)"""
+    version counters).  dtype: the networks' activation dtype, for producers that can write the NHWC16 form themselves
+    (wanted_image_act_dtype)"""
     if getattr(_tls, "image_acts", None) is not None:
         yield
         return
     _tls.image_acts = {}
+    _tls.image_act_dtype = dtype
     try:
         yield
     finally:
         _tls.image_acts = None
+        _tls.image_act_dtype = None
 
 
 def image_to_act(img, dtype):
@@ -78,6 +81,24 @@ def image_to_act(img, dtype):
     if cache is not None:
         cache[id(img)] = (img, img._version, dtype, t)
     return Act(t, 3)
+
+
+def register_image_act(img, t):
+    """inside a share_image_acts() block: `t` [B,H,W,16] IS image_to_act(img, t.dtype) already (written by the kernel that produced img:
+    the encoder's head, the block-JPEG attack), so the first layer that reads img launches no conversion"""
+    cache = getattr(_tls, "image_acts", None)
+    if cache is not None and t is not None:
+        cache[id(img)] = (img, img._version, t.dtype, t)
+
+
+def sharing_image_acts():
+    return getattr(_tls, "image_acts", None) is not None
+
+
+def wanted_image_act_dtype():
+    """inside a training step (share_image_acts(dtype)): the activation dtype of the networks that will read an image this step produces --
+    a kernel that writes such an image may write its NHWC16 form beside it (register_image_act); None outside a step"""
+    return getattr(_tls, "image_act_dtype", None) if sharing_image_acts() else None
 
 
 class CBRCtx:

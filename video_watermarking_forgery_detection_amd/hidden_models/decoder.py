@@ -37,9 +37,10 @@ def head_bwd(mod, ctx, I, g_out, grads, accumulate):
                                accumulate, CP, 1.0 / ctx.HW)
 
 
-def stack_bwd(blocks, ctx, gvec, grads, accumulate, need_input_grad, weight_grads=True):
+def stack_bwd(blocks, ctx, gvec, grads, accumulate, need_input_grad, weight_grads=True, raw_input_grad=False):
     """gvec [B,CP] f32 (gradient wrt the pooled features / (H*W), zero padded) -> gradient wrt the image [B,3,H,W] or None
-    (weight_grads False: engine.cbr_backward's input-gradient-only form)"""
+    (weight_grads False: engine.cbr_backward's input-gradient-only form; raw_input_grad: the first layer's NHWC input gradient as its
+    kernel wrote it -- channels 0..2 are the image's -- for a consumer that converts it on the way, ops.image_grad_mse)"""
     g = None
     n = len(blocks)
     for i in range(n - 1, -1, -1):
@@ -49,7 +50,7 @@ def stack_bwd(blocks, ctx, gvec, grads, accumulate, need_input_grad, weight_grad
                                 pool_stats=ctx.pool_stats if i == n - 1 else None, weight_grads=weight_grads)
     if not need_input_grad:
         return None
-    return ops.nhwc_to_nchw(g, 3, 0)
+    return g if raw_input_grad else ops.nhwc_to_nchw(g, 3, 0)
 
 
 def bump_bn_counters(mod):

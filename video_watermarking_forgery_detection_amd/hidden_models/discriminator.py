@@ -35,11 +35,11 @@ class Discriminator(nn.Module, engine.FlatModule):
             engine.bump_bn_counters(self)
         return out, ctx
 
-    def bwd(self, ctx, g_out, grads, accumulate=False, need_input_grad=False, weight_grads=True):
+    def bwd(self, ctx, g_out, grads, accumulate=False, need_input_grad=False, weight_grads=True, raw_input_grad=False):
         """weight_grads False (with need_input_grad): the gradient wrt the image only -- the convolutions' weight gradients are not
         computed (the generator's pass through the discriminator, hidden.py:85-103: nothing reads them)"""
         gvec = head_bwd(self, ctx, self.channels, g_out, grads, accumulate)
-        return stack_bwd(self._blocks(), ctx, gvec, grads, accumulate, need_input_grad, weight_grads=weight_grads)
+        return stack_bwd(self._blocks(), ctx, gvec, grads, accumulate, need_input_grad, weight_grads=weight_grads, raw_input_grad=raw_input_grad)
 
     def forward(self, image):
         if not image.is_cuda:

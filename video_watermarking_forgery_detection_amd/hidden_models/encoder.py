@@ -83,7 +83,13 @@ class Encoder(nn.Module, engine.FlatModule):
                                                  perm=self._perm, training=training)
         ctx.final_in = a5
         fl = self.final_layer
-        enc = ops.conv1x1_head_fwd(a5.t, a5.scale, a5.shift, fl.weight.data.view(3, c), fl.bias.data, act=0)
+        if training and engine.sharing_image_acts():
+            # inside a training step the encoded image is read by the discriminator (twice) and, under an Identity attack, the decoder:
+            # the head writes their 16-channel NHWC input beside the NCHW result
+            enc, a16 = ops.conv1x1_head_fwd(a5.t, a5.scale, a5.shift, fl.weight.data.view(3, c), fl.bias.data, act=0, want_act16=True)
+            engine.register_image_act(enc, a16)
+        else:
+            enc = ops.conv1x1_head_fwd(a5.t, a5.scale, a5.shift, fl.weight.data.view(3, c), fl.bias.data, act=0)
         if training:
             engine.bump_bn_counters(self)
         return enc, ctx

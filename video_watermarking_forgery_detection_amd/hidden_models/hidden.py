@@ -476,7 +476,7 @@ class Hidden:
         try:
             for n in nets:
                 n.refresh_packs()
-            with engine.defer_bn_counters(), engine.share_image_acts():
+            with engine.defer_bn_counters(), engine.share_image_acts(dec_net.compute_dtype):
                 return self._train_step(images, messages, B, cfg, ed, enc_net, dec_net, D, gD, gE, gDec, extra_encoded_grad, clip, enc_gate)
         finally:
             for n in nets:
@@ -519,15 +519,17 @@ class Hidden:
         g_loss_adv, g = self._bce_logits(d_on_encoded_for_enc, self.cover_label, cfg.adversarial_loss)
         # the reference's g_loss.backward() also accumulates into the discriminator's .grad (zeroed at the start of the next step, never
         # read): kept by default so the .grad state matches; keep_dead_discriminator_grads=False computes the image gradient alone
-        g_enc = D.bwd(c, g, gD, accumulate=True, need_input_grad=True, weight_grads=self.keep_dead_discriminator_grads)
-
         n_img = encoded.numel()
         gate = enc_gate(encoded, images) if enc_gate is not None else None
         if gate is None:
-            enc_part, g_mse = ops.mse_fwd_bwd(encoded, images, 2.0 * cfg.encoder_loss / n_img, gscale_dev=self._gsd())
+            # the adversarial term's gradient (NHWC, as the discriminator's first layer wrote it) + the image-fidelity term's, and that
+            # term's loss, in one pass
+            g_img = D.bwd(c, g, gD, accumulate=True, need_input_grad=True, weight_grads=self.keep_dead_discriminator_grads, raw_input_grad=True)
+            g_enc, enc_part = ops.image_grad_mse(g_img, encoded, images, 2.0 * cfg.encoder_loss / n_img, gscale_dev=self._gsd())
         else:
+            g_enc = D.bwd(c, g, gD, accumulate=True, need_input_grad=True, weight_grads=self.keep_dead_discriminator_grads)
             enc_part, g_mse = ops.mse_fwd_bwd_gated(encoded, images, 2.0 * cfg.encoder_loss / n_img, gate[1:2], gscale_dev=self._gsd())
-        ops.axpy_(g_enc, g_mse)
+            ops.axpy_(g_enc, g_mse)
         msg_out, g_dec = ops.message_loss(decoded, messages, 2.0 * cfg.decoder_loss / decoded.numel(), gscale_dev=self._gsd())   # mse, bit error, grad
         g_dec = g_dec.view_as(decoded)
         zero_attack = self.skip_zero_attack_gradient and _noise_bwd_is_zero(ed.noiser, cN)
@@ -615,10 +617,9 @@ class Hidden:
             D.refresh_packs()
             d_on_encoded_for_enc, c = D.fwd(encoded)
             g_loss_adv, g = self._bce_logits(d_on_encoded_for_enc, self.cover_label, cfg.adversarial_loss)
-            g_enc = D.bwd(c, g, gD, accumulate=True, need_input_grad=True, weight_grads=self.keep_dead_discriminator_grads)
+            g_img = D.bwd(c, g, gD, accumulate=True, need_input_grad=True, weight_grads=self.keep_dead_discriminator_grads, raw_input_grad=True)
             n_img = encoded.numel()
-            enc_part, g_mse = ops.mse_fwd_bwd(encoded, images, 2.0 * cfg.encoder_loss / n_img, gscale_dev=self._gsd())
-            ops.axpy_(g_enc, g_mse)
+            g_enc, enc_part = ops.image_grad_mse(g_img, encoded, images, 2.0 * cfg.encoder_loss / n_img, gscale_dev=self._gsd())
             if zero_attack:
                 # nothing of chain B reaches the encoder's gradient (the attack passes back zeros): the encoder's backward continues chain A,
                 # beside the decoder's backward on chain B, and the chains meet only at the optimiser step

@@ -59,8 +59,15 @@ class JpegBasic(nn.Module):
 
     # explicit (autograd-free) interface used by the training step
     def fwd(self, image):
+        from .. import engine
         x = image.contiguous()
-        return ops.jpeg_fwd(x, self._mode, self._tables, self.subsample), (x if self._mode == ops.JPEG_SS else None)
+        dt = engine.wanted_image_act_dtype()
+        if dt is not None:   # inside a training step: the decoder's NHWC16 input written by this kernel too (no conversion launch)
+            y, a16 = ops.jpeg_fwd(x, self._mode, self._tables, self.subsample, act16_dtype=dt)
+            engine.register_image_act(y, a16)
+        else:
+            y = ops.jpeg_fwd(x, self._mode, self._tables, self.subsample)
+        return y, (x if self._mode == ops.JPEG_SS else None)
 
     def bwd(self, ctx, g):
         return ops.jpeg_bwd(ctx, g, self._mode, self._tables, self.subsample)

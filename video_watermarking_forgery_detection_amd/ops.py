@@ -61,18 +61,20 @@ def _host_floats(vals):
 
 
 # ----------------------------------------------------------------------------- block JPEG
-def jpeg_fwd(x, mode, tables, subsample=0):
-    """x [B,3,H,W] f32 cuda; tables: 128 python floats (lum, chroma) or None for mask."""
+def jpeg_fwd(x, mode, tables, subsample=0, act16_dtype=None):
+    """x [B,3,H,W] f32 cuda; tables: 128 python floats (lum, chroma) or None for mask.  act16_dtype: -> (y, the same image as the
+    [B,H,W,16] zero-padded NHWC tensor of that dtype: engine.image_to_act's result without its launch)"""
     _need_cuda(x)
     assert x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.float32
     x = x.contiguous()
     y = torch.empty_like(x)
     B, _, H, W = x.shape
+    a16 = torch.empty(B, H, W, 16, device=x.device, dtype=act16_dtype) if act16_dtype is not None else None
     tb = _host_floats(tables) if tables is not None else None
-    rc = _timed("jpeg_fwd", None, lambda: _lib.lib().wm_jpeg_fwd(_p(x), _p(y), c_int(B), c_int(H), c_int(W), c_int(mode), tb, c_int(subsample),
-                                                                 _stream()))
+    rc = _timed("jpeg_fwd", None, lambda: _lib.lib().wm_jpeg_fwd_act(_p(x), _p(y), _p(a16), c_int(dt_id(act16_dtype) if a16 is not None else WM_F32),
+                                                                     c_int(B), c_int(H), c_int(W), c_int(mode), tb, c_int(subsample), _stream()))
     _lib.check(rc, "wm_jpeg_fwd")
-    return y
+    return (y, a16) if act16_dtype is not None else y
 
 
 def jpeg_bwd(x, gy, mode, tables, subsample=0):
@@ -721,15 +723,17 @@ def bnrelu_avgpool(y, scale, shift):
     return out
 
 
-def conv1x1_head_fwd(y, scale, shift, w, bias, act=0):
-    """y [B,H,W,Cin]; w [Cout,Cin(,1,1)] f32; -> out [B,Cout,H,W] f32"""
+def conv1x1_head_fwd(y, scale, shift, w, bias, act=0, want_act16=False):
+    """y [B,H,W,Cin]; w [Cout,Cin(,1,1)] f32; -> out [B,Cout,H,W] f32; want_act16: -> (out, the same image as the [B,H,W,16] zero-padded
+    NHWC tensor of y's dtype that the image-fed first layers read: engine.image_to_act's result without its launch)"""
     B, H, W, Cin = y.shape
     Cout = w.shape[0]
     out = torch.empty(B, Cout, H, W, device=y.device, dtype=torch.float32)
-    rc = _lib.lib().wm_conv1x1_head_fwd(_p(y), c_int(Cin), _p(scale), _p(shift), _p(w), _p(bias), _p(out), c_int(B),
-                                        c_size_t(H * W), c_int(Cin), c_int(Cout), c_int(act), c_int(dtype_id(y)), _stream())
+    a16 = torch.empty(B, H, W, 16, device=y.device, dtype=y.dtype) if want_act16 else None
+    rc = _lib.lib().wm_conv1x1_head_fwd_act(_p(y), c_int(Cin), _p(scale), _p(shift), _p(w), _p(bias), _p(out), _p(a16), c_int(B),
+                                            c_size_t(H * W), c_int(Cin), c_int(Cout), c_int(act), c_int(dtype_id(y)), _stream())
     _lib.check(rc, "wm_conv1x1_head_fwd")
-    return out
+    return (out, a16) if want_act16 else out
 
 
 def conv1x1_head_bwd(y, scale, shift, w, gout, dw, dbias, accumulate, want_bn_partials=False):
@@ -766,6 +770,23 @@ def mse_fwd_bwd(a, b, gscale, want_grad=True, gscale_dev=None):
     rc = _lib.lib().wm_mse_fwd_bwd(_p(a), _p(b), _p(grad), c_float(gscale), _p(gscale_dev), _p(part), c_int(nparts), c_size_t(n), _stream())
     _lib.check(rc, "wm_mse_fwd_bwd")
     return part, grad
+
+
+def image_grad_mse(g, a, b, gscale, C=3, C_off=0, gscale_dev=None):
+    """(out [B,C,H,W] f32 = nhwc_to_nchw(g)[:, :C] + gscale * (a - b), partials of sum (a - b)^2): the discriminator's input gradient, the
+    image-fidelity term's gradient and its loss in one pass (nhwc_to_nchw + mse_fwd_bwd + axpy_ before)"""
+    _need_cuda(g, a, b)
+    B, H, W, ld = g.shape
+    assert a.shape == (B, C, H, W) and b.shape == a.shape and a.dtype == torch.float32 and b.dtype == torch.float32 and g.is_contiguous()
+    a = a.contiguous(); b = b.contiguous()
+    n = a.numel()
+    nparts = max(1, min(1024, (n + 4095) // 4096))
+    out = torch.empty_like(a)
+    part = torch.empty(nparts, device=a.device, dtype=torch.float32)
+    rc = _lib.lib().wm_image_grad_mse(_p(g), c_int(ld), c_int(C_off), _p(a), _p(b), _p(out), c_float(gscale), _p(gscale_dev), _p(part), c_int(nparts),
+                                      c_int(B), c_int(C), c_int(H), c_int(W), c_int(dtype_id(g)), _stream())
+    _lib.check(rc, "wm_image_grad_mse")
+    return out, part
 
 
 def axpy_(a, b, s=1.0):
