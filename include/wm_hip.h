@@ -455,6 +455,17 @@ int wm_linear_head_fwd(const float* pooled, int ldp, const float* w, const float
                        void* stream);
 int wm_linear_head_bwd(const float* pooled, int ldp, const float* w, const float* g_out, float* dw, float* db,
                        int accumulate, float* gvec, int CP, float inv_hw, int B, int I, int O, void* stream);
+/* The four small launches a pooled head runs in a row -- wm_linear_head_fwd, the loss (kind 0: wm_bce_logits against the constant label
+ * `target`; kind 1: wm_message_loss against messages [B][O]), wm_linear_head_bwd and wm_bn_bwd_finalize_pooled of the pooled ConvBNRelu --
+ * as ONE launch of one workgroup, each stage with the arithmetic (and operation order) of the kernel it replaces.
+ * out3 [3][B][CP] = wm_bnrelu_avgpool_stats' result (pooled mean, N+, S+); logits [B][O]; loss_out [1] (kind 0) / [2] (kind 1: MSE, bitwise
+ * error); dw [O][I], db [O] (+)=; gvec [B][CP]; C, count, gamma, mean, invstd, dgamma, dbeta, coef [3][CP] as wm_bn_bwd_finalize_pooled.
+ * wm_pooled_head_supported: the sizes one workgroup's LDS holds (B*CP <= 2048, O*I <= 4096, B*O <= 1024). */
+int wm_pooled_head_supported(int B, int CP, int I, int O);
+int wm_pooled_head(const float* out3, int B, int CP, int I, int O, const float* w, const float* bias, int kind, float target,
+                   const float* messages, float gscale, const float* gscale_dev, float* logits, float* loss_out, float* dw, float* db,
+                   int accumulate, float* gvec, float inv_hw, int C, double count, const float* gamma, const float* mean,
+                   const float* invstd, float* dgamma, float* dbeta, float* coef, void* stream);
 /* nn.BCEWithLogitsLoss (mean) of n logits against a constant label (hidden_models/hidden.py:68-97): *loss_out = the
  * loss, grad_out[n] (may be NULL) = gscale * d loss / d logits.  One small launch. */
 int wm_bce_logits(const float* logits, float target, int n, float gscale, const float* gscale_dev, float* loss_out, float* grad_out,

@@ -268,7 +268,130 @@ __global__ __launch_bounds__(256) void linear_head_bwd_kernel(const float* __res
         gvec[idx] = acc * inv_hw;
     }
 }
+
+// ------------------------------------------------------------------ the whole pooled head in ONE launch (round 4)
+// After the global average pool a discriminator / decoder pass ran four tiny launches in a row, each waiting for the one before
+// (nn.Linear forward, the loss, nn.Linear backward, the pooled layer's BatchNorm-backward finalisation; hidden.py:68-101 over
+// discriminator.py:24-26 / decoder.py:32-34): ~7 us of latency each on the step's critical chain for a few thousand flops.  One workgroup
+// does them back to back through the LDS, each stage with the arithmetic of the kernel it replaces (same operation order: bit-identical
+// results; tests/test_gpu_fused_glue.py):
+//   logits = pooled @ w^T + bias                          (linear_head_fwd_kernel)
+//   kind 0: BCE-with-logits against `target`, grad = (sigmoid - target) gscale / n          (bce_logits_kernel)
+//   kind 1: message MSE + bitwise error against messages, grad = (logits - messages) gscale  (message_loss_kernel)
+//   dw, db (+)=, gvec = (grad @ w) inv_hw                  (linear_head_bwd_kernel)
+//   dgamma, dbeta (+)=, coef of the pooled ConvBNRelu from (gvec, N+, S+)                    (bn_bwd_finalize_kernel, pooled rows)
+constexpr int PH_MAX_BC = 2048, PH_MAX_OI = 4096, PH_MAX_BO = 1024;
+__global__ __launch_bounds__(256) void pooled_head_kernel(const float* __restrict__ out3, int B, int CP, int I, int O,
+                                                          const float* __restrict__ w, const float* __restrict__ bias, int kind, float target,
+                                                          const float* __restrict__ messages, float gscale, const float* __restrict__ gscale_dev,
+                                                          float* __restrict__ logits, float* __restrict__ loss_out, float* __restrict__ dw,
+                                                          float* __restrict__ db, int accumulate, float* __restrict__ gvec, float inv_hw, int C,
+                                                          double count, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          float* __restrict__ coef) {
+    __shared__ float s_pool[PH_MAX_BC], s_w[PH_MAX_OI], s_logit[PH_MAX_BO], s_g[PH_MAX_BO], s_gv[PH_MAX_BC];
+    __shared__ float s_red[2][4];
+    const int tid = threadIdx.x;
+    const float* pooled = out3;                       // plane 0 [B][CP]
+    const float* npos = out3 + (size_t)B * CP;        // plane 1
+    const float* ysum = out3 + (size_t)2 * B * CP;    // plane 2
+    if (gscale_dev) gscale *= gscale_dev[0];
+    for (int i = tid; i < B * I; i += 256) s_pool[i] = pooled[(size_t)(i / I) * CP + (i % I)];
+    for (int i = tid; i < O * I; i += 256) s_w[i] = w[i];
+    __syncthreads();
+    for (int idx = tid; idx < B * O; idx += 256) {
+        const int b = idx / O, o = idx - b * O;
+        float acc = bias ? bias[o] : 0.f;
+        for (int i = 0; i < I; ++i) acc = fmaf(s_pool[b * I + i], s_w[o * I + i], acc);
+        logits[idx] = acc;
+        s_logit[idx] = acc;
+    }
+    __syncthreads();
+    const int n = B * O;
+    float a1 = 0.f, a2 = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float v = s_logit[i];
+        if (kind == 0) {
+            a1 += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
+            s_g[i] = (1.f / (1.f + expf(-v)) - target) * gscale / (float)n;
+        } else {
+            const float df = v - messages[i];
+            a1 += df * df;
+            a2 += fabsf(fminf(fmaxf(rintf(v), 0.f), 1.f) - messages[i]);
+            s_g[i] = df * gscale;
+        }
+    }
+    a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = a1; s_red[1][tid >> 6] = a2; }
+    __syncthreads();
+    if (tid == 0) {
+        loss_out[0] = (s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3]) / (float)n;
+        if (kind == 1) loss_out[1] = (s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]) / (float)n;
+    }
+    for (int idx = tid; idx < O * I; idx += 256) {
+        const int o = idx / I, i = idx - o * I;
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc = fmaf(s_g[b * O + o], s_pool[b * I + i], acc);
+        dw[idx] = (accumulate ? dw[idx] : 0.f) + acc;
+    }
+    for (int o = tid; o < O; o += 256) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += s_g[b * O + o];
+        db[o] = (accumulate ? db[o] : 0.f) + acc;
+    }
+    for (int idx = tid; idx < B * CP; idx += 256) {
+        const int b = idx / CP, i = idx - b * CP;
+        float acc = 0.f;
+        if (i < I)
+            for (int o = 0; o < O; ++o) acc = fmaf(s_g[b * O + o], s_w[o * I + i], acc);
+        const float gv = acc * inv_hw;
+        gvec[idx] = gv;
+        s_gv[idx] = gv;
+    }
+    __syncthreads();
+    // the pooled layer's BatchNorm-backward finalisation: wm_bn_bwd_finalize_block's sums in ITS order (32 row slices, then the slices in order)
+    for (int c = tid; c < CP; c += 256) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int sl = 0; sl < 32; ++sl) {
+            double p1 = 0.0, p2 = 0.0;
+            for (int p = sl; p < B; p += 32) {
+                const float gv = s_gv[p * CP + c];
+                p1 += (double)(gv * npos[(size_t)p * CP + c]);
+                p2 += (double)(gv * ysum[(size_t)p * CP + c]);
+            }
+            t1 = sl == 0 ? p1 : t1 + p1;
+            t2 = sl == 0 ? p2 : t2 + p2;
+        }
+        if (c < C) {
+            t2 = (t2 - (double)mean[c] * t1) * (double)invstd[c];
+            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)t1;
+            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)t2;
+            coef[c] = gamma[c] * invstd[c];
+            coef[CP + c] = (float)(t1 / count);
+            coef[2 * CP + c] = (float)(t2 / count);
+        } else {
+            coef[c] = 0.f; coef[CP + c] = 0.f; coef[2 * CP + c] = 0.f;
+        }
+    }
+}
 }  // namespace
+
+extern "C" int wm_pooled_head_supported(int B, int CP, int I, int O) {
+    return (B > 0 && CP > 0 && I > 0 && O > 0 && I <= CP && B * CP <= PH_MAX_BC && O * I <= PH_MAX_OI && B * O <= PH_MAX_BO) ? 1 : 0;
+}
+
+extern "C" int wm_pooled_head(const float* out3, int B, int CP, int I, int O, const float* w, const float* bias, int kind, float target,
+                              const float* messages, float gscale, const float* gscale_dev, float* logits, float* loss_out, float* dw, float* db,
+                              int accumulate, float* gvec, float inv_hw, int C, double count, const float* gamma, const float* mean,
+                              const float* invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
+    WM_REQUIRE(out3 && w && logits && loss_out && dw && db && gvec && gamma && mean && invstd && coef, WM_E_BADARG, "wm_pooled_head: null pointer");
+    WM_REQUIRE(kind == 0 || (kind == 1 && messages), WM_E_BADARG, "wm_pooled_head: kind 0 (BCE against a constant label) or 1 (message loss, messages non-NULL)");
+    WM_REQUIRE(wm_pooled_head_supported(B, CP, I, O) && C > 0 && C <= CP && count > 0, WM_E_SHAPE, "wm_pooled_head: B=%d CP=%d I=%d O=%d beyond the one-workgroup form", B, CP, I, O);
+    hipLaunchKernelGGL(pooled_head_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out3, B, CP, I, O, w, bias, kind, target, messages, gscale,
+                       gscale_dev, logits, loss_out, dw, db, accumulate, gvec, inv_hw, C, count, gamma, mean, invstd, dgamma, dbeta, coef);
+    WM_LAUNCH_CHECK("wm_pooled_head");
+    return WM_OK;
+}
 
 extern "C" int wm_linear_head_fwd(const float* pooled, int ldp, const float* w, const float* bias, float* out, int B, int I,
                                   int O, void* stream) {

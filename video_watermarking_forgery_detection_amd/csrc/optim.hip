@@ -45,7 +45,9 @@ __global__ __launch_bounds__(256) void image_grad_mse_kernel(const T* __restrict
             const size_t i = (bi * C + c) * hw + q;
             const float d = a[i] - b[i];
             acc += d * d;
-            out[i] = __fadd_rn(to_f32(gp[c]), __fmul_rn(gscale, d));
+            float m = gscale * d;
+            asm volatile("" : "+v"(m));          // (keeps the product's own rounding: hipcc would contract product + sum into one fma)
+            out[i] = to_f32(gp[c]) + m;
         }
     }
     acc = wave_sum(acc);

@@ -161,7 +161,7 @@ def fin_rider(x, part, grads, accumulate):
 
 
 def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, accumulate=False,
-                 dgrad_channels=None, perm_dev=None, pool_stats=None, weight_grads=True):
+                 dgrad_channels=None, perm_dev=None, pool_stats=None, weight_grads=True, coef_pre=None):
     """Backward of ConvBNRelu.  g: NHWC gradient wrt the ReLU output ([B,H,W,>=CoutP]) or gvec [B,CoutP]
     (global-average-pool gradient, already / (H*W)).  grads: dict param -> f32 grad view.
     Returns the NHWC gradient wrt the (activated) input, `dgrad_channels` wide (default: the input's
@@ -188,6 +188,8 @@ def cbr_backward(conv, bn, ctx, grads, g=None, gvec=None, need_input_grad=True, 
     gam, dgam, dbet = bn.weight.data, grads[bn.weight], grads[bn.bias]
 
     def coef_of():
+        if gvec is not None and coef_pre is not None:     # finished already by the fused pooled head (ops.pooled_head: dgamma / dbeta written there)
+            return coef_pre
         if gvec is not None and pool_stats is not None:   # (N+, S+) from the forward pool: no pass over y
             return ops.bn_bwd_coef_pooled(gvec, pool_stats, y, ctx.stats, Cout, gam, dgam, dbet, accumulate)
         if pre is not None:

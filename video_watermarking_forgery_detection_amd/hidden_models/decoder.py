@@ -10,7 +10,7 @@ from .conv_bn_relu import ConvBNRelu
 
 
 class StackCtx:
-    __slots__ = ("layers", "pooled", "pool_stats", "HW", "x_is_leaf_image")
+    __slots__ = ("layers", "pooled", "pool_stats", "HW", "x_is_leaf_image", "gvec", "head_coef", "g_out")
 
 
 def stack_fwd(blocks, image, dt, training):
@@ -26,12 +26,46 @@ def stack_fwd(blocks, image, dt, training):
     else:
         ctx.pooled, ctx.pool_stats = ops.bnrelu_avgpool(a.t, a.scale, a.shift), None
     ctx.HW = image.shape[2] * image.shape[3]
+    ctx.gvec = ctx.head_coef = ctx.g_out = None
     return ctx.pooled, ctx
+
+
+def stack_fwd_loss(mod, blocks, image, dt, I, kind, target, messages, gscale, gscale_dev, grads, accumulate):
+    """training forward of the stack + its pooled head + the LOSS on the head's output + everything of the backward that depends on nothing
+    else -- the head's weight gradients, the per-sample gradient vector of the pooled features, the pooled layer's BatchNorm-backward
+    coefficients -- in one launch behind the pool (ops.pooled_head; hidden.py:68-101 calls criterion(D(x), label) / mse(decoder(x), m)
+    and .backward() right after).  kind 0: BCEWithLogits against the constant `target`; kind 1: the message loss against `messages`.
+    -> (head output [B,O], loss tensor [1] or [2], ctx); the backward continues with mod.bwd(ctx, None, ...).  Falls back to the
+    separate launches (same results) when the sizes exceed the one-workgroup form or the pool kept no statistics."""
+    pooled, ctx = stack_fwd(blocks, image, dt, True)
+    lin = mod.linear
+    O = lin.weight.shape[0]
+    last = ctx.layers[-1]
+    B, CP = pooled.shape
+    conv, bn = blocks[-1].layers[0], blocks[-1].layers[1]
+    if ctx.pool_stats is not None and last.stats.is_contiguous() and ops.pooled_head_supported(B, CP, I, O) and pooled._base is not None:
+        out, loss, ctx.gvec, ctx.head_coef = ops.pooled_head(
+            pooled._base, I, lin.weight.data, lin.bias.data, kind, target, messages, gscale, gscale_dev, grads[lin.weight], grads[lin.bias],
+            accumulate, 1.0 / ctx.HW, conv.weight.shape[0], B * ctx.HW, bn.weight.data, last.stats, grads[bn.weight], grads[bn.bias])
+        return out, loss, ctx
+    out = ops.linear_head_fwd(pooled, lin.weight.data, lin.bias.data, I)
+    if kind == 0:
+        loss, g = ops.bce_logits(out, target, gscale, gscale_dev=gscale_dev)
+    else:
+        loss, g = ops.message_loss(out, messages, gscale, gscale_dev=gscale_dev)
+    ctx.g_out = g.view_as(out)
+    return out, loss, ctx
 
 
 def head_bwd(mod, ctx, I, g_out, grads, accumulate):
     """nn.Linear after the pool, backward: fills the weight / bias gradients and returns the per-sample gradient vector
-    [B,CP] of the last ConvBNRelu's pooled output (already / (H*W)), one launch."""
+    [B,CP] of the last ConvBNRelu's pooled output (already / (H*W)), one launch.  (A ctx of stack_fwd_loss has it all already.)"""
+    if ctx.gvec is not None:
+        if g_out is not None:
+            raise RuntimeError("this forward already ran its head's backward (fwd_loss): call bwd(ctx, None, ...)")
+        return ctx.gvec
+    if g_out is None:
+        g_out = ctx.g_out
     CP = ctx.layers[-1].y.shape[-1]
     return ops.linear_head_bwd(ctx.pooled, mod.linear.weight.data, g_out, grads[mod.linear.weight], grads[mod.linear.bias],
                                accumulate, CP, 1.0 / ctx.HW)
@@ -47,7 +81,8 @@ def stack_bwd(blocks, ctx, gvec, grads, accumulate, need_input_grad, weight_grad
         blk = blocks[i]
         g = engine.cbr_backward(blk.layers[0], blk.layers[1], ctx.layers[i], grads, g=g, gvec=gvec if i == n - 1 else None,
                                 accumulate=accumulate, need_input_grad=(i > 0 or need_input_grad),
-                                pool_stats=ctx.pool_stats if i == n - 1 else None, weight_grads=weight_grads)
+                                pool_stats=ctx.pool_stats if i == n - 1 else None, weight_grads=weight_grads,
+                                coef_pre=ctx.head_coef if i == n - 1 else None)
     if not need_input_grad:
         return None
     return g if raw_input_grad else ops.nhwc_to_nchw(g, 3, 0)
@@ -104,6 +139,14 @@ class Decoder(nn.Module, engine.FlatModule):
         if training:
             engine.bump_bn_counters(self)
         return out, ctx
+
+    def fwd_loss(self, image, messages, gscale, grads, accumulate=False, gscale_dev=None):
+        """fwd(image) + the message loss (hidden.py:96-99,109-111) + the head's share of the backward: -> (decoded [B,L], [2] = MSE, bitwise
+        error, ctx); continue with bwd(ctx, None, grads, accumulate)"""
+        out, loss, ctx = stack_fwd_loss(self, self._blocks(), image, self.compute_dtype, self.message_length, 1, 0.0, messages, gscale,
+                                        gscale_dev, grads, accumulate)
+        engine.bump_bn_counters(self)
+        return out, loss, ctx
 
     def bwd(self, ctx, g_out, grads, accumulate=False, need_input_grad=True):
         gvec = head_bwd(self, ctx, self.message_length, g_out, grads, accumulate)

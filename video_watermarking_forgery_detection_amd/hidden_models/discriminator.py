@@ -7,7 +7,7 @@ import torch.nn as nn
 from .. import engine, ops
 from ..options import HiDDenConfiguration
 from .conv_bn_relu import ConvBNRelu
-from .decoder import _StackLinearFn, bump_bn_counters, head_bwd, stack_bwd, stack_fwd
+from .decoder import _StackLinearFn, bump_bn_counters, head_bwd, stack_bwd, stack_fwd, stack_fwd_loss
 
 
 class Discriminator(nn.Module, engine.FlatModule):
@@ -34,6 +34,14 @@ class Discriminator(nn.Module, engine.FlatModule):
         if training:
             engine.bump_bn_counters(self)
         return out, ctx
+
+    def fwd_loss(self, image, label, gscale, grads, accumulate=False, gscale_dev=None):
+        """fwd(image) + BCEWithLogitsLoss against the constant label (hidden.py:68-97) + the head's share of the backward (gscale * the
+        loss's gradient): -> (logits [B,1], loss [1], ctx); continue with bwd(ctx, None, grads, accumulate, ...)"""
+        out, loss, ctx = stack_fwd_loss(self, self._blocks(), image, self.compute_dtype, self.channels, 0, float(label), None, gscale,
+                                        gscale_dev, grads, accumulate)
+        engine.bump_bn_counters(self)
+        return out, loss, ctx
 
     def bwd(self, ctx, g_out, grads, accumulate=False, need_input_grad=False, weight_grads=True, raw_input_grad=False):
         """weight_grads False (with need_input_grad): the gradient wrt the image only -- the convolutions' weight gradients are not

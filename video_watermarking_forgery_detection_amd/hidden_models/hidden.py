@@ -487,21 +487,21 @@ class Hidden:
                 and hasattr(ed.noiser, "fwd") and hasattr(ed.noiser, "bwd")):
             return self._train_step_two_chains(images, messages, B, cfg, ed, enc_net, dec_net, D, gD, gE, gDec)
         # ---------------- train the discriminator (hidden.py:68-83)
-        d_on_cover, c = D.fwd(images)
-        d_loss_on_cover, g = self._bce_logits(d_on_cover, self.cover_label)
-        D.bwd(c, g, gD, accumulate=False, need_input_grad=False)          # zero_grad + backward
+        # (fwd_loss: the forward, the loss on its output and the head's share of the backward -- one launch behind the pool instead of four)
+        d_on_cover, d_loss_on_cover, c = D.fwd_loss(images, self.cover_label, 1.0, gD, accumulate=False, gscale_dev=self._gsd())
+        D.bwd(c, None, gD, accumulate=False, need_input_grad=False)       # zero_grad + backward
 
         encoded, cE = enc_net.fwd(images, messages)
         noised, cN = self._run_noiser(encoded, images)
 
-        d_on_encoded, c = D.fwd(encoded)                                  # encoded.detach()
-        d_loss_on_encoded, g = self._bce_logits(d_on_encoded, self.encoded_label)
-        D.bwd(c, g, gD, accumulate=True, need_input_grad=False)
+        d_on_encoded, d_loss_on_encoded, c = D.fwd_loss(encoded, self.encoded_label, 1.0, gD, accumulate=True, gscale_dev=self._gsd())   # encoded.detach()
+        D.bwd(c, None, gD, accumulate=True, need_input_grad=False)
         gs = self.grad_sync
         # data parallel: the discriminator's bucket travels under the decoder's forward (independent of D; the reference runs it
         # before D(encoded), the results are the same)
         pending_d = gs.start(D.flat_grads) if gs is not None else None
-        decoded, cDec = dec_net.fwd(noised)
+        decoded, msg_out, cDec = dec_net.fwd_loss(noised, messages, 2.0 * cfg.decoder_loss / (B * cfg.message_length), gDec, accumulate=False,
+                                                  gscale_dev=self._gsd())     # mse, bit error, and the head's backward
         gscale = 1.0
         if gs is not None:
             gs.finish(pending_d)
@@ -515,8 +515,8 @@ class Hidden:
         D.refresh_packs()
 
         # ---------------- train the generator (hidden.py:85-103)
-        d_on_encoded_for_enc, c = D.fwd(encoded)
-        g_loss_adv, g = self._bce_logits(d_on_encoded_for_enc, self.cover_label, cfg.adversarial_loss)
+        d_on_encoded_for_enc, g_loss_adv, c = D.fwd_loss(encoded, self.cover_label, cfg.adversarial_loss, gD, accumulate=True, gscale_dev=self._gsd())
+        g = None
         # the reference's g_loss.backward() also accumulates into the discriminator's .grad (zeroed at the start of the next step, never
         # read): kept by default so the .grad state matches; keep_dead_discriminator_grads=False computes the image gradient alone
         n_img = encoded.numel()
@@ -530,10 +530,8 @@ class Hidden:
             g_enc = D.bwd(c, g, gD, accumulate=True, need_input_grad=True, weight_grads=self.keep_dead_discriminator_grads)
             enc_part, g_mse = ops.mse_fwd_bwd_gated(encoded, images, 2.0 * cfg.encoder_loss / n_img, gate[1:2], gscale_dev=self._gsd())
             ops.axpy_(g_enc, g_mse)
-        msg_out, g_dec = ops.message_loss(decoded, messages, 2.0 * cfg.decoder_loss / decoded.numel(), gscale_dev=self._gsd())   # mse, bit error, grad
-        g_dec = g_dec.view_as(decoded)
         zero_attack = self.skip_zero_attack_gradient and _noise_bwd_is_zero(ed.noiser, cN)
-        g_noised = dec_net.bwd(cDec, g_dec, gDec, accumulate=False, need_input_grad=not zero_attack)
+        g_noised = dec_net.bwd(cDec, None, gDec, accumulate=False, need_input_grad=not zero_attack)
         # data parallel: the decoder's bucket goes out now and travels while the attack and the encoder run their backward
         pending = [gs.start(dec_net.flat_grads)] if gs is not None else []
         if not zero_attack:
@@ -592,9 +590,8 @@ class Hidden:
             engine.image_to_act(images, dt)              # converted once, before the fork: both chains read it
         sA.wait_stream(main); sB.wait_stream(main)
         with torch.cuda.stream(sA):
-            d_on_cover, c = D.fwd(images)
-            d_loss_on_cover, g = self._bce_logits(d_on_cover, self.cover_label)
-            D.bwd(c, g, gD, accumulate=False, need_input_grad=False)
+            d_on_cover, d_loss_on_cover, c = D.fwd_loss(images, self.cover_label, 1.0, gD, accumulate=False, gscale_dev=self._gsd())
+            D.bwd(c, None, gD, accumulate=False, need_input_grad=False)
         with torch.cuda.stream(sB):
             encoded, cE = enc_net.fwd(images, messages)
             for dt in {D.compute_dtype, dec_net.compute_dtype}:
@@ -602,21 +599,19 @@ class Hidden:
             ev_enc = torch.cuda.Event()
             ev_enc.record(sB)
             noised, cN = self._run_noiser(encoded, images)
-            decoded, cDec = dec_net.fwd(noised)
-            msg_out, g_dec = ops.message_loss(decoded, messages, 2.0 * cfg.decoder_loss / decoded.numel(), gscale_dev=self._gsd())
-            g_dec = g_dec.view_as(decoded)
+            decoded, msg_out, cDec = dec_net.fwd_loss(noised, messages, 2.0 * cfg.decoder_loss / (B * cfg.message_length), gDec, accumulate=False,
+                                                      gscale_dev=self._gsd())
             zero_attack = self.skip_zero_attack_gradient and _noise_bwd_is_zero(ed.noiser, cN)
-            g_noised = dec_net.bwd(cDec, g_dec, gDec, accumulate=False, need_input_grad=not zero_attack)
+            g_noised = dec_net.bwd(cDec, None, gDec, accumulate=False, need_input_grad=not zero_attack)
             g_from_noise = None if zero_attack else _noise_bwd(ed.noiser, cN, g_noised).contiguous()
         with torch.cuda.stream(sA):
             sA.wait_event(ev_enc)
-            d_on_encoded, c = D.fwd(encoded)
-            d_loss_on_encoded, g = self._bce_logits(d_on_encoded, self.encoded_label)
-            D.bwd(c, g, gD, accumulate=True, need_input_grad=False)
+            d_on_encoded, d_loss_on_encoded, c = D.fwd_loss(encoded, self.encoded_label, 1.0, gD, accumulate=True, gscale_dev=self._gsd())
+            D.bwd(c, None, gD, accumulate=True, need_input_grad=False)
             self.optimizer_discrim.step(grad_scale=1.0)
             D.refresh_packs()
-            d_on_encoded_for_enc, c = D.fwd(encoded)
-            g_loss_adv, g = self._bce_logits(d_on_encoded_for_enc, self.cover_label, cfg.adversarial_loss)
+            d_on_encoded_for_enc, g_loss_adv, c = D.fwd_loss(encoded, self.cover_label, cfg.adversarial_loss, gD, accumulate=True, gscale_dev=self._gsd())
+            g = None
             g_img = D.bwd(c, g, gD, accumulate=True, need_input_grad=True, weight_grads=self.keep_dead_discriminator_grads, raw_input_grad=True)
             n_img = encoded.numel()
             g_enc, enc_part = ops.image_grad_mse(g_img, encoded, images, 2.0 * cfg.encoder_loss / n_img, gscale_dev=self._gsd())

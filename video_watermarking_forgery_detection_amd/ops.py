@@ -610,6 +610,31 @@ def linear_head_bwd(pooled, w, g_out, dw, db, accumulate, CP, inv_hw):
     return gvec
 
 
+def pooled_head_supported(B, CP, I, O):
+    return bool(_lib.lib().wm_pooled_head_supported(c_int(B), c_int(CP), c_int(I), c_int(O)))
+
+
+def pooled_head(out3, I, w, bias, kind, target, messages, gscale, gscale_dev, dw, db, accumulate, inv_hw, C, count, gamma, stats, dgamma, dbeta):
+    """linear_head_fwd + the loss (kind 0: bce_logits vs the constant `target`; kind 1: message_loss vs messages [B,O]) + linear_head_bwd +
+    bn_bwd_coef_pooled as ONE launch.  out3 [3,B,CP] = bnrelu_avgpool_stats' buffer (pooled, N+, S+); stats [4,CP] of the pooled
+    ConvBNRelu.  -> (logits [B,O], loss [1] or [2], gvec [B,CP], coef [3,CP]); dw, db, dgamma, dbeta written in place."""
+    _, B, CP = out3.shape
+    O = w.shape[0]
+    assert out3.is_contiguous() and out3.dtype == torch.float32 and tuple(w.shape) == (O, I) and w.is_contiguous() and dw.is_contiguous()
+    dev = out3.device
+    logits = torch.empty(B, O, device=dev, dtype=torch.float32)
+    loss = torch.empty(2 if kind == 1 else 1, device=dev, dtype=torch.float32)
+    gvec = torch.empty(B, CP, device=dev, dtype=torch.float32)
+    coef = torch.empty(3, CP, device=dev, dtype=torch.float32)
+    msg = messages.contiguous().float() if messages is not None else None
+    rc = _lib.lib().wm_pooled_head(_p(out3), c_int(B), c_int(CP), c_int(I), c_int(O), _p(w), _p(bias), c_int(kind), c_float(float(target)), _p(msg),
+                                   c_float(float(gscale)), _p(gscale_dev), _p(logits), _p(loss), _p(dw), _p(db), c_int(1 if accumulate else 0),
+                                   _p(gvec), c_float(inv_hw), c_int(C), c_double(float(count)), _p(gamma), _p(stats[2]), _p(stats[3]),
+                                   _p(dgamma), _p(dbeta), _p(coef), _stream())
+    _lib.check(rc, "wm_pooled_head")
+    return logits, loss, gvec, coef
+
+
 def bce_logits(logits, target, gscale=1.0, want_grad=True, gscale_dev=None):
     """BCEWithLogitsLoss(mean) against a constant label: (loss [1] tensor, gscale * d loss / d logits or None).
     gscale_dev (here and in the other loss ops): optional device scalar multiplied into gscale (the AMP loss scale)."""
