@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
             invstd_out[c] = invstd;
             if (running_mean) {
                 const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                running_mean[c] = wm_running_update(running_mean[c], (float)m, momentum);
-                running_var[c] = wm_running_update(running_var[c], (float)unbiased, momentum);
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
             }
         } else {  // padded channel: contributes nothing downstream
             scale[c] = 0.f; shift[c] = 0.f; mean_out[c] = 0.f; invstd_out[c] = 0.f;

@@ -130,10 +130,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
     if (tid < COUT) sBias[tid] = (a.bias && tid < a.nbias) ? a.bias[tid] : 0.f;
-    // (a lambda every thread of the workgroup calls exactly once: the producers AFTER they have issued their first two tiles' loads, so that
-    // the statistics rows travel beside them, the consumers right away)
-    auto input_bn = [&]() {
-      if (XFORM) {
+    if (XFORM) {
         // The input transform's constants.  Either given (in_scale / in_shift), or -- round 4 -- finalised HERE from the feeding layer's
         // statistics rows: bn_finalize_kernel's arithmetic in its order (32 row slices per channel summed in double, then the slices in
         // order), by every workgroup for itself (128 KB of L2 reads beside the filter's trip), instead of a 5 us launch of its own between
@@ -171,8 +168,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                     mo = (float)m;
                     if (blockIdx.x == 0 && a.fin.running_mean) {
                         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                        a.fin.running_mean[c] = wm_running_update(a.fin.running_mean[c], (float)m, a.fin.momentum);
-                        a.fin.running_var[c] = wm_running_update(a.fin.running_var[c], (float)unbiased, a.fin.momentum);
+                        a.fin.running_mean[c] = (1.f - a.fin.momentum) * a.fin.running_mean[c] + a.fin.momentum * (float)m;
+                        a.fin.running_var[c] = (1.f - a.fin.momentum) * a.fin.running_var[c] + a.fin.momentum * (float)unbiased;
                     }
                 }
                 sFin[c] = sc; sFin[C64 + c] = sh;
@@ -184,8 +181,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             sFin[tid] = a.in_scale[tid]; sFin[C64 + tid] = a.in_shift[tid];
         }
         __syncthreads();   // (the slice sums are dead from here: the halo buffers are the producers')
-      }
-    };
+    }
 
     // ---- filter -> LDS (all 512 threads).  The filter is the A operand of the MFMA (D rows = output channels, D
     // columns = pixels), so a lane of the accumulator tile holds ONE pixel and, in its 16 registers, the MFMA rows
@@ -245,6 +241,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         f32x2 sc2[4], sh2[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sc2[e] = f32x2{1.f, 1.f}; sh2[e] = f32x2{0.f, 0.f}; }
+        if (XFORM) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sc2[e] = f32x2{sFin[vec * 8 + 2 * e], sFin[vec * 8 + 2 * e + 1]};
+                sh2[e] = f32x2{sFin[C64 + vec * 8 + 2 * e], sFin[C64 + vec * 8 + 2 * e + 1]};
+            }
+        }
         static_assert(!(BNBWD && XFORM), "one input transform at a time");
         static_assert(BNBWD != 2 || CIN == 64, "the tensor-gradient form is built for 64-channel layers");
         float kca[8];   // BNBWD == 2: ca of the 8 channels
@@ -438,14 +441,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         unsigned okA = 0, okB = 0;
         if (t_begin < t_end) load_tile(geo(t_begin), dA, okA, false);
         if (t_begin + 1 < t_end) load_tile(geo(t_begin + 1), dB, okB, reuse_of(t_begin + 1));
-        input_bn();
-        if (XFORM) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sc2[e] = f32x2{sFin[vec * 8 + 2 * e], sFin[vec * 8 + 2 * e + 1]};
-                sh2[e] = f32x2{sFin[C64 + vec * 8 + 2 * e], sFin[C64 + vec * 8 + 2 * e + 1]};
-            }
-        }
         if (!early_filter) commit_filter();
         if (t_begin < t_end) {
             load_gvec(geo(t_begin).b);
@@ -533,7 +528,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
     // fragment mf = 0 then mf = 1 (2 MFMAs per step; the filter fragments are read twice -- the LDS has the room), and
     // while one half accumulates, the finished other half is drained (BatchNorm sums, bf16 pack, stores) in the
     // shadow of the MFMAs, a few instructions per step, so the matrix pipe never waits for an epilogue.
-    input_bn();
     if (!early_filter) commit_filter();
     if constexpr (M16) {
         // lane (p, q): pixel column p of the tile row wave*4 + mf; accumulator [mf][nf] register i = channel 16q + 4nf + i

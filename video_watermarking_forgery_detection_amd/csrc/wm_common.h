@@ -50,15 +50,6 @@ void wm_set_error(const char* fmt, ...);
 
 static inline int wm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// BatchNorm's running statistic: (1 - momentum) * old + momentum * stat, with ONE fixed rounding sequence (the product (1 - momentum) * old
-// rounded, then one fma) wherever it is evaluated -- bn_finalize_kernel and the consumers that finalise in their prologue (conv3x3_ws.hip)
-// must agree bit for bit, and hipcc contracts a * b + c * d either way
-__device__ __forceinline__ float wm_running_update(float old, float stat, float momentum) {
-    float keep = (1.f - momentum) * old;
-    asm volatile("" : "+v"(keep));
-    return __builtin_fmaf(momentum, stat, keep);
-}
-
 // ---- BatchNorm+ReLU backward apply, folded (bf16 path).  With g one value per (sample, channel) -- a globally pooled layer:
 //   dy = ca*(g*[z>0] - c1 - (y-mean)*invstd*c2),  z = scale*y + shift
 //      = (z > 0 ? k3 + ca*g : k3) - k2*y,         k2 = ca*invstd*c2,  k3 = k2*mean - ca*c1
