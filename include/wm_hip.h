@@ -55,15 +55,6 @@ typedef struct WmBnBwdFin {
     float* dgamma; float* dbeta; int accumulate; float* coef;
 } WmBnBwdFin;
 
-/* The forward BatchNorm finalisation of a layer (wm_bn_finalize's arguments) handed to the launch that CONSUMES that layer's raw output
- * (wm_conv3x3_fwd_fin / wm_conv3x3_fwd_addin_fin): every workgroup of the consumer reduces the <= 256 partial rows itself in its prologue
- * (same sums, same order, same result as wm_bn_finalize; the rows sit in L2), workgroup 0 writes stats_out [4][CP] = scale | shift |
- * mean | invstd and the running statistics.  Saves the finalisation's own launch between two convolutions of a chain (round 4). */
-typedef struct WmBnFin {
-    const float* partials; int nparts; int C; int CP; double count; const float* gamma; const float* beta;
-    float* running_mean; float* running_var; float momentum; float eps; float* stats_out;
-} WmBnFin;
-
 /* ------------------------------------------------------------------ block-JPEG attack
  * replaces: noise_layers/jpeg.py:226-240 (Jpeg.forward), :259-273 (JpegSS), :295-306 (JpegMask)
  * with helpers :52-211.  x,y: [B,3,H,W] f32 NCHW.  mode 0 = round, 1 = round_ss, 2 = mask.
@@ -291,14 +282,6 @@ int wm_concat_side_msg_wgrad(const void* dy, const float* msg, float* partial, f
                              int W, int Cin, int c_msg, int L, int dtype, void* stream);
 int wm_conv3x3_fwd_addin(const void* x, const void* wp, const float* in_scale, const float* in_shift, const void* addend, void* y,
                          float* stat_partials, int B, int H, int W, int dtype, int sweep_reverse, void* stream);
-/* wm_conv3x3_fwd / wm_conv3x3_fwd_addin of a 64-channel ConvBNRelu output x [B][H][W][64] (16-bit dtypes) with in_scale / in_shift
- * replaced by in_fin: the launch finalises the feeding layer's BatchNorm itself (WmBnFin above; reference conv_bn_relu.py:11-15, the
- * BatchNorm2d of the block BELOW).  CoutP 64 or 32 (_supported); bias [nbias] may be NULL. */
-int wm_conv3x3_fwd_fin_supported(int Cin, int CoutP, int dtype);
-int wm_conv3x3_fwd_fin(const void* x, const void* wp, const float* bias, int nbias, const WmBnFin* in_fin, void* y, float* stat_partials,
-                       int B, int H, int W, int CoutP, int dtype, int sweep_reverse, void* stream);
-int wm_conv3x3_fwd_addin_fin(const void* x, const void* wp, const WmBnFin* in_fin, const void* addend, void* y, float* stat_partials,
-                             int B, int H, int W, int dtype, int sweep_reverse, void* stream);
 /* The backward of an IMAGE-FED first ConvBNRelu (3 -> 64 channels; replaces autograd's backward of conv_bn_relu.py:11-15 for the layers of
  * decoder.py:16 / discriminator.py:13, whose input image needs a gradient) in ONE pass (csrc/bwd_ws16.hip): reads g, y [B,H,W,64] (gradient
  * wrt the layer's ReLU output, its raw conv output; stats4 / coef as wm_conv3x3_dgrad_applyfused) and the layer's input x [B,H,W,16] (the

@@ -91,73 +91,3 @@ def test_pooled_head_equals_the_four_launches(case):
     for a, b, name in ((logits0, logits1, "logits"), (loss0, loss1, "loss"), (gvec0, gvec1, "gvec"), (coef0, coef1, "coef"), (dw0, dw1, "dw"),
                        (db0, db1, "db"), (dg0, dg1, "dgamma"), (dbt0, dbt1, "dbeta")):
         assert torch.equal(a.reshape(-1), b.reshape(-1)), name
-
-
-@pytest.mark.parametrize("case", [(torch.bfloat16, 4, 64, 64, 64, 256), (torch.float16, 2, 32, 48, 32, 7), (torch.bfloat16, 16, 256, 256, 64, 256)])
-def test_forward_conv_finalises_the_feeding_layers_batchnorm_itself(case):
-    """wm_conv3x3_fwd_fin (every workgroup reduces the feeding layer's statistics rows in its prologue) against wm_bn_finalize + wm_conv3x3_fwd:
-    the statistics tensor (scale, shift, mean, invstd), the running statistics, the output and its own statistics rows, bit for bit
-    (reference: BatchNorm2d of the block below, hidden_models/conv_bn_relu.py:11-15)."""
-    from video_watermarking_forgery_detection_amd import ops
-    dt, B, H, W, CoutP, nparts = case
-    C = 64
-    x = detgen.normal((B, H, W, C), 51, mean=0.1).to(dt).cuda()
-    part = (detgen.normal((nparts, 2, C), 52, mean=3.0, std=1.0).abs() * (B * H * W / nparts)).cuda()
-    part[:, 1] = part[:, 0] * 1.5 + 10.0        # sum of squares consistent with a positive variance
-    gamma = detgen.normal((C,), 53, mean=1.0, std=0.2).cuda(); beta = detgen.normal((C,), 54, std=0.3).cuda()
-    w = detgen.normal((CoutP, C, 3, 3), 55, std=0.05).cuda()
-    bias = detgen.normal((CoutP,), 56, std=0.1).cuda()
-    wp = ops.pack_w3x3(w, CoutP, C, dt)
-    rm0, rv0 = detgen.normal((C,), 57).cuda(), detgen.uniform((C,), 58).cuda() + 0.5
-    # ---- two launches
-    rm1, rv1 = rm0.clone(), rv0.clone()
-    stats1 = ops.bn_finalize(part.clone(), C, C, B * H * W, gamma, beta, rm1, rv1, 0.1, 1e-5)
-    y1, st1 = ops.conv3x3_fwd(x, wp, bias, stats1[0], stats1[1], want_stats=True)
-    # ---- one
-    rm2, rv2 = rm0.clone(), rv0.clone()
-    fin = ops.BnFin(part.clone(), C, C, B * H * W, gamma, beta, rm2, rv2, 0.1, 1e-5)
-    assert ops.conv3x3_fwd_takes_fin(x, CoutP, fin)
-    y2, st2 = ops.conv3x3_fwd(x, wp, bias, None, None, want_stats=True, fin=fin)
-    torch.cuda.synchronize()
-    assert torch.equal(stats1, fin.stats) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
-    assert torch.equal(y1, y2) and torch.equal(st1, st2)
-
-
-def test_lazy_batchnorm_finalisation_changes_no_bit_of_a_training_step():
-    """engine.lazy_bn_finalize: a step whose forward convolutions finalise their input's BatchNorm themselves against the same step with the
-    finalisation launched on the spot (rounds 1-3) -- losses, outputs, parameters, BatchNorm buffers, gradients and optimiser state."""
-    from video_watermarking_forgery_detection_amd import engine, noise_layers as NL
-    from video_watermarking_forgery_detection_amd.hidden_models import Hidden
-    from video_watermarking_forgery_detection_amd.options import HiDDenConfiguration
-
-    def make():
-        h = Hidden(HiDDenConfiguration(H=64, W=64), torch.device("cuda"), NL.JpegSS(50), None, compute_dtype=torch.bfloat16)
-        for m in (h.encoder_decoder.encoder, h.encoder_decoder.decoder, h.discriminator):
-            detgen.fill_module(m)
-        return h
-
-    def state(h):
-        out = {}
-        for k, m in (("E", h.encoder_decoder.encoder), ("Dec", h.encoder_decoder.decoder), ("D", h.discriminator)):
-            out.update({f"{k}.{n}": t.detach().clone() for n, t in m.state_dict().items()})
-            out[f"{k}.grad"] = m.flat_grads.detach().clone()
-        for k, o in (("optD", h.optimizer_discrim), ("optED", h.optimizer_enc_dec)):
-            for i, (m, v) in enumerate(zip(o._m, o._v)):
-                out[f"{k}.m{i}"], out[f"{k}.v{i}"] = m.detach().clone(), v.detach().clone()
-        return out
-
-    eager, lazy = make(), make()
-    assert engine.lazy_bn_finalize()
-    try:
-        for i in range(3):
-            images = detgen.uniform((4, 3, 64, 64), 7700 + i).cuda(); messages = detgen.bits((4, 30), 7800 + i).cuda()
-            engine.lazy_bn_finalize(False)
-            le, oe = eager.train_on_batch([images, messages])
-            engine.lazy_bn_finalize(True)
-            ll, ol = lazy.train_on_batch([images, messages])
-            assert all(le[k] == ll[k] for k in le) and all(torch.equal(a, b) for a, b in zip(oe, ol)), i
-    finally:
-        engine.lazy_bn_finalize(True)
-    se, sl = state(eager), state(lazy)
-    for k in se:
-        assert torch.equal(se[k], sl[k]), k

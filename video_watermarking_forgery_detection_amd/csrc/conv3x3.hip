@@ -36,7 +36,7 @@ WM_DECL_STREAM(_f16);
                                   int tiles_per_wg, hipStream_t s, int reverse, const float* bw_stats4 = nullptr, int bw_ld = 0,            \
                                   const float* bw_coef = nullptr, const float* bw_gvec = nullptr, const void* ry = nullptr,                 \
                                   const float* r_scale = nullptr, const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr, \
-                                  const void* addend = nullptr, const WmBnFin* fin = nullptr)
+                                  const void* addend = nullptr)
 WM_DECL_WS(_bf16);
 WM_DECL_WS(_f16);
 // the two compilations of conv3x3_ws.hip, by activation dtype (WM_BF16 / WM_F16)
@@ -402,41 +402,8 @@ extern "C" int wm_conv3x3_fwd(const void* x, int ldx, const void* wp, const floa
     return WM_OK;
 }
 
-// The forward conv of a 64-channel ConvBNRelu output with that layer's BatchNorm finalisation done by the launch itself (WmBnFin,
-// include/wm_hip.h): 16-bit dtypes, Cin == 64 == x's pixel stride, CoutP 64 or 32, dense output; the input transform is
-// relu(scale * x + shift) with scale / shift from in_fin.  wm_conv3x3_fwd_fin_supported says for which shapes.
-extern "C" int wm_conv3x3_fwd_fin_supported(int Cin, int CoutP, int dtype) { return (Cin == 64 && use_ws(Cin, CoutP, dtype)) ? 1 : 0; }
-
-extern "C" int wm_conv3x3_fwd_fin(const void* x, const void* wp, const float* bias, int nbias, const WmBnFin* in_fin, void* y, float* stat_partials,
-                                  int B, int H, int W, int CoutP, int dtype, int sweep_reverse, void* stream) {
-    WM_REQUIRE(x && wp && y && in_fin, WM_E_BADARG, "wm_conv3x3_fwd_fin: null pointer");
-    WM_REQUIRE(B > 0 && H > 0 && W > 0 && wm_conv3x3_fwd_fin_supported(64, CoutP, dtype), WM_E_SHAPE, "wm_conv3x3_fwd_fin: 16-bit dtype, 64 input channels, CoutP 64 or 32");
-    WM_REQUIRE((((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y | (uintptr_t)in_fin->partials) & 15) == 0, WM_E_SHAPE, "wm_conv3x3_fwd_fin: pointers must be 16-byte aligned");
-    const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
-    const int rc = wm_launch_conv3x3_ws(dtype, x, 64, 64, CoutP, wp, bias, nbias, nullptr, nullptr, y, stat_partials, B, H, W, ws_wgs(ntiles),
-                                        ws_tiles_per_wg(ntiles), (hipStream_t)stream, sweep_reverse ? 1 : 0, nullptr, 0, nullptr, nullptr, nullptr,
-                                        nullptr, nullptr, nullptr, nullptr, nullptr, in_fin);
-    WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_fwd_fin: bad finalisation arguments (<= 256 rows of 64 channels, gamma / beta / stats_out non-NULL)");
-    WM_LAUNCH_CHECK("wm_conv3x3_fwd_fin");
-    return WM_OK;
-}
-
 // forward 64 -> 64 conv (16-bit dtypes, dense tensors) whose epilogue adds a second tensor before the BatchNorm statistics:
 // y = conv3x3(relu(in_scale*x + in_shift), wp) + addend
-extern "C" int wm_conv3x3_fwd_addin_fin(const void* x, const void* wp, const WmBnFin* in_fin, const void* addend, void* y,
-                                        float* stat_partials, int B, int H, int W, int dtype, int sweep_reverse, void* stream) {
-    WM_REQUIRE(x && wp && in_fin && addend && y && stat_partials, WM_E_BADARG, "wm_conv3x3_fwd_addin_fin: null pointer");
-    WM_REQUIRE(B > 0 && H > 0 && W > 0 && is16(dtype), WM_E_BADARG, "wm_conv3x3_fwd_addin_fin: bad shape / dtype (WM_BF16 or WM_F16)");
-    WM_REQUIRE((((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y | (uintptr_t)addend | (uintptr_t)in_fin->partials) & 15) == 0, WM_E_SHAPE, "wm_conv3x3_fwd_addin_fin: pointers must be 16-byte aligned");
-    const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
-    const int rc = wm_launch_conv3x3_ws(dtype, x, 64, 64, 64, wp, nullptr, 0, nullptr, nullptr, y, stat_partials, B, H, W, ws_wgs(ntiles),
-                                        ws_tiles_per_wg(ntiles), (hipStream_t)stream, sweep_reverse ? 1 : 0, nullptr, 0, nullptr, nullptr, nullptr,
-                                        nullptr, nullptr, nullptr, nullptr, addend, in_fin);
-    WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_fwd_addin_fin: no kernel for this shape / bad finalisation arguments");
-    WM_LAUNCH_CHECK("wm_conv3x3_fwd_addin_fin");
-    return WM_OK;
-}
-
 extern "C" int wm_conv3x3_fwd_addin(const void* x, const void* wp, const float* in_scale, const float* in_shift, const void* addend, void* y,
                                     float* stat_partials, int B, int H, int W, int dtype, int sweep_reverse, void* stream) {
     WM_REQUIRE(x && wp && in_scale && in_shift && addend && y && stat_partials, WM_E_BADARG, "wm_conv3x3_fwd_addin: null pointer");

@@ -52,7 +52,6 @@ struct WsArgs {
     const hx_t* ry; const float* r_scale; const float* r_shift;   // BWDST: raw output [B,H,W,COUT] and scale / shift of the layer whose output gradient this kernel writes
     const hx_t* ay; hx_t* dy_out;   // BNBWD == 2: x is g [B,H,W,64]; ay the layer's raw output, dy_out where dy is written (both dense)
     int reverse;  // walk the workgroup's run of tiles backwards (Infinity Cache reuse of the previous kernel's tail)
-    WmBnFin fin;  // XFORM, fin.partials != null: in_scale / in_shift are not given -- the workgroup finalises the feeding layer's BatchNorm itself
     unsigned mX, mY;   // ceil(2^32 / tilesX), ceil(2^32 / tilesY) (0 for 1): the tile index is divided by mulhi, not by ~40 scalar instructions
 };
 
@@ -120,68 +119,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_start)::"memory");
     }
     constexpr int SW_BYTES = 9 * COUT * CIN * 2, SX_BYTES = NPIX * CIN * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SW_BYTES + 2 * SX_BYTES + 4 * 2 * C64 * 4 + C64 * 4 + 2 * C64 * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SW_BYTES + 2 * SX_BYTES + 4 * 2 * C64 * 4 + C64 * 4];
     hx_t* sW = reinterpret_cast<hx_t*>(smem);
     hx_t* sX0 = reinterpret_cast<hx_t*>(smem + SW_BYTES);  // two halo tiles back to back
     float* sRed = reinterpret_cast<float*>(smem + SW_BYTES + 2 * SX_BYTES);
     float* sBias = sRed + 4 * 2 * C64;   // the accumulators start from the bias
-    float* sFin = sBias + C64;           // XFORM: the input transform's scale [64] | shift [64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
     if (tid < COUT) sBias[tid] = (a.bias && tid < a.nbias) ? a.bias[tid] : 0.f;
-    if (XFORM) {
-        // The input transform's constants.  Either given (in_scale / in_shift), or -- round 4 -- finalised HERE from the feeding layer's
-        // statistics rows: bn_finalize_kernel's arithmetic in its order (32 row slices per channel summed in double, then the slices in
-        // order), by every workgroup for itself (128 KB of L2 reads beside the filter's trip), instead of a 5 us launch of its own between
-        // two convolutions of a chain.  Workgroup 0 leaves scale | shift | mean | invstd for the backward pass and updates the running
-        // statistics.  The halo buffers are free until the first tile is published: the slice sums live there.
-        if (CIN == 64 && a.fin.partials) {
-            double (*f1)[C64] = reinterpret_cast<double (*)[C64]>(smem + SW_BYTES);
-            double (*f2)[C64] = f1 + 32;
-            static_assert(2 * 32 * C64 * 8 <= 2 * SX_BYTES || CIN != 64, "the slice sums fit the halo buffers");
-            const int sl = tid >> 4, cq = (tid & 15) * 4, CP = a.fin.CP;
-            double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 8
-            for (int p = sl; p < a.fin.nparts; p += 32) {
-                const float4 v1 = *reinterpret_cast<const float4*>(a.fin.partials + ((size_t)p * 2 + 0) * CP + cq);
-                const float4 v2 = *reinterpret_cast<const float4*>(a.fin.partials + ((size_t)p * 2 + 1) * CP + cq);
-                a1[0] += (double)v1.x; a1[1] += (double)v1.y; a1[2] += (double)v1.z; a1[3] += (double)v1.w;
-                a2[0] += (double)v2.x; a2[1] += (double)v2.y; a2[2] += (double)v2.z; a2[3] += (double)v2.w;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { f1[sl][cq + e] = a1[e]; f2[sl][cq + e] = a2[e]; }
-            __syncthreads();
-            if (tid < C64) {
-                const int c = tid;
-                double s1 = f1[0][c], s2 = f2[0][c];
-                for (int k = 1; k < 32; ++k) { s1 += f1[k][c]; s2 += f2[k][c]; }
-                float sc = 0.f, sh = 0.f, mo = 0.f, iv = 0.f;
-                if (c < a.fin.C) {
-                    const double count = a.fin.count;
-                    const double m = s1 / count;
-                    double var = s2 / count - m * m;
-                    if (var < 0.0) var = 0.0;
-                    iv = (float)(1.0 / sqrt(var + (double)a.fin.eps));
-                    sc = a.fin.gamma[c] * iv;
-                    sh = a.fin.beta[c] - (float)m * sc;
-                    mo = (float)m;
-                    if (blockIdx.x == 0 && a.fin.running_mean) {
-                        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                        a.fin.running_mean[c] = (1.f - a.fin.momentum) * a.fin.running_mean[c] + a.fin.momentum * (float)m;
-                        a.fin.running_var[c] = (1.f - a.fin.momentum) * a.fin.running_var[c] + a.fin.momentum * (float)unbiased;
-                    }
-                }
-                sFin[c] = sc; sFin[C64 + c] = sh;
-                if (blockIdx.x == 0) {
-                    a.fin.stats_out[c] = sc; a.fin.stats_out[CP + c] = sh; a.fin.stats_out[2 * CP + c] = mo; a.fin.stats_out[3 * CP + c] = iv;
-                }
-            }
-        } else if (tid < CIN) {
-            sFin[tid] = a.in_scale[tid]; sFin[C64 + tid] = a.in_shift[tid];
-        }
-        __syncthreads();   // (the slice sums are dead from here: the halo buffers are the producers')
-    }
 
     // ---- filter -> LDS (all 512 threads).  The filter is the A operand of the MFMA (D rows = output channels, D
     // columns = pixels), so a lane of the accumulator tile holds ONE pixel and, in its 16 registers, the MFMA rows
@@ -244,8 +190,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         if (XFORM) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sc2[e] = f32x2{sFin[vec * 8 + 2 * e], sFin[vec * 8 + 2 * e + 1]};
-                sh2[e] = f32x2{sFin[C64 + vec * 8 + 2 * e], sFin[C64 + vec * 8 + 2 * e + 1]};
+                sc2[e] = f32x2{a.in_scale[vec * 8 + 2 * e], a.in_scale[vec * 8 + 2 * e + 1]};
+                sh2[e] = f32x2{a.in_shift[vec * 8 + 2 * e], a.in_shift[vec * 8 + 2 * e + 1]};
             }
         }
         static_assert(!(BNBWD && XFORM), "one input transform at a time");
@@ -890,7 +836,6 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
     a.in_shift = in_shift; a.y = (hx_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY; ws_magic(a);
     const int wgs = a.ntiles < 256 ? a.ntiles : 256;
-    a.fin = WmBnFin{};
     a.tiles_per_wg = wm_cdiv(a.ntiles, wgs); a.reverse = 0; a.bw_stats4 = nullptr; a.bw_ld = 0; a.bw_coef = nullptr; a.bw_gvec = nullptr; a.ry = nullptr; a.r_scale = nullptr; a.r_shift = nullptr; a.ay = nullptr; a.dy_out = nullptr;
     const dim3 grid((unsigned)wm_cdiv(a.ntiles, a.tiles_per_wg)), block(512);
     if (in_scale && stat) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, true, true, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
@@ -923,18 +868,8 @@ int WM_HSYM(wm_launch_conv3x3_ws)(const void* x, int ldx, int Cin, int CoutP, co
                            const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
                            hipStream_t s, int reverse, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
                            const float* bw_gvec = nullptr, const void* ry = nullptr, const float* r_scale = nullptr,
-                           const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr, const void* addend = nullptr,
-                           const WmBnFin* fin = nullptr) {
+                           const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr, const void* addend = nullptr) {
     WsArgs a;
-    a.fin = WmBnFin{};
-    if (fin) {   // the consumer finalises the feeding layer's BatchNorm: forward 64-channel-input forms only
-        if (Cin != 64 || in_scale || in_shift || ay || ry || bw_stats4 || !fin->partials || !fin->gamma || !fin->beta || !fin->stats_out ||
-            fin->nparts < 1 || fin->nparts > 256 || fin->CP != 64 || fin->C < 1 || fin->C > 64 || !(fin->count > 0) ||
-            (fin->running_mean == nullptr) != (fin->running_var == nullptr))
-            return WM_E_SHAPE;
-        a.fin = *fin;
-        in_scale = in_shift = fin->stats_out;   // (non-null marks the XFORM forms below; the kernel reads neither when fin.partials is set)
-    }
     a.dbg = g_ws_variant == 3 ? 8 : (g_ws_variant == 8 ? 64 : (g_ws_variant == 10 ? 128 : 0)); a.xcd_map = g_ws_variant != 2;
     a.x = (const hx_t*)x; a.ldx = ldx; a.wp = (const hx_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
     a.in_shift = in_shift; a.y = (hx_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;

@@ -22,44 +22,17 @@ from . import ops
 
 
 class Act:
-    """NHWC activation: logical value = t (if it has no transform) or relu(scale*t+shift).
+    """NHWC activation: logical value = t (if scale is None) or relu(scale*t+shift)."""
+    __slots__ = ("t", "C", "scale", "shift", "bwd", "rev", "src")
 
-    scale / shift are views of the producing layer's statistics tensor.  Round 4: that tensor may still be UNFILLED -- `pending` holds the
-    BatchNorm finalisation (ops.BnFin) that fills it.  A consumer that can run the finalisation inside its own launch takes it with
-    take_pending() (cbr_forward: the forward convolution of a chain's next layer, which saves the finalisation's own launch); everything
-    else simply reads .scale / .shift, which launches the pending finalisation first."""
-    __slots__ = ("t", "C", "_scale", "_shift", "bwd", "rev", "src", "pending", "xform")
-
-    def __init__(self, t, C, scale=None, shift=None, rev=None, src=None, pending=None):
-        self.t, self.C, self._scale, self._shift = t, C, scale, shift
-        self.pending = pending
-        self.xform = scale is not None       # does the logical value carry the BatchNorm + ReLU transform?
+    def __init__(self, t, C, scale=None, shift=None, rev=None, src=None):
+        self.t, self.C, self.scale, self.shift = t, C, scale, shift
         self.bwd = None   # backward: (g, partials, coef or None, g._version) left by the consumer's dgrad when it reduced this layer's BatchNorm sums
         self.src = src    # (bn module, stats [4,CP]) of the ConvBNRelu that produced t (lets the consumer's backward finish this layer's statistics).
                           # NOT the layer's ctx: ctx.out -> Act -> src -> ctx would be a reference cycle, and a cycle keeps a step's 134 MB
                           # tensors alive until Python's cyclic collector runs -- the caching allocator then falls back to hipMalloc mid-step
                           # (measured: 40-60 ms host stalls)
         self.rev = rev    # sweep direction of the conv that just wrote t (False forward, True backward, None: not fresh)
-
-    def _settle(self):
-        p, self.pending = self.pending, None
-        if p is not None:
-            p.run()
-
-    @property
-    def scale(self):
-        self._settle()
-        return self._scale
-
-    @property
-    def shift(self):
-        self._settle()
-        return self._shift
-
-    def take_pending(self):
-        """hand the not-yet-launched finalisation to a consumer that runs it inside its own launch (None if there is none)"""
-        p, self.pending = self.pending, None
-        return p
 
 
 def _opposite(rev):
@@ -152,11 +125,7 @@ def cbr_forward(conv, bn, x, dtype, perm=None, training=True, momentum=0.1):
     wp = _packed(conv, CoutP, CinX, dtype, perm, False)
     bias = conv.bias.data if conv.bias is not None else None
     d = _opposite(x.rev)
-    if ops.conv3x3_fwd_takes_fin(x.t, CoutP, x.pending):
-        # the feeding layer's BatchNorm finalisation runs in this launch's prologue (its statistics tensor is filled by workgroup 0)
-        y, st = ops.conv3x3_fwd(x.t, wp, bias, None, None, want_stats=training, reverse=d, fin=x.take_pending())
-    else:
-        y, st = ops.conv3x3_fwd(x.t, wp, bias, x.scale, x.shift, want_stats=training, reverse=d)
+    y, st = ops.conv3x3_fwd(x.t, wp, bias, x.scale, x.shift, want_stats=training, reverse=d)
     return cbr_finish(conv, bn, x, y, st, d, perm, training, momentum)
 
 
@@ -165,13 +134,7 @@ def cbr_finish(conv, bn, x, y, st, d, perm=None, training=True, momentum=0.1):
     Cout = conv.weight.shape[0]
     CoutP = y.shape[-1]
     B, H, W, _ = y.shape
-    pending = None
-    if training and lazy_bn_finalize() and st.shape[0] <= 256:
-        # not launched yet: the consumer of this layer's output may run it inside its own launch (Act.pending)
-        pending = ops.BnFin(st, Cout, CoutP, B * H * W, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
-                            momentum if bn.momentum is None else bn.momentum, bn.eps)
-        stats = pending.stats
-    elif training:
+    if training:
         stats = ops.bn_finalize(st, Cout, CoutP, B * H * W, bn.weight.data, bn.bias.data, bn.running_mean,
                                 bn.running_var, momentum if bn.momentum is None else bn.momentum, bn.eps)
     else:
@@ -184,20 +147,8 @@ def cbr_finish(conv, bn, x, y, st, d, perm=None, training=True, momentum=0.1):
         stats[3, :Cout] = invstd
     ctx = CBRCtx()
     ctx.x, ctx.y, ctx.stats, ctx.perm, ctx.training = x, y, stats, perm, training
-    ctx.out = Act(y, Cout, stats[0], stats[1], rev=d, src=(bn, stats), pending=pending)
+    ctx.out = Act(y, Cout, stats[0], stats[1], rev=d, src=(bn, stats))
     return ctx.out, ctx
-
-
-_LAZY_BN = True
-
-
-def lazy_bn_finalize(on=None):
-    """switch (default on): cbr_finish leaves a training-mode BatchNorm finalisation to the consumer of the layer's output (Act.pending).
-    lazy_bn_finalize(False) launches it on the spot, as rounds 1-3 did (A/B, tests)."""
-    global _LAZY_BN
-    if on is not None:
-        _LAZY_BN = bool(on)
-    return _LAZY_BN
 
 
 def fin_rider(x, part, grads, accumulate):

@@ -64,7 +64,7 @@ class Encoder(nn.Module, engine.FlatModule):
             a, cx = engine.cbr_forward(blk.layers[0], blk.layers[1], a, dt, training=training)
             ctx.layers.append(cx)
         blk = self.after_concat_layer
-        ctx.split = (self.split_concat and dt in (torch.bfloat16, torch.float16) and c == 64 and a.t.shape[-1] == 64 and a.xform
+        ctx.split = (self.split_concat and dt in (torch.bfloat16, torch.float16) and c == 64 and a.t.shape[-1] == 64 and a.scale is not None
                      and self.H >= 2 and self.W >= 2)
         if ctx.split:
             # encoder.py:34-41 without materialising the concat: P = conv3(image) + bias + message term (one store-bound pass),
@@ -73,10 +73,7 @@ class Encoder(nn.Module, engine.FlatModule):
             P = ops.concat_side_fwd(image, conv.weight.data, conv.bias.data, message, dt, 0, L, L + c)
             wp = engine._packed(conv, 64, 64, dt, self._fperm, False)
             d = engine._opposite(a.rev)
-            if ops.conv3x3_fwd_takes_fin(a.t, 64, a.pending):   # the last body layer's BatchNorm finalisation inside this launch
-                y, st = ops.conv3x3_fwd_addin(a.t, wp, None, None, P, reverse=d, fin=a.take_pending())
-            else:
-                y, st = ops.conv3x3_fwd_addin(a.t, wp, a.scale, a.shift, P, reverse=d)
+            y, st = ops.conv3x3_fwd_addin(a.t, wp, a.scale, a.shift, P, reverse=d)
             a5, ctx.cat_ctx = engine.cbr_finish(conv, bn, a, y, st, d, None, training)
             ctx.message, ctx.image = message, image
         else:

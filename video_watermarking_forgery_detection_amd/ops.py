@@ -269,43 +269,6 @@ class _WmBnBwdFin(ctypes.Structure):   # include/wm_hip.h: WmBnBwdFin
                 ("dbeta", ctypes.c_void_p), ("accumulate", ctypes.c_int), ("coef", ctypes.c_void_p)]
 
 
-class _WmBnFin(ctypes.Structure):   # include/wm_hip.h: WmBnFin
-    _fields_ = [("partials", ctypes.c_void_p), ("nparts", ctypes.c_int), ("C", ctypes.c_int), ("CP", ctypes.c_int), ("count", ctypes.c_double),
-                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p),
-                ("momentum", ctypes.c_float), ("eps", ctypes.c_float), ("stats_out", ctypes.c_void_p)]
-
-
-class BnFin:
-    """the arguments of bn_finalize, not yet launched: a forward BatchNorm finalisation that the kernel consuming the layer's output may
-    run in its own prologue (conv3x3_fwd(..., fin=) / conv3x3_fwd_addin(..., fin=)), or that run() launches the usual way.  `stats`
-    [4,CP] (scale, shift, mean, invstd) is allocated here and filled by whichever does it."""
-    __slots__ = ("partials", "C", "CP", "count", "gamma", "beta", "running_mean", "running_var", "momentum", "eps", "stats")
-
-    def __init__(self, partials, C, CP, count, gamma, beta, running_mean, running_var, momentum, eps):
-        self.partials, self.C, self.CP, self.count = partials, C, CP, count
-        self.gamma, self.beta, self.running_mean, self.running_var, self.momentum, self.eps = gamma, beta, running_mean, running_var, momentum, eps
-        self.stats = torch.empty(4, CP, device=partials.device, dtype=torch.float32)
-
-    def run(self):
-        bn_finalize(self.partials, self.C, self.CP, self.count, self.gamma, self.beta, self.running_mean, self.running_var, self.momentum, self.eps,
-                    out=self.stats)
-        return self.stats
-
-    def struct(self):
-        assert self.partials.is_contiguous() and self.partials.shape[0] <= 256 and self.partials.shape[2] == self.CP
-        return _WmBnFin(partials=self.partials.data_ptr(), nparts=self.partials.shape[0], C=self.C, CP=self.CP, count=float(self.count),
-                        gamma=self.gamma.data_ptr(), beta=self.beta.data_ptr(),
-                        running_mean=0 if self.running_mean is None else self.running_mean.data_ptr(),
-                        running_var=0 if self.running_var is None else self.running_var.data_ptr(), momentum=float(self.momentum),
-                        eps=float(self.eps), stats_out=self.stats.data_ptr())
-
-
-def conv3x3_fwd_takes_fin(x, CoutP, fin):
-    """can the forward conv of x (the raw output of the layer `fin` belongs to) run that layer's BatchNorm finalisation itself?"""
-    return (fin is not None and x.shape[-1] == 64 and fin.CP == 64 and fin.partials.shape[0] <= 256 and x.is_contiguous()
-            and bool(_lib.lib().wm_conv3x3_fwd_fin_supported(c_int(64), c_int(CoutP), c_int(dt_id(x.dtype)))))
-
-
 def fin_rider_enabled():
     return bool(_lib.lib().wm_fin_rider_enabled())
 
@@ -331,9 +294,8 @@ def _sweep(reverse):
     return c_int(1 if reverse else 0)
 
 
-def conv3x3_fwd(x, wp, bias, in_scale, in_shift, want_stats, Cin=None, reverse=False, fin=None):
-    """x [B,H,W,ld]; wp [9,CoutP,Cin]; returns y [B,H,W,CoutP] and stat partials (or None).  fin (a BnFin accepted by
-    conv3x3_fwd_takes_fin) instead of in_scale / in_shift: the launch finalises the feeding layer's BatchNorm itself and fills fin.stats."""
+def conv3x3_fwd(x, wp, bias, in_scale, in_shift, want_stats, Cin=None, reverse=False):
+    """x [B,H,W,ld]; wp [9,CoutP,Cin]; returns y [B,H,W,CoutP] and stat partials (or None)."""
     _need_cuda(x, wp)
     B, H, W, ldx = x.shape
     CoutP, CinW = wp.shape[1], wp.shape[2]
@@ -341,15 +303,7 @@ def conv3x3_fwd(x, wp, bias, in_scale, in_shift, want_stats, Cin=None, reverse=F
     assert Cin == CinW and Cin <= ldx
     y = torch.empty(B, H, W, CoutP, device=x.device, dtype=x.dtype)
     st = torch.empty(conv3x3_nparts(B, H, W, Cin, CoutP, x.dtype), 2, CoutP, device=x.device, dtype=torch.float32) if want_stats else None
-    info = {"B": B, "H": H, "W": W, "Cin": Cin, "CoutP": CoutP, "xform": in_scale is not None or fin is not None, "dtype": x.dtype}
-    if fin is not None:
-        assert in_scale is None and in_shift is None and Cin == 64 and ldx == 64
-        fs = fin.struct()
-        rc = _timed("conv3x3_fwd", info, lambda: _lib.lib().wm_conv3x3_fwd_fin(
-            _p(x), _p(wp), _p(bias), c_int(0 if bias is None else bias.numel()), ctypes.byref(fs), _p(y), _p(st), c_int(B), c_int(H), c_int(W),
-            c_int(CoutP), c_int(dtype_id(x)), _sweep(reverse), _stream()))
-        _lib.check(rc, "wm_conv3x3_fwd_fin")
-        return y, st
+    info = {"B": B, "H": H, "W": W, "Cin": Cin, "CoutP": CoutP, "xform": in_scale is not None, "dtype": x.dtype}
     rc = _timed("conv3x3_fwd", info, lambda: _lib.lib().wm_conv3x3_fwd(
         _p(x), c_int(ldx), _p(wp), _p(bias), c_int(0 if bias is None else bias.numel()), _p(in_scale), _p(in_shift),
         _p(y), c_int(CoutP), _p(st), c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(CoutP), c_int(dtype_id(x)), _sweep(reverse), _stream()))
@@ -357,22 +311,15 @@ def conv3x3_fwd(x, wp, bias, in_scale, in_shift, want_stats, Cin=None, reverse=F
     return y, st
 
 
-def conv3x3_fwd_addin(x, wp, in_scale, in_shift, addend, reverse=False, fin=None):
+def conv3x3_fwd_addin(x, wp, in_scale, in_shift, addend, reverse=False):
     """dense 64 -> 64 forward conv (16-bit dtypes) whose epilogue adds `addend` [B,H,W,64] before the BatchNorm statistics:
-    y = conv3x3(relu(in_scale*x + in_shift), wp) + addend.  Returns (y, stat partials).  fin: as conv3x3_fwd."""
+    y = conv3x3(relu(in_scale*x + in_shift), wp) + addend.  Returns (y, stat partials)."""
     _need_cuda(x, wp, addend)
     B, H, W, C = x.shape
     assert C == 64 and tuple(wp.shape) == (9, 64, 64) and addend.shape == x.shape and addend.dtype == x.dtype and x.is_contiguous() and addend.is_contiguous()
     y = torch.empty_like(x)
     st = torch.empty(conv3x3_nparts(B, H, W, 64, 64, x.dtype), 2, 64, device=x.device, dtype=torch.float32)
     info = {"B": B, "H": H, "W": W, "Cin": 64, "CoutP": 64, "xform": True, "dtype": x.dtype, "addin": True}
-    if fin is not None:
-        assert in_scale is None and in_shift is None
-        fs = fin.struct()
-        rc = _timed("conv3x3_fwd", info, lambda: _lib.lib().wm_conv3x3_fwd_addin_fin(_p(x), _p(wp), ctypes.byref(fs), _p(addend), _p(y), _p(st), c_int(B),
-                                                                                     c_int(H), c_int(W), c_int(dtype_id(x)), _sweep(reverse), _stream()))
-        _lib.check(rc, "wm_conv3x3_fwd_addin_fin")
-        return y, st
     rc = _timed("conv3x3_fwd", info, lambda: _lib.lib().wm_conv3x3_fwd_addin(_p(x), _p(wp), _p(in_scale), _p(in_shift), _p(addend), _p(y), _p(st), c_int(B),
                                                                              c_int(H), c_int(W), c_int(dtype_id(x)), _sweep(reverse), _stream()))
     _lib.check(rc, "wm_conv3x3_fwd_addin")
@@ -408,10 +355,9 @@ def concat_side_msg_wgrad(dy, msg, dw, accumulate, c_msg, L):
     _lib.check(rc, "wm_concat_side_msg_wgrad")
 
 
-def bn_finalize(partials, C, CP, count, gamma, beta, running_mean, running_var, momentum, eps, out=None):
+def bn_finalize(partials, C, CP, count, gamma, beta, running_mean, running_var, momentum, eps):
     dev = partials.device
-    if out is None:
-        out = torch.empty(4, CP, device=dev, dtype=torch.float32)  # scale, shift, mean, invstd
+    out = torch.empty(4, CP, device=dev, dtype=torch.float32)  # scale, shift, mean, invstd
     rc = _lib.lib().wm_bn_finalize(_p(partials), c_int(partials.shape[0]), c_int(C), c_int(CP), c_double(count), _p(gamma),
                                    _p(beta), _p(running_mean), _p(running_var), c_float(momentum), c_float(eps),
                                    _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _stream())
