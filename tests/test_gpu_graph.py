@@ -42,6 +42,8 @@ def test_captured_step_equals_eager_bit_for_bit(case):
     def noise():
         if name == "Resize":
             class Fixed:   # Resize with its ratio pinned: the random draw is a host decision and would be baked into the graph
+                capturable = True
+
                 def __init__(self):
                     self.l = NL.Resize()
                 def fwd(self, x):
@@ -108,7 +110,12 @@ def test_graph_mode_refuses_nothing_silently():
     for _ in range(4):
         h.train_on_batch([images, messages])
     assert h._graphs == {}
-    assert NL is not None
+    # ... and so is a layer that draws its arguments on the host (Resize's ratio, Crop's rectangle): a capture would freeze one draw
+    for layer in (NL.Resize(), NL.Crop(), NL.Combined([NL.Jpeg(50), NL.JpegSS(50)])):
+        h = _make(32, layer, torch.float32).enable_graph()
+        for _ in range(4):
+            h.train_on_batch([images, messages])
+        assert h._graphs == {}, type(layer).__name__
 
 
 @pytest.mark.parametrize("case", [("Jpeg50", torch.bfloat16, 256, 16), ("Identity", torch.bfloat16, 128, 8), ("JpegSS50", torch.float32, 64, 4),
@@ -125,6 +132,8 @@ def test_two_chain_step_equals_one_stream_bit_for_bit(case):
             return NL.Identity()
         if name == "Crop":
             class Fixed:
+                capturable = True
+
                 def __init__(self):
                     self.l = NL.Crop()
                 def fwd(self, x):

@@ -399,8 +399,10 @@ class Hidden:
 
     def enable_graph(self, on=True):
         """replay the step from a hipGraph instead of enqueueing its ~190 launches every call (same results bit for bit: _StepGraph).
-        Used for plain train_on_batch(batch) calls on one GPU with an attack layer that has an explicit fwd / bwd; a call with
-        extra_encoded_grad / clip / enc_gate, with a grad_sync, or while a kernel timer is installed runs eagerly as before."""
+        Used for plain train_on_batch(batch) calls on one GPU with an attack layer that has an explicit fwd / bwd and declares itself
+        `capturable` (the same launches with the same arguments every call: the Jpeg family, GaussianBlur, MiddleBlur, Identity -- not the
+        layers that draw their arguments on the host, Resize / Crop / Combined); a call with extra_encoded_grad / clip / enc_gate, with a
+        grad_sync, or while a kernel timer is installed runs eagerly as before."""
         self._graphs = {} if on else None
         return self
 
@@ -437,7 +439,7 @@ class Hidden:
         messages = messages.to(self.device, torch.float32).contiguous()
         n = self.encoder_decoder.noiser
         if (self._graphs is not None and extra_encoded_grad is None and clip is None and enc_gate is None and self.grad_sync is None
-                and not ops.kernel_timer_installed() and hasattr(n, "fwd") and hasattr(n, "bwd")
+                and not ops.kernel_timer_installed() and hasattr(n, "fwd") and hasattr(n, "bwd") and getattr(n, "capturable", False)
                 and not torch.cuda.is_current_stream_capturing()):
             key = (tuple(images.shape), tuple(messages.shape), self.noise_id, self.keep_dead_discriminator_grads, self.lazy_losses, self.two_streams, self.skip_zero_attack_gradient,
                    self.encoder_decoder.encoder.compute_dtype)

@@ -127,6 +127,9 @@ class IRNrhiModel(BaseModel):
             from ..distributed import GradSync
             grad_sync = GradSync()
         self.hidden = Hidden(cfg, self.device, self.attack, None, compute_dtype=dtype, grad_sync=grad_sync, amp=self.amp)
+        # train.two_streams (default true): the step's two independent chains on two streams wherever a step has them to itself (one GPU, no
+        # localisation branch / clipping / PSNR gate: Hidden._train_step_two_chains); same results bit for bit
+        self.hidden.two_streams = bool(_get(train_opt, 'two_streams', default=True))
         self.netG = self.hidden.encoder_decoder
         self.discriminator = self.hidden.discriminator
         lr = _get(train_opt, 'lr_G', default=1e-3)

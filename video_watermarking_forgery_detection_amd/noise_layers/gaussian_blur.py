@@ -33,6 +33,8 @@ class _StencilFn(torch.autograd.Function):
 
 
 class GaussianBlur(nn.Module):
+    capturable = True    # deterministic launches: Hidden.enable_graph may capture a step through this layer
+
     def __init__(self, kernel_size=3, channels=3):
         super(GaussianBlur, self).__init__()
         if kernel_size != 3:

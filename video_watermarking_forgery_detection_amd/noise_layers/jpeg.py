@@ -39,6 +39,8 @@ class _JpegFn(torch.autograd.Function):
 class JpegBasic(nn.Module):
     _mode = ops.JPEG_ROUND
     _prefix = "Jpeg"
+    capturable = True    # fwd / bwd launch the same kernels with the same arguments every call (no host-side randomness): a training step
+                         # through this layer may be captured into a hipGraph (Hidden.enable_graph)
 
     def __init__(self, Q=50, subsample=0):
         super(JpegBasic, self).__init__()

@@ -24,6 +24,8 @@ class _MedianFn(torch.autograd.Function):
 
 
 class MiddleBlur(nn.Module):
+    capturable = True    # deterministic launches: Hidden.enable_graph may capture a step through this layer
+
     def __init__(self, kernel):
         super(MiddleBlur, self).__init__()
         if kernel not in (3, 5):
