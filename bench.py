@@ -173,7 +173,7 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-PMC_FILE = "r03_pmc_traffic.json"
+PMC_FILE = "r04_pmc_traffic.json"
 GRAPH_DEFAULT = True          # --graph / --no-graph: the step replayed from a hipGraph (one GPU; N > 1 runs eagerly around the all-reduces)
 TWO_STREAMS_DEFAULT = True    # --two-streams / --one-stream: the step's two independent chains on two streams
 _pmc = {}
@@ -182,7 +182,7 @@ _pmc = {}
 def pmc_traffic(args, S, B, key="hbm_bytes_per_launch"):
     """HBM bytes per launch of the dominant kernel (key: of the runner-up), from this round's committed PMC passes: same workload, same
     kernel sources only (else None)."""
-    if args.dtype != "bf16" or S != 256 or B != 16 or args.keep_dead_grads:
+    if args.dtype != "bf16" or S != 256 or B != 16 or args.keep_dead_grads or args.noise != "Jpeg50":
         return None
     if not _pmc:
         try:

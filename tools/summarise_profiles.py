@@ -8,7 +8,7 @@ import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_final")
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 os.makedirs(dst, exist_ok=True)
 NXCD, NCU, NSIMD = 8, 256, 4
 
@@ -52,7 +52,12 @@ def traffic_tables(fetch_sub, write_sub, base):
     return out
 
 
-avg_ns = stats_summary("stats", f"{tag}_bench_c2_kernel_stats", 13.0, "python3 bench.py --no-cpu-baseline --steps 10 --warmup 3")
+avg_ns = stats_summary("stats", f"{tag}_bench_c2_kernel_stats", 13.0, "python3 bench.py --no-cpu-baseline --no-extra --one-stream --no-graph --steps 10 --warmup 3   (the step's launches one after the other: every kernel alone on the chip)")
+try:
+    stats_summary("stats2", f"{tag}_bench_c2_two_chains_graph_kernel_stats", 13.0, "python3 bench.py --no-cpu-baseline --no-extra --steps 10 --warmup 3   (bench.py's default: two chains on two streams, replayed from a hipGraph -- a kernel's duration here includes the time it shares the chip with a launch of the other chain)")
+    os.remove(os.path.join(dst, f"{tag}_bench_c2_two_chains_graph_kernel_stats.csv"))
+except (ValueError, IndexError, OSError) as e:
+    print("missing: stats2", e)
 tr = traffic_tables("pmc_fetch", "pmc_write", f"{tag}_bench_c2")
 
 # ---- MFMA utilisation per kernel and for the whole step
@@ -70,7 +75,7 @@ for k, v in m.items():
 rows.sort(reverse=True)
 step_util = tot_busy / (tot_act / NXCD * NCU * NSIMD)
 with open(os.path.join(dst, f"{tag}_bench_c2_pmc_mfma.csv"), "w") as g:
-    g.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1\n")
+    g.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --no-cpu-baseline --no-extra --one-stream --no-graph --steps 3 --warmup 1\n")
     g.write(f"# whole run (every kernel of 4 training steps): MFMA utilisation {step_util:.4f}\n")
     g.write("kernel,dispatches,mean_SQ_VALU_MFMA_BUSY_CYCLES,mean_GRBM_GUI_ACTIVE,mfma_util\n")
     for busy, k, n, mb, ma, u in rows:
@@ -136,7 +141,9 @@ for name, out in (("c3_c5_steps.jsonl", f"{tag}_c3_c5_steps.jsonl"), ("literal_s
                   ("bwd_phase_cycles.txt", f"{tag}_bwd_phase_cycles.txt"), ("mfma_coissue_micro.txt", f"{tag}_mfma_coissue_micro.txt"),
                   ("bench_512_b8.json", f"{tag}_bench_512_b8.json"), ("bench_c2.json", f"{tag}_bench_c2.json"),
                   ("bench_c2_keep_dead_grads.json", f"{tag}_bench_c2_keep_dead_grads.json"), ("bwd_sq_counters.txt", f"{tag}_bwd_sq_counters.txt"),
-                  ("bwd8_phase_cycles.txt", f"{tag}_bwd8_phase_cycles.txt")):
+                  ("bwd8_phase_cycles.txt", f"{tag}_bwd8_phase_cycles.txt"), ("fwd_sq_counters.txt", f"{tag}_fwd_sq_counters.txt"),
+                  ("fwd_phase_cycles.txt", f"{tag}_fwd_phase_cycles.txt"), ("two_chains.txt", f"{tag}_two_chains.txt"),
+                  ("step_modes.txt", f"{tag}_step_modes.txt"), ("step_trace_one_stream.txt", f"{tag}_step_trace_one_stream.txt")):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 0:
         shutil.copy(f, os.path.join(dst, out))
@@ -149,11 +156,11 @@ if os.path.exists(_sq) and os.path.exists(_sq1):
     with open(_sq, "a") as g:
         g.write("\n" + open(_sq1).read())
 for sub, base, steps, cmd in (("lit_stats", f"{tag}_literal_step_kernel_stats", 8.0, "python3 tools/bench_literal.py 4 bf16 6   (8 steps: the reference's literal IRNrhi step, 24 frames 256x256, bf16)"),
-                              ("s512_stats", f"{tag}_bench_512_b8_kernel_stats", 13.0, "python3 bench.py --no-cpu-baseline --size 512 --batch 8 --steps 10 --warmup 3   (13 steps of 8 frames 512x512)"),
+                              ("s512_stats", f"{tag}_bench_512_b8_kernel_stats", 13.0, "python3 bench.py --no-cpu-baseline --no-extra --one-stream --no-graph --size 512 --batch 8 --steps 10 --warmup 3   (13 steps of 8 frames 512x512, one stream)"),
                               ("c5_stats", f"{tag}_c5_fp16_kernel_stats", 42.0, "python3 tools/bench_c5.py train_hidden_c5_fp16.yml f16 44   (42 steps with work, 16 frames 256x256 each, UNet head, f16 + device GradScaler)")):
     try:
         stats_summary(sub, base, steps, cmd)
         os.remove(os.path.join(dst, base + ".csv"))   # (the summary is what is cited; the full CSVs of the benchmarked step are kept above)
-    except (IndexError, OSError) as e:
+    except (ValueError, IndexError, OSError) as e:
         print("missing:", sub, e)
 print(json.dumps(res, indent=1)[:1500])
