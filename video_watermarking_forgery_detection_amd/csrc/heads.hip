@@ -63,19 +63,16 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ y, 
             }
             // act16 (round 4): the same pixel once more as the 16-channel NHWC pixel the image-fed first layers read (channels 0..COUT-1,
             // zero tail) -- what wm_nchw_to_nhwc would make of `out` in a launch of its own; every lane of the pixel's group holds all sums
-            if (act16 && valid[u] && vv == 0) {
+            if (act16 && valid[u] && vv < 16 / VE) {   // lane vv of the pixel's group writes the pixel's vv-th 16-byte piece: one store
+                vec16<T> o;                            // instruction covers the wave's 8 adjacent pixels (256 contiguous bytes at 16 bits)
 #pragma unroll
-                for (int k = 0; k < 16 / VE; ++k) {
-                    vec16<T> o;
+                for (int e = 0; e < VE; ++e) {
+                    float val = 0.f;
 #pragma unroll
-                    for (int e = 0; e < VE; ++e) {
-                        float val = 0.f;
-#pragma unroll
-                        for (int co = 0; co < COUT; ++co) val = (k * VE + e == co) ? part[co] + bias[co] : val;
-                        o.set(e, val);
-                    }
-                    *reinterpret_cast<vec16<T>*>(act16 + p * 16 + k * VE) = o;
+                    for (int co = 0; co < COUT; ++co) val = (vv * VE + e == co) ? part[co] + bias[co] : val;
+                    o.set(e, val);
                 }
+                *reinterpret_cast<vec16<T>*>(act16 + p * 16 + vv * VE) = o;
             }
         }
     }
@@ -289,15 +286,20 @@ __global__ __launch_bounds__(256) void pooled_head_kernel(const float* __restric
                                                           double count, const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                           float* __restrict__ coef) {
-    __shared__ float s_pool[PH_MAX_BC], s_w[PH_MAX_OI], s_logit[PH_MAX_BO], s_g[PH_MAX_BO], s_gv[PH_MAX_BC];
+    __shared__ float s_pool[PH_MAX_BC], s_w[PH_MAX_OI], s_logit[PH_MAX_BO], s_g[PH_MAX_BO], s_gv[PH_MAX_BC], s_np[PH_MAX_BC], s_ys[PH_MAX_BC], s_msg[PH_MAX_BO];
     __shared__ float s_red[2][4];
     const int tid = threadIdx.x;
     const float* pooled = out3;                       // plane 0 [B][CP]
     const float* npos = out3 + (size_t)B * CP;        // plane 1
     const float* ysum = out3 + (size_t)2 * B * CP;    // plane 2
     if (gscale_dev) gscale *= gscale_dev[0];
+    // every global operand of every stage is fetched here, all loads in flight together (the stages then run out of the LDS: a stage that
+    // loaded inside its loop paid one L2 round trip per trip -- 16 us for the whole kernel instead of 6)
     for (int i = tid; i < B * I; i += 256) s_pool[i] = pooled[(size_t)(i / I) * CP + (i % I)];
     for (int i = tid; i < O * I; i += 256) s_w[i] = w[i];
+    for (int i = tid; i < B * CP; i += 256) { s_np[i] = npos[i]; s_ys[i] = ysum[i]; }
+    if (kind == 1)
+        for (int i = tid; i < B * O; i += 256) s_msg[i] = messages[i];
     __syncthreads();
     for (int idx = tid; idx < B * O; idx += 256) {
         const int b = idx / O, o = idx - b * O;
@@ -315,9 +317,9 @@ __global__ __launch_bounds__(256) void pooled_head_kernel(const float* __restric
             a1 += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
             s_g[i] = (1.f / (1.f + expf(-v)) - target) * gscale / (float)n;
         } else {
-            const float df = v - messages[i];
+            const float df = v - s_msg[i];
             a1 += df * df;
-            a2 += fabsf(fminf(fmaxf(rintf(v), 0.f), 1.f) - messages[i]);
+            a2 += fabsf(fminf(fmaxf(rintf(v), 0.f), 1.f) - s_msg[i]);
             s_g[i] = df * gscale;
         }
     }
@@ -356,8 +358,8 @@ __global__ __launch_bounds__(256) void pooled_head_kernel(const float* __restric
             double p1 = 0.0, p2 = 0.0;
             for (int p = sl; p < B; p += 32) {
                 const float gv = s_gv[p * CP + c];
-                p1 += (double)(gv * npos[(size_t)p * CP + c]);
-                p2 += (double)(gv * ysum[(size_t)p * CP + c]);
+                p1 += (double)(gv * s_np[p * CP + c]);
+                p2 += (double)(gv * s_ys[p * CP + c]);
             }
             t1 = sl == 0 ? p1 : t1 + p1;
             t2 = sl == 0 ? p2 : t2 + p2;
