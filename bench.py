@@ -215,11 +215,18 @@ def timed_steps(h, batch, steps, warmup, barrier, world, dev, timer=None, every=
     over ranks) -> seconds.  timer: an ops.KernelTimer switched on for every `every`-th timed step"""
     import torch.distributed as dist
     from video_watermarking_forgery_detection_amd import ops
-    for _ in range(warmup):
+    ts = h.two_streams
+    for w in range(warmup):
+        cold = w == 0 and timer is not None     # (as the headline loop's warm-up: one step on the bracketed steps' path)
+        if cold:
+            ops.set_kernel_timer(ops.KernelTimer(lambda name, i: name == "conv3x3_bwd_fused"))
+            h.two_streams = False
         h.train_on_batch(batch)
+        if cold:
+            ops.set_kernel_timer(None)
+            h.two_streams = ts
     barrier()
     t0 = time.perf_counter()
-    ts = h.two_streams
     for i in range(steps):
         bracket = timer is not None and i % every == 0
         ops.set_kernel_timer(timer if bracket else None)
@@ -326,8 +333,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
+        # the first warm-up step takes the path of the timed region's bracketed steps (one stream, eagerly, kernel events on): its buffers come
+        # from the main stream's pool, which the replayed / two-chain steps never touch -- left cold, the first bracketed step of the timed
+        # region pays the allocator's hipMallocs (~10 ms, once)
+        bracket = w == 0 and (use_graph or two_streams)
+        if bracket:
+            ops.set_kernel_timer(ops.KernelTimer(lambda name, i: name in ("conv3x3_bwd_fused", "conv3x3_fwd", "jpeg_fwd", "jpeg_bwd")))
+            h.two_streams = False
         h.train_on_batch([images, messages])
+        if bracket:
+            ops.set_kernel_timer(None)
+            h.two_streams = two_streams
     if sync is not None:
         sync.report()   # (drop the warm-up's entries)
     # the two heaviest kernels: the one-pass backward of the 64->64 body layers (13 launches / step, 16-bit activations only) and the

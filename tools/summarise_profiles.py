@@ -164,3 +164,71 @@ for sub, base, steps, cmd in (("lit_stats", f"{tag}_literal_step_kernel_stats", 
     except (ValueError, IndexError, OSError) as e:
         print("missing:", sub, e)
 print(json.dumps(res, indent=1)[:1500])
+
+
+# ---- the measurement table of DESIGN.md section 5 / README, generated from the files above so that the prose cannot drift from them
+def _load(name):
+    try:
+        return json.load(open(os.path.join(dst, name)))
+    except (OSError, ValueError):
+        return None
+
+
+def emit_measurements_md():
+    b = _load(f"{tag}_bench_c2.json")
+    if not b:
+        print("no bench_c2.json: measurements table not written")
+        return
+    pm = res
+    L = []
+    A = L.append
+    A(f"<!-- generated by tools/summarise_profiles.py {tag} from profiles/{tag}_*: do not edit by hand -->")
+    A("| quantity | value (files under `profiles/`) |")
+    A("|---|---|")
+    A(f"| step time / throughput, C2 as `bench.py` runs it by default (two chains on two streams, replayed from a hipGraph; every {b.get('kernel_events_every')}th step enqueued on one stream with its kernels bracketed by events) | **{b['ms_per_step']:.3f} ms → {b['value']:.0f} frames/s** (`{tag}_bench_c2.json`; step events: median {b['ms_per_step_median_events']:.3f} ms, fastest {b['ms_per_step_min_events']:.3f} ms); host enqueue per replayed step {b['host_enqueue_ms_median']:.2f} ms" + (f", per eager step {b['host_enqueue_ms_median_eager_steps']:.2f} ms" if b.get('host_enqueue_ms_median_eager_steps') else "") + " |")
+    try:
+        modes = open(os.path.join(dst, f"{tag}_step_modes.txt")).read().strip().splitlines()
+        A("| the step's four modes, same box, interleaved, two rounds (`" + f"{tag}_step_modes.txt" + "`) | " + "<br>".join(m.replace("|", "/") for m in modes) + " |")
+    except OSError:
+        pass
+    A(f"| FLOPs as executed / time against 2.5 PFLOP/s dense bf16 | {b['step_gflop_per_frame']:.1f} GFLOP per frame → **{100 * b['step_flops_frac_of_peak']:.1f} %** of peak |")
+    rs, c4 = b.get("reference_state"), b.get("c4_shard_512")
+    if rs:
+        A(f"| `reference_state` (same invocation: every launch of the reference's autograd, 249.0 GFLOP per frame) | {rs['ms_per_step']:.3f} ms → {rs['value']:.0f} frames/s = {100 * rs['step_flops_frac_of_peak']:.1f} % of peak |")
+    if c4:
+        r4 = c4.get("roofline") or {}
+        A(f"| `c4_shard_512` (same invocation: 512×512, 8 frames per GPU) | {c4['ms_per_step']:.3f} ms → {c4['value']:.0f} frames/s = {100 * c4['step_flops_frac_of_peak']:.1f} % of peak; dominant kernel {1e3 * r4.get('avg_launch_ms', 0):.1f} µs = {r4.get('frac', 0):.3f} of the HBM roof by algorithmic bytes |")
+    A(f"| MFMA utilisation as the counters report it, whole step (`{tag}_bench_c2_pmc_mfma.csv`, one-stream order) | **{100 * pm['step_mfma_util']:.1f} %** |")
+    bf, fw = pm.get("bwd_fused"), pm.get("fwd")
+    if bf:
+        alg = 4 * 16 * 256 * 256 * 64 * 2
+        A(f"| dominant kernel `bwd_ws8_kernel<true,false>` (11 + 2 launches per step) | rocprofv3 {bf['avg_us_rocprof']:.1f} µs per launch (bench's own events: {1e3 * b['roofline']['avg_launch_ms']:.1f} µs on its box); algorithmic {alg / 1e6:.1f} MB → {alg / bf['avg_us_rocprof'] / 1e6:.2f} TB/s = **{alg / bf['avg_us_rocprof'] / 1e6 / 8:.3f} of 8 TB/s**; 154.6 GFLOP → {154.6188 / bf['avg_us_rocprof']:.3f} PFLOP/s = {154.6188 / bf['avg_us_rocprof'] / 2.5:.3f} of the MFMA peak; PMC traffic {bf['hbm_bytes_per_launch'] / 1e6:.1f} MB = **{bf['hbm_bytes_per_launch'] / alg:.3f} × algorithmic** (FETCH {bf['FETCH_SIZE_KB'] * 1024 / 1e6:.1f} MB × 2 + WRITE {bf['WRITE_SIZE_KB'] * 1024 / 1e6:.1f} MB); matrix pipe busy {100 * bf['mfma_util']:.1f} % |")
+    if fw:
+        A(f"| forward 64→64 conv (15 + 1 launches per step) | rocprofv3 {fw['avg_us_rocprof']:.1f} µs per launch; 77.3 GFLOP → {77.3094 / fw['avg_us_rocprof']:.3f} PFLOP/s = {77.3094 / fw['avg_us_rocprof'] / 2.5:.3f} of peak; PMC traffic {fw['hbm_bytes_per_launch'] / 1e6:.1f} MB = {fw['hbm_bytes_per_launch'] / 268435456.0:.3f} × algorithmic; matrix pipe busy {100 * fw['mfma_util']:.1f} % |")
+    # time by kernel family from the one-stream kernel stats
+    fam = collections.OrderedDict((k, 0.0) for k in ("one-pass backward 64→64 (bwd_ws8)", "forward conv 64→64", "other convolutions / input gradients", "image-fed first layers (forward, weight gradient, one-pass backward)",
+                                                     "weight gradients outside the one-pass kernel", "slab reductions", "BatchNorm finalisations", "pools, heads (1×1, pooled head)", "concat side kernels", "rest (layout, attack, losses, Adam, packs, copies)"))
+    tot = 0.0
+    for r in csv.DictReader(open(os.path.join(dst, f"{tag}_bench_c2_kernel_stats.csv"))):
+        n, ms = r["Name"], float(r["TotalDurationNs"]) / 1e6 / 13.0
+        tot += ms
+        if "bwd_ws8" in n: k = "one-pass backward 64→64 (bwd_ws8)"
+        elif "conv3x3_ws_kernel<64, 64, true, true" in n: k = "forward conv 64→64"
+        elif "conv3x3_ws_kernel<16" in n or "wgrad_ws16_kernel<16" in n or "bwd_ws16" in n: k = "image-fed first layers (forward, weight gradient, one-pass backward)"
+        elif "conv3x3_ws_kernel" in n or "conv3x3_kernel" in n: k = "other convolutions / input gradients"
+        elif "wgrad_ws16_kernel" in n or "wgrad_kernel" in n: k = "weight gradients outside the one-pass kernel"
+        elif "wgrad_reduce" in n: k = "slab reductions"
+        elif "finalize" in n or "tree_reduce" in n or "colsum" in n: k = "BatchNorm finalisations"
+        elif "avgpool" in n or "head" in n: k = "pools, heads (1×1, pooled head)"
+        elif "concat_side" in n or "msg_" in n or "dy_" in n or "side_pack" in n: k = "concat side kernels"
+        else: k = "rest (layout, attack, losses, Adam, packs, copies)"
+        fam[k] += ms
+    A(f"| time by kernel family (ms per step under rocprofv3, one-stream order, {tot:.2f} ms of kernels: `{tag}_bench_c2_kernel_stats_summary.txt`) | " + " · ".join(f"{k} {v:.2f}" for k, v in fam.items()) + " |")
+    cb = b.get("cpu_baseline")
+    if cb:
+        A(f"| CPU baseline (`cpu_baseline`) | {cb['value']:.2f} frames/s on {cb['cores']} threads ({cb['sample']}) |")
+    open(os.path.join(dst, f"{tag}_measurements.md"), "w").write("\n".join(L) + "\n")
+    print("wrote", f"profiles/{tag}_measurements.md")
+
+
+emit_measurements_md()
