@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--noise", default="Jpeg50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel-events-every", type=int, default=10,
+    ap.add_argument("--kernel-events-every", type=int, default=20,
                     help="the roofline kernels are bracketed with HIP events on every n-th timed step only: an event pair idles the GPU for ~11 us "
                          "around the launch it brackets (28 bracketed launches = 0.31 ms of a 5.5 ms step when every step is instrumented)")
     ap.add_argument("--keep-dead-grads", action="store_true", help="also compute the discriminator weight gradients of the generator pass (the reference's state; nothing reads them)")
@@ -228,7 +228,7 @@ def timed_steps(h, batch, steps, warmup, barrier, world, dev, timer=None, every=
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
-        bracket = timer is not None and i % every == 0
+        bracket = timer is not None and ((i + 1) % every == 0 or (steps < every and i == steps - 1))
         ops.set_kernel_timer(timer if bracket else None)
         h.two_streams = ts and not bracket      # (a bracketed step runs its kernels one after the other: see the headline loop)
         h.train_on_batch(batch)
@@ -361,16 +361,19 @@ def main():
         # The kernel events are part of the timed region, and they are not free: rocprofv3's kernel trace shows 5.3-6.1 us of idle GPU on
         # either side of every bracketed launch (the event's marker packet) and none around the launches that are not bracketed -- so the
         # roofline kernels are bracketed on every `every`-th timed step, all their launches of that step.
-        ops.set_kernel_timer(timer if i % every == 0 else None)
+        # (the LAST step of every `every`, not the first: the first steps behind the barrier + synchronize run on a chip whose clock is still
+        # ramping up, and an eagerly enqueued step there also starts from an empty queue -- 6.2 ms instead of 5.5)
+        bracket = (i + 1) % every == 0 or (args.steps < every and i == args.steps - 1)
+        ops.set_kernel_timer(timer if bracket else None)
         # a bracketed step runs its launches ONE AFTER THE OTHER (one stream, eagerly): beside a launch of the other chain a kernel's event
         # pair would time the sharing of the chip, not the kernel (178 us instead of 149 for the dominant one)
-        h.two_streams = two_streams and i % every != 0
+        h.two_streams = two_streams and not bracket
         if sync is not None:
-            sync.profile = i % every == 0    # (the same for the events around the gradient all-reduces' waits)
+            sync.profile = bracket    # (the same for the events around the gradient all-reduces' waits)
         marks[i].record()
         th = time.perf_counter()
         losses, _ = h.train_on_batch([images, messages])
-        (host_ms_eager if (use_graph and i % every == 0) else host_ms).append(1e3 * (time.perf_counter() - th))
+        (host_ms_eager if (use_graph and bracket) else host_ms).append(1e3 * (time.perf_counter() - th))
     marks[args.steps].record()
     host_ms.sort(); host_ms_eager.sort()
     if not host_ms:
@@ -379,10 +382,11 @@ def main():
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
     h.two_streams = two_streams
-    sync_rep = sync.report((args.steps + every - 1) // every) if sync is not None else None
+    sync_rep = sync.report(max(1, args.steps // every)) if sync is not None else None
     if sync_rep is not None:   # every rank: its buckets and how long its compute stream stood waiting for them (the exposed part of the all-reduces)
         sys.stderr.write(f"[bench rank {rank}] grad sync: {json.dumps(sync_rep)}\n")
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_ms_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    step_ms = sorted(step_ms_order)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -481,7 +485,7 @@ def main():
             "kernel_events_note": "the steps whose kernels are bracketed with events run on one stream, eagerly (every kernel alone on the chip): avg_launch_ms is the kernel's own duration; the other steps run as two chains" + (" replayed from a hipGraph" if use_graph else "") if two_streams or use_graph else None,
             "host_enqueue_ms_median": host_ms[len(host_ms) // 2], "host_enqueue_ms_max": host_ms[-1],
             "host_enqueue_ms_median_eager_steps": host_ms_eager[len(host_ms_eager) // 2] if host_ms_eager else None,
-            "kernel_events_every": every,
+            "kernel_events_every": every, "ms_per_step_events": [round(v, 3) for v in step_ms_order],
             "roofline": roof,
             "roofline_mfma": mfma,
             "roofline_attack": attack_roofline(timer, B, S, args.noise),
