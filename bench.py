@@ -12,12 +12,19 @@ D(enc) fwd/bwd, Adam(D), D(enc) + MSE + MSE fwd/bwd, Adam(enc+dec); L=30, encode
 decoder 7x64, discriminator 3x64; bf16 activations, f32 accumulate/params; synthetic data,
 random-init weights; inputs resident in HBM before the timed region.  One step = one batch.
 
-Dead work (round 3): the reference's g_loss.backward() (hidden.py:101) also accumulates the generator loss's gradients into the
-DISCRIMINATOR's parameters -- gradients no optimiser step uses and hidden.py:67 zeroes unread.  By default the bench runs
-Hidden(keep_dead_discriminator_grads=False): that pass computes the gradient wrt the encoded image only; every loss, output and
-parameter update is identical (tests/test_gpu_configs.py), and the FLOPs NOT executed are NOT counted: 239.1 GFLOP per 256x256 frame
-instead of the reference autograd's 249.0 in `step_flops_frac_of_peak` (config.workload says which).  --keep-dead-grads runs and
-counts the reference's full set.
+Launches the reference's autograd runs whose results nothing can observe are not launched by default, and their FLOPs are not counted
+(config.workload says which; `step_gflop_per_frame`): (1) round 3 -- g_loss.backward() (hidden.py:101) also accumulates the generator loss's
+gradients into the DISCRIMINATOR's parameters, which no optimiser step uses and hidden.py:67 zeroes unread
+(Hidden(keep_dead_discriminator_grads=False): 2 x 4.832 + 0.226 GFLOP per 256x256 frame); (2) round 4 -- Jpeg(Q) quantises with torch.round,
+whose gradient is identically zero (noise_layers/jpeg.py:226-240), so the decoder's gradient wrt its input is multiplied by zero
+(Hidden.skip_zero_attack_gradient: 0.226 GFLOP).  Every loss, output and parameter update is identical (tests/test_gpu_configs.py,
+tests/test_gpu_graph.py).  The SAME invocation times the step with every launch of the reference's autograd (`reference_state`, 249.0 GFLOP
+per frame) and the 512 x 512 / 8-frame shard of BASELINE's C4 (`c4_shard_512`); --keep-dead-grads makes the former the headline.
+
+Round 4, one GPU: the step runs as its two independent chains on two streams (Hidden.two_streams) and is replayed from a hipGraph
+(Hidden.enable_graph) -- bit-identical to the eager one-stream step; --one-stream / --no-graph switch either off.  The steps whose kernels
+are bracketed with events (the last of every --kernel-events-every) run on one stream, eagerly, so that an event pair times the kernel
+alone.  With a gradient all-reduce (N > 1) the step runs eagerly on one stream as in round 3.
 
 The JSON line carries, besides the driver contract:
   roofline     -- the dominant kernel (most time per step, 13 launches): bwd_ws8_kernel (csrc/bwd_ws8.hip; csrc/bwd_ws.hip for shapes that
@@ -27,9 +34,9 @@ The JSON line carries, besides the driver contract:
                   288 FLOP/B, just under the 312 FLOP/B ridge), so the bound is HBM: achieved = algorithmic bytes / launch
                   duration measured live with events on the launch stream inside the timed region (every launch of every
                   `kernel_events_every`-th timed step: an event pair costs ~11 us of idle GPU around its launch); peak = 8 TB/s; `traffic` =
-                  HBM bytes / launch from the committed rocprofv3 PMC passes of this round (profiles/r03_pmc_traffic.json;
+                  HBM bytes / launch from the committed rocprofv3 PMC passes of this round (profiles/r04_pmc_traffic.json;
                   FETCH_SIZE doubled as the gfx950 guide says); `mfma_util_pmc` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x
-                  1024 SIMDs) from the committed counter pass (profiles/r03_bench_c2_pmc_mfma.csv); `step_mfma_util_pmc` = the same
+                  1024 SIMDs) from the committed counter pass (profiles/r04_bench_c2_pmc_mfma.csv); `step_mfma_util_pmc` = the same
                   ratio over every kernel of the step.  Those three come from a FILE, not from this run: the file carries the sha256
                   of the kernel sources it was measured on (csrc/*, build.py), and when the sources here hash differently the three
                   are null and `pmc_stale` is true.  (Until this kernel the work was two launches -- the fused input gradient,
