@@ -273,6 +273,7 @@ class _StepGraph:
                                         # with it THEN -- not whenever the cyclic collector next runs, which may be inside another capture)
         self.calls = 0
         self.graph = None
+        self._seen = {}
 
     @property
     def h(self):
@@ -297,6 +298,7 @@ class _StepGraph:
             self.hyper = torch.zeros(4, device=dev, dtype=torch.float32)
             self.hyper_host = torch.empty(4, dtype=torch.float32, pin_memory=True)
             self.img.copy_(images); self.msg.copy_(messages)
+            self._seen = {"img": (images, images._version), "msg": (messages, messages._version)}
             opts = (h.optimizer_discrim, h.optimizer_enc_dec)
             for i, o in enumerate(opts):
                 o._ensure()
@@ -320,10 +322,13 @@ class _StepGraph:
                 for o in opts:
                     o.hyper_dev, o.capturing = None, False
             self.graph = graph
-        if images.data_ptr() != self.img.data_ptr():
-            self.img.copy_(images)
-        if messages.data_ptr() != self.msg.data_ptr():
-            self.msg.copy_(messages)
+        # fresh inputs into the graph's static tensors -- unless the caller hands in the very tensor object of the previous call, unmodified
+        # (torch's version counter: every in-place op bumps it, this library's own through ops._wrote): a loop over one resident batch
+        for name, src, dst in (("img", images, self.img), ("msg", messages, self.msg)):
+            seen = self._seen.get(name)
+            if seen is None or seen[0] is not src or seen[1] != src._version:
+                dst.copy_(src)
+                self._seen[name] = (src, src._version)
         self._hyper_refresh()
         self.graph.replay()
         self.calls += 1
