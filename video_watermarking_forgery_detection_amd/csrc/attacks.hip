@@ -378,15 +378,27 @@ __global__ __launch_bounds__(256) void resample_bwd_y_kernel(const float* __rest
     const float sh = (float)hs / (float)OH;
     const int w = blockIdx.x * 256 + threadIdx.x;
     if (w >= W) return;
-    for (int n = blockIdx.z; n < N; n += gridDim.z) {
-        const float* t = tmp + (size_t)n * OH * W + w;
-        for (int h = blockIdx.y; h < H; h += gridDim.y) {
-            const int ih = h - h0;
+    // rows outside, planes inside (round 4): a row's tap range and weights are evaluated ONCE and serve every plane the block walks -- with
+    // one (row, plane) per block (12-18 thousand blocks of one row each) the weight polynomials were most of the kernel
+    constexpr int MAXT = 12;
+    for (int h = blockIdx.y; h < H; h += gridDim.y) {
+        const int ih = h - h0;
+        int ylo = 0, yhi = -1;
+        float wys[MAXT];
+        const bool in_y = ih >= 0 && ih < hs;
+        if (in_y) {
+            axis_range<KIND>(ih, hs, OH, sh, ylo, yhi);           // (wave-uniform bounds and weights: every lane of the row has the same ih)
+#pragma unroll
+            for (int c = 0; c < MAXT; ++c) wys[c] = (ylo + c <= yhi) ? axis_weight<KIND>(ylo + c, ih, hs, sh) : 0.f;
+        }
+        for (int n = blockIdx.z; n < N; n += gridDim.z) {
+            const float* t = tmp + (size_t)n * OH * W + w;
             float acc = 0.f;
-            if (ih >= 0 && ih < hs) {
-                int ylo, yhi;
-                axis_range<KIND>(ih, hs, OH, sh, ylo, yhi);
-                for (int oy = ylo; oy <= yhi; ++oy) {           // (wave-uniform bounds and weights: every lane of the row has the same ih)
+            if (in_y) {
+#pragma unroll
+                for (int c = 0; c < MAXT; ++c)
+                    if (ylo + c <= yhi && wys[c] != 0.f) acc += wys[c] * t[(size_t)(ylo + c) * W];
+                for (int oy = ylo + MAXT; oy <= yhi; ++oy) {     // (footprints wider than MAXT taps: evaluated on the fly, as before)
                     const float wy = axis_weight<KIND>(oy, ih, hs, sh);
                     if (wy != 0.f) acc += wy * t[(size_t)oy * W];
                 }
@@ -435,8 +447,17 @@ extern "C" int wm_resample_bwd_sep(const float* gy, const float* y_clamped, floa
     WM_REQUIRE(gy && gx && tmp, WM_E_BADARG, "wm_resample_bwd_sep: null pointer");
     int rc = resample_check("wm_resample_bwd_sep", N, H, W, h0, hs, w0, ws, OH, OW, kind);
     if (rc) return rc;
+    // x pass: a thread keeps its column's weights in registers and walks rows: ~1024 blocks in all instead of one per (row, plane), so that
+    // the weights are evaluated once per ~OH / 16 rows.  y pass: rows outside, planes inside (its kernel): a block per row and plane GROUP
     const unsigned gz = (unsigned)(N < 65535 ? N : 65535);
-    const dim3 gx_grid((unsigned)((W + 255) / 256), (unsigned)(OH < 65535 ? OH : 65535), gz), gy_grid((unsigned)((W + 255) / 256), (unsigned)(H < 65535 ? H : 65535), gz), block(256);
+    const unsigned bx = (unsigned)((W + 255) / 256);
+    unsigned ry = (unsigned)(1024u / (bx * gz > 0 ? bx * gz : 1u));
+    if (ry < 1) ry = 1;
+    if (ry > (unsigned)OH) ry = (unsigned)OH;
+    unsigned pz = (unsigned)(1024u / (bx * (unsigned)(H < 65535 ? H : 65535)));
+    if (pz < 1) pz = 1;
+    if (pz > gz) pz = gz;
+    const dim3 gx_grid(bx, ry, gz), gy_grid(bx, (unsigned)(H < 65535 ? H : 65535), pz), block(256);
     hipStream_t s = (hipStream_t)stream;
     // candidate columns of one input pixel: axis_range's [lo, hi] spans at most 4 / scale + 5 outputs (scale = ws / OW)
     const int span = (int)(4.0 * (double)OW / (double)ws) + 5;
