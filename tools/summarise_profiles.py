@@ -4,7 +4,7 @@ FETCH_SIZE is doubled (gfx950 reports half of wide coalesced reads: MI355X_MICRO
 KB per dispatch.  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs): busy cycles of the
 matrix pipes over the SIMD-cycles the dispatch held the chip (the gfx94x MfmaUtil formula; GRBM_GUI_ACTIVE is summed over the XCDs).
 usage: python tools/summarise_profiles.py <tag>"""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_final")
 dst = os.path.join(ROOT, "profiles")
@@ -227,8 +227,44 @@ def emit_measurements_md():
     cb = b.get("cpu_baseline")
     if cb:
         A(f"| CPU baseline (`cpu_baseline`) | {cb['value']:.2f} frames/s on {cb['cores']} threads ({cb['sample']}) |")
-    open(os.path.join(dst, f"{tag}_measurements.md"), "w").write("\n".join(L) + "\n")
+    # the widened configurations (tools/collect_profiles.sh b)
+    def _jsonl(name):
+        try:
+            return [json.loads(l) for l in open(os.path.join(dst, name)) if l.startswith("{")]
+        except OSError:
+            return []
+    cc = _jsonl(f"{tag}_c3_c5_steps.jsonl")
+    if cc:
+        A(f"| C3 / C5 through the model surface, attack drawn per step (`{tag}_c3_c5_steps.jsonl`; median over the timed steps) | " + "<br>".join(
+            f"{r['yml']} {r['dtype']}: {r['ms_per_step_median']:.2f} ms → {r['frames_per_s']:.0f} frames/s (slowest attack {max(r['ms_per_step_by_attack'].items(), key=lambda kv: kv[1])[0]} {max(r['ms_per_step_by_attack'].values()):.2f} ms)" for r in cc) + " |")
+    lt = _jsonl(f"{tag}_literal_steps.jsonl")
+    if lt:
+        A(f"| the literal IRNrhi step (generator + localizer + discriminator, `{tag}_literal_steps.jsonl`) | " + "<br>".join(
+            f"{r['dtype']}, {r['frames_per_step']} frames: {r['ms_per_step_median']:.1f} ms = {r['tflops']:.0f} TFLOP/s ({100 * r['flops_frac_of_mfma_peak']:.1f} % of peak)" for r in lt) + " |")
+    inn = _jsonl(f"{tag}_inn_steps.jsonl")
+    if inn:
+        A(f"| the invertible embedder's step (`{tag}_inn_steps.jsonl`) | " + "<br>".join(
+            f"{r['dtype']}, {r['frames_per_step']} frames, {'replayed' if r.get('graph') else 'enqueued'}: {r['ms_per_step_median']:.1f} ms = {r['tflops']:.0f} TFLOP/s ({100 * r['flops_frac_of_mfma_peak']:.1f} % of peak)" for r in inn) + " |")
+    try:
+        rows = [r for r in csv.DictReader(l for l in open(os.path.join(dst, f"{tag}_attack_roofline.csv")) if not l.startswith("#"))]
+        def short(n):
+            m = re.search(r"::(\w+<[^>]*>|\w+)\(", n)
+            return m.group(1) if m else n[:40]
+        A(f"| attack kernels at B=16, 3×256×256 f32, per launch (`{tag}_attack_roofline.csv`: rocprofv3 average, PMC bytes, fraction of 8 TB/s) | " + "<br>".join(
+            f"`{short(r['kernel'])}` {float(r['avg_us']):.1f} µs, {float(r['hbm_MB_pmc']):.1f} MB → {float(r['frac_of_8TBps']):.3f}" for r in rows[:12]) + " |")
+    except (OSError, KeyError, ValueError):
+        pass
+    text = "\n".join(L) + "\n"
+    open(os.path.join(dst, f"{tag}_measurements.md"), "w").write(text)
     print("wrote", f"profiles/{tag}_measurements.md")
+    # DESIGN.md carries the table between two markers; refresh it in place so that the prose cannot drift from the committed files
+    dpath = os.path.join(os.path.dirname(dst), "DESIGN.md")
+    d = open(dpath).read()
+    b0, b1 = f"<!-- BEGIN {tag}_measurements -->", f"<!-- END {tag}_measurements -->"
+    if b0 in d and b1 in d:
+        d = d[:d.index(b0) + len(b0)] + "\n" + text + d[d.index(b1):]
+        open(dpath, "w").write(d)
+        print("refreshed the table in DESIGN.md")
 
 
 emit_measurements_md()

@@ -587,8 +587,10 @@ class Hidden:
 
         Why: every persistent kernel spends a fixed part of its launch outside its tile loop (filter -> LDS, first HBM round trip, for the
         one-pass backward the weight-gradient slabs) and the chip idles through each launch's ramp and tail; a second, independent launch fills
-        those: 24 launches of the forward 64 -> 64 kernel take 1.78 ms from two streams against 1.96 ms from one, of the one-pass backward 4.00
-        against 4.24 (tools/bench_two_chains.py, profiles/r04_two_chains.txt).  Results are bit-identical to the one-stream order: no kernel's
+        those.  Measured on the step itself: 5.25 ms against 5.35 ms enqueued, 5.21 against 5.34 replayed from the graph (-1.7 ... -2.4 %,
+        profiles/r04_step_modes.txt).  The kernels alone promised more (24 launches of the forward 64 -> 64 kernel 1.75 ms from two streams
+        against 2.02 from one, of the one-pass backward 3.93 against 4.17: tools/bench_two_chains.py, profiles/r04_two_chains.txt), but that
+        comparison's one-stream arm carries host gaps the step does not have.  Results are bit-identical to the one-stream order: no kernel's
         inputs or reduction order change, only when it runs."""
         main = torch.cuda.current_stream()
         sA, sB = self._chain_streams()
