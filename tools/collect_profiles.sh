@@ -48,8 +48,8 @@ exit 0
 fi
 # ---- part b: the widened configurations through the model surface, the literal IRNrhi step, the one-pass backward kernel's phases, the co-issue micro
 cd $ROOT
-(python3 tools/bench_c5.py train_hidden_c3.yml bf16 72 && python3 tools/bench_c5.py train_hidden_c3.yml f16 72 && python3 tools/bench_c5.py train_hidden_c5.yml bf16 72 &&
- python3 tools/bench_c5.py train_hidden_c5_fp16.yml f16 72) 2> $OUT/c3_c5.err | grep '^{' > $OUT/c3_c5_steps.jsonl
+(python3 tools/bench_c5.py train_hidden_c3.yml bf16 130 && python3 tools/bench_c5.py train_hidden_c3.yml bf16 130 deferred && python3 tools/bench_c5.py train_hidden_c3.yml f16 130 && python3 tools/bench_c5.py train_hidden_c5.yml bf16 130 &&
+ python3 tools/bench_c5.py train_hidden_c5_fp16.yml f16 130) 2> $OUT/c3_c5.err | grep '^{' > $OUT/c3_c5_steps.jsonl
 (python3 tools/bench_literal.py 4 bf16 12 && python3 tools/bench_literal.py 4 f16 12) 2> $OUT/literal.err | grep '^{' > $OUT/literal_steps.jsonl
 (python3 tools/bench_inn.py 8 bf16 6 && python3 tools/bench_inn.py 8 bf16 6 graph && python3 tools/bench_inn.py 8 f16 6 graph) 2> $OUT/inn.err | grep '^{' > $OUT/inn_steps.jsonl
 (python3 tools/phase_bwd.py 0 && python3 tools/phase_bwd.py 256 && python3 tools/phase_bwd.py 8 && python3 tools/phase_bwd.py 1048832) 2>&1 | grep -v amdgpu.ids > $OUT/bwd_phase_cycles.txt

@@ -235,8 +235,8 @@ def emit_measurements_md():
             return []
     cc = _jsonl(f"{tag}_c3_c5_steps.jsonl")
     if cc:
-        A(f"| C3 / C5 through the model surface, attack drawn per step (`{tag}_c3_c5_steps.jsonl`; median over the timed steps) | " + "<br>".join(
-            f"{r['yml']} {r['dtype']}: {r['ms_per_step_median']:.2f} ms → {r['frames_per_s']:.0f} frames/s (slowest attack {max(r['ms_per_step_by_attack'].items(), key=lambda kv: kv[1])[0]} {max(r['ms_per_step_by_attack'].values()):.2f} ms)" for r in cc) + " |")
+        A(f"| C3 / C5 through the model surface (`feed_data` of pinned host batches + `optimize_parameters`), attack cycling with the step (`{tag}_c3_c5_steps.jsonl`; wall clock of the whole loop per step, and the median of the steps' own event times) | " + "<br>".join(
+            f"{r['yml']} {r['dtype']}{', deferred logs' if r.get('deferred_logs') else ''}: wall {r.get('wall_ms_per_step', float('nan')):.2f} ms → {r.get('wall_frames_per_s', float('nan')):.0f} frames/s; step events {r['ms_per_step_median']:.2f} ms (slowest attack {max(r['ms_per_step_by_attack'].items(), key=lambda kv: kv[1])[0]} {max(r['ms_per_step_by_attack'].values()):.2f} ms)" for r in cc) + " |")
     lt = _jsonl(f"{tag}_literal_steps.jsonl")
     if lt:
         A(f"| the literal IRNrhi step (generator + localizer + discriminator, `{tag}_literal_steps.jsonl`) | " + "<br>".join(

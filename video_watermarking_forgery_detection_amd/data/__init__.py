@@ -17,8 +17,11 @@ def create_dataloader(dataset, dataset_opt, opt=None, sampler=None):
             num_workers = dataset_opt['n_workers'] * len(opt['gpu_ids'] or [0])
             batch_size = dataset_opt['batch_size']
             shuffle = sampler is None
+        # pin_memory: the reference passes False (data/__init__.py:25); here the default is True -- feed_data's non_blocking copy then does not
+        # wait for the step in flight (a pageable source makes the copy a per-step drain of the stream); `pin_memory: false` restores it
+        pin = dataset_opt['pin_memory']
         return torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers, sampler=sampler,
-                                           drop_last=True, pin_memory=False)
+                                           drop_last=True, pin_memory=torch.cuda.is_available() if pin is None else bool(pin))
     return torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=False, num_workers=1, pin_memory=True)
 
 

@@ -402,12 +402,15 @@ class Hidden:
         self.two_streams = False  # the step's two independent chains on two streams (_train_step_two_chains); same results bit for bit
         self._streams = None
 
+    MAX_GRAPHS = 32   # captured variants kept per model (shapes x attack variants x ...); calls beyond that run eagerly
+
     def enable_graph(self, on=True):
         """replay the step from a hipGraph instead of enqueueing its ~190 launches every call (same results bit for bit: _StepGraph).
         Used for plain train_on_batch(batch) calls on one GPU with an attack layer that has an explicit fwd / bwd and declares itself
         `capturable` (the same launches with the same arguments every call: the Jpeg family, GaussianBlur, MiddleBlur, Identity -- not the
-        layers that draw their arguments on the host, Resize / Crop / Combined); a call with extra_encoded_grad / clip / enc_gate, with a
-        grad_sync, or while a kernel timer is installed runs eagerly as before."""
+        layers that draw their arguments on the host, Resize / Crop / Combined) or names the deterministic variant this call runs through
+        `capture_key()` (one graph per variant: the model surface's attack cycle, which calls Resize / Crop with fixed arguments); a call with
+        extra_encoded_grad / clip / enc_gate, with a grad_sync, or while a kernel timer is installed runs eagerly as before."""
         self._graphs = {} if on else None
         return self
 
@@ -444,14 +447,22 @@ class Hidden:
         messages = messages.to(self.device, torch.float32).contiguous()
         n = self.encoder_decoder.noiser
         if (self._graphs is not None and extra_encoded_grad is None and clip is None and enc_gate is None and self.grad_sync is None
-                and not ops.kernel_timer_installed() and hasattr(n, "fwd") and hasattr(n, "bwd") and getattr(n, "capturable", False)
-                and not torch.cuda.is_current_stream_capturing()):
+                and not ops.kernel_timer_installed() and hasattr(n, "fwd") and hasattr(n, "bwd") and not torch.cuda.is_current_stream_capturing()):
+            # a layer is capturable as a whole (`capturable`), or says per call which of its deterministic variants this call runs
+            # (`capture_key()`: a hashable, or None for "not this time" -- the model surface's attack cycle, whose choice follows the step)
+            ck = True if getattr(n, "capturable", False) else (n.capture_key() if hasattr(n, "capture_key") else None)
+        else:
+            ck = None
+        if ck is not None:
             key = (tuple(images.shape), tuple(messages.shape), self.noise_id, self.keep_dead_discriminator_grads, self.lazy_losses, self.two_streams, self.skip_zero_attack_gradient,
-                   self.encoder_decoder.encoder.compute_dtype)
+                   self.encoder_decoder.encoder.compute_dtype, ck)
+            if self.amp is not None:   # under the scaler the learning rate reaches wm_adam_step_amp as a launch argument: a scheduler's new value needs its own graph
+                key += tuple(o.param_groups[0]["lr"] for o in (self.optimizer_discrim, self.optimizer_enc_dec))
             g = self._graphs.get(key)
-            if g is None:
+            if g is None and len(self._graphs) < self.MAX_GRAPHS:
                 g = self._graphs[key] = _StepGraph(self)
-            return g.step(images, messages)
+            if g is not None:
+                return g.step(images, messages)
         return self._step_eager(images, messages, extra_encoded_grad, clip, enc_gate)
 
     def _step_eager(self, images, messages, extra_encoded_grad=None, clip=None, enc_gate=None):

@@ -45,6 +45,35 @@ def _get(d, *keys, default=None):
     return default if d is None else d
 
 
+class DeferredLogs:
+    """`logs` of a step whose scalars have not been waited for yet (train.deferred_logs; the reference's list of (name, value) pairs,
+    IRNrhi_model.py optimize_parameters -> train.py:109).  Behaves as that list; the first look at it (iteration, len, truth value, indexing,
+    comparison) waits for the device.  A loop that looks one step late -- after enqueueing the next step -- never drains the GPU queue."""
+
+    def __init__(self, read):
+        self._read, self._logs = read, None
+
+    def resolve(self):
+        if self._logs is None:
+            self._logs, self._read = self._read(), None
+        return self._logs
+
+    def __iter__(self):
+        return iter(self.resolve())
+
+    def __len__(self):
+        return len(self.resolve())
+
+    def __getitem__(self, i):
+        return self.resolve()[i]
+
+    def __eq__(self, other):
+        return self.resolve() == (other.resolve() if isinstance(other, DeferredLogs) else other)
+
+    def __repr__(self):
+        return repr(self.resolve())
+
+
 class _AttackCycle:
     """the attack cycles deterministically with the step."""
 
@@ -53,7 +82,7 @@ class _AttackCycle:
         self.k = 0
         self.name = "NotChosenYet"
 
-    def fwd(self, image, id=None, exclude=()):
+    def _choose(self, id=None, exclude=()):
         i = self.k % len(self.layers) if id is None else id
         layer = self.layers[i]
         for _ in range(len(self.layers)):   # a layer type the caller cannot use (the localiser and Crop): take the next one in the cycle
@@ -62,7 +91,19 @@ class _AttackCycle:
             i = (i + 1) % len(self.layers)
             layer = self.layers[i]
         else:
-            layer = Identity()
+            i, layer = -1, Identity()
+        self.name = getattr(layer, "name", type(layer).__name__)
+        return i, layer
+
+    def capture_key(self):
+        """Hidden.enable_graph: every layer of the cycle runs with fixed arguments here (Resize at 0.7, Crop at a fixed rectangle), so a step
+        through layer i launches the same kernels every time -- one captured graph per layer.  (Also names the layer, as fwd does: a
+        replayed step does not call fwd.)"""
+        i, layer = self._choose()
+        return ("cycle", i, type(layer).__name__)
+
+    def fwd(self, image, id=None, exclude=()):
+        i, layer = self._choose(id, exclude)
         if isinstance(layer, Resize):
             y, c = layer.fwd(image, resize_ratio=0.7)
         elif isinstance(layer, Crop):
@@ -70,7 +111,7 @@ class _AttackCycle:
             y, c = layer.fwd(image, apex=(H // 8, H // 8 + int(0.75 * H), W // 8, W // 8 + int(0.75 * W)))
         else:
             y, c = layer.fwd(image)
-        self.name = getattr(layer, "name", type(layer).__name__)
+        self.name = getattr(layer, "name", type(layer).__name__)   # (a layer may name itself in its forward: the reference's G_Blur -> GaussianBlur)
         return y, (layer, c)
 
     def bwd(self, ctx, g):
@@ -95,6 +136,9 @@ class IRNrhiModel(BaseModel):
         self.previous_images = self.previous_previous_images = None
         self.save_interval = _get(train_opt, 'save_interval', default=3000)
         self.gradient_clipping = _get(train_opt, 'gradient_clipping', default=None)
+        # train.deferred_logs (default false = the reference's behaviour: every step's scalars are read before optimize_parameters returns):
+        # the returned logs wait for the device only when looked at (DeferredLogs)
+        self.deferred_logs = bool(_get(train_opt, 'deferred_logs', default=False))
         dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16, "f32": torch.float32,
                  None: torch.bfloat16}[_get(train_opt, 'compute_dtype')]
         # torch.cuda.amp.autocast() + GradScaler() of the reference (IRNcrop_model.py:143,340,407-416): with f16 activations the
@@ -130,6 +174,10 @@ class IRNrhiModel(BaseModel):
         # train.two_streams (default true): the step's two independent chains on two streams wherever a step has them to itself (one GPU, no
         # localisation branch / clipping / PSNR gate: Hidden._train_step_two_chains); same results bit for bit
         self.hidden.two_streams = bool(_get(train_opt, 'two_streams', default=True))
+        # train.graph (default true): a step WITHOUT the localiser branch, gradient clipping and PSNR gate (configuration C3) is replayed from a
+        # hipGraph, one graph per layer of the attack cycle (Hidden.enable_graph; same results bit for bit, tests/test_gpu_graph.py); one GPU only
+        if grad_sync is None and bool(_get(train_opt, 'graph', default=True)):
+            self.hidden.enable_graph()
         self.netG = self.hidden.encoder_decoder
         self.discriminator = self.hidden.discriminator
         lr = _get(train_opt, 'lr_G', default=1e-3)
@@ -160,6 +208,7 @@ class IRNrhiModel(BaseModel):
         self.image_dump_interval = _get(train_opt, 'image_dump_interval', default=None)
         self.image_dump_dir = _get(self.opt, 'path', 'images', default=None)
         self._loc = None
+        self._copy_stream = None
         self.messages = None
         self.keep_outputs = False    # tests / image dumps: keep the step's tensors in self.last_outputs
         self.last_outputs = {}
@@ -187,14 +236,31 @@ class IRNrhiModel(BaseModel):
             mask = batch[1] if len(batch) > 1 and torch.is_tensor(batch[1]) and batch[1].dim() >= 4 else None
         else:
             imgs = batch
-        imgs = imgs.to(self.device, torch.float32, non_blocking=True)
+        imgs, mask = self._to_device(imgs), (self._to_device(mask) if mask is not None else None)
         if imgs.dim() == 5:
             B, C, T, H, W = imgs.shape
             imgs = imgs.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
             if mask is not None:
                 mask = mask.permute(0, 2, 1, 3, 4).reshape(B * T, 1, H, W)
         self.real_H = imgs.contiguous()
-        self.mask = mask.to(self.device, torch.float32).contiguous() if mask is not None else None
+        self.mask = mask.contiguous() if mask is not None else None
+
+    def _to_device(self, t):
+        """host -> device.  A PINNED source (the training loader's default here, data/__init__.py) is copied on a side stream, so the copy
+        runs beside whatever the step's stream still holds -- with train.deferred_logs that is the previous step -- and the step's stream
+        only waits for the copy's event; a pageable source is copied in stream order (the host blocks: torch's semantics)."""
+        if t.is_cuda or not t.is_pinned():
+            return t.to(self.device, torch.float32)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(self.device)
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._copy_stream):
+            d = t.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        cur.wait_event(ev)
+        d.record_stream(cur)
+        return d if d.dtype == torch.float32 else d.float()
 
     # ------------------------------------------------------------------ localisation branch
     def _gate(self, encoded, images):
@@ -292,11 +358,19 @@ class IRNrhiModel(BaseModel):
                 self.last_outputs.update(encoded=outs[0], noised=outs[1], decoded=outs[2])
             self.keep_outputs = keep
             extra_logs = losses.pop('_extra', [])
-            logs = [(k.strip(), v) for k, v in losses.items()]
-            for name, v in extra_logs:
-                logs.append((name, v.item() if torch.is_tensor(v) else v))
-            logs.append(('lr', self.get_current_learning_rate()))
-            self._log_side(step, logs)
+            lr = self.get_current_learning_rate()
+
+            def read_logs():   # waits for the step's scalars (the reference's .item() calls)
+                out = [(k.strip(), v) for k, v in losses.items()]
+                for name, v in extra_logs:
+                    out.append((name, v.item() if torch.is_tensor(v) else v))
+                out.append(('lr', lr))
+                return out
+            if self.deferred_logs and self.writer is None and not dump:
+                logs = DeferredLogs(read_logs)   # train.deferred_logs: read when the caller first looks at them (train.py: one step later)
+            else:
+                logs = read_logs()
+                self._log_side(step, logs)
         elif ready:
             L = self.hidden.config.message_length
             messages = torch.randint(0, 2, (self.real_H.shape[0], L), device=self.device).float()

@@ -17,7 +17,7 @@ import torch
 
 from .data import DistIterSampler, DVDataset, create_dataloader
 from .distributed import init_dist, shard_batch_size
-from .models.IRNrhi_model import IRNrhiModel
+from .models.IRNrhi_model import DeferredLogs, IRNrhiModel
 from .options import options as option
 from .utils import Progbar
 
@@ -81,7 +81,7 @@ def main():
     per_rank = shard_batch_size(opt['datasets']['train']['batch_size'], world)
     current_step = opt['train']['current_step'] or 0
     total_iters = int(opt['train']['niter'])
-    latest_values = None
+    latest_values, pending = None, None
     progbar = Progbar(total_iters * per_rank, stateful_metrics=['lr', 'Kind', 'LocKind', 'PF']) if rank <= 0 and opt['train']['progbar'] else None
     batches = (davis_batches(opt, max(rank, 0), world, total_iters) if opt['datasets']['train']['dataroot']
                else synthetic_batches(opt, per_rank, rank, total_iters))
@@ -95,10 +95,17 @@ def main():
         else:
             logs, debug_logs = model.evaluate()
         if progbar is not None:
-            progbar.add(len(model.real_H), values=logs)      # train.py:109
-        elif rank <= 0 and logs and current_step % 10 == 0:
+            if isinstance(logs, DeferredLogs):   # train.deferred_logs: the bar is fed one step late, after the next step has been enqueued
+                if pending is not None:
+                    progbar.add(pending[0], values=pending[1])
+                pending = (len(model.real_H), logs)
+            else:
+                progbar.add(len(model.real_H), values=logs)      # train.py:109
+        elif rank <= 0 and current_step % 10 == 0 and logs:
             log.info("step %d  frames %d  %s", current_step, len(model.real_H),
                      "  ".join(f"{k}={v:.4f}" if isinstance(v, float) else f"{k}={v}" for k, v in logs))
+    if progbar is not None and pending is not None:
+        progbar.add(pending[0], values=pending[1])
 
 
 if __name__ == '__main__':
