@@ -181,6 +181,11 @@ def kernel_sources_sha():
 
 
 PMC_FILE = "r04_pmc_traffic.json"
+def graph_failures(h):
+    """reasons of failed step captures (Hidden falls back to enqueueing those steps eagerly and warns), [] if none"""
+    return [g.failed for g in (h._graphs or {}).values() if g.failed is not None]
+
+
 GRAPH_DEFAULT = True          # --graph / --no-graph: the step replayed from a hipGraph (one GPU; N > 1 runs eagerly around the all-reduces)
 TWO_STREAMS_DEFAULT = True    # --two-streams / --one-stream: the step's two independent chains on two streams
 _pmc = {}
@@ -488,7 +493,7 @@ def main():
                                       + " -- reference_state times the step with them"),
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "ms_per_step_median_events": step_ms[len(step_ms) // 2], "ms_per_step_min_events": step_ms[0], "ms_per_step_max_events": step_ms[-1],
-            "graph": use_graph, "two_streams": bool(two_streams),
+            "graph": use_graph and not graph_failures(h), "graph_capture_failed": graph_failures(h) or None, "two_streams": bool(two_streams),
             "kernel_events_note": "the steps whose kernels are bracketed with events run on one stream, eagerly (every kernel alone on the chip): avg_launch_ms is the kernel's own duration; the other steps run as two chains" + (" replayed from a hipGraph" if use_graph else "") if two_streams or use_graph else None,
             "host_enqueue_ms_median": host_ms[len(host_ms) // 2], "host_enqueue_ms_max": host_ms[-1],
             "host_enqueue_ms_median_eager_steps": host_ms_eager[len(host_ms_eager) // 2] if host_ms_eager else None,

@@ -273,6 +273,7 @@ class _StepGraph:
                                         # with it THEN -- not whenever the cyclic collector next runs, which may be inside another capture)
         self.calls = 0
         self.graph = None
+        self.failed = None   # why the capture failed, if it did: the step then runs eagerly (same launches, same results) and says so once
         self._seen = {}
 
     @property
@@ -289,7 +290,7 @@ class _StepGraph:
 
     def step(self, images, messages):
         h = self.h
-        if self.calls < self.WARMUP:
+        if self.calls < self.WARMUP or self.failed is not None:
             self.calls += 1
             return h._step_eager(images, messages)
         if self.graph is None:
@@ -316,11 +317,20 @@ class _StepGraph:
             try:
                 with torch.cuda.graph(graph):
                     self.result = h._step_launches(self.img, self.msg)
+            except Exception as e:   # noqa: BLE001 -- whatever stopped the capture (nothing was executed: the model is as it was before)
+                import warnings
+                self.failed = f"{type(e).__name__}: {e}"
+                self.result = None
+                warnings.warn("hipGraph capture of the training step failed; this and the following steps are enqueued eagerly (same launches, "
+                              "same results, more host time per step): " + self.failed)
             finally:
                 if gc_was_on:
                     gc.enable()
                 for o in opts:
                     o.hyper_dev, o.capturing = None, False
+            if self.failed is not None:
+                self.calls += 1
+                return h._step_eager(images, messages)
             self.graph = graph
         # fresh inputs into the graph's static tensors -- unless the caller hands in the very tensor object of the previous call, unmodified
         # (torch's version counter: every in-place op bumps it, this library's own through ops._wrote): a loop over one resident batch
