@@ -282,6 +282,27 @@ int wm_concat_side_msg_wgrad(const void* dy, const float* msg, float* partial, f
                              int W, int Cin, int c_msg, int L, int dtype, void* stream);
 int wm_conv3x3_fwd_addin(const void* x, const void* wp, const float* in_scale, const float* in_shift, const void* addend, void* y,
                          float* stat_partials, int B, int H, int W, int dtype, int sweep_reverse, void* stream);
+/* conv + bias + ELU as ONE launch and that layer's backward in two (16-bit dtypes; rows f1 / f2).  replaces: the coupling subnets'
+ * `elu(conv(x))` pairs, /root/reference/models/invertible_net.py:326-366 (ResBlock: conv1..conv4 + nn.ELU), whose autograd backward is
+ * elu' * g, a bias column sum, the input gradient and the weight gradient -- five passes over the data here before.
+ *   wm_conv3x3_fwd_elu       : out [B,H,W,64] = elu(conv3x3(x, wp) + bias); x [B,H,W,Cin] stride ldx, Cin in {16, 32, 64}; the pre-activation
+ *                              is not stored: elu'(z) = out > 0 ? 1 : out + 1.
+ *   wm_conv3x3_dgrad_elufused: g [B,H,W,64] = the gradient wrt out; forms gz = g * (out > 0 ? 1 : out + 1) while staging, writes
+ *                              dx [B,H,W,CinP] = conv3x3(gz, wpt) (wpt from wm_pack_w3x3, transposed; CinP in {64, 32}), gz_out [B,H,W,64]
+ *                              (NULL: not wanted) and bias_partials f32 [wm_conv3x3_dgrad_elufused_nparts(B,H,W)][64]: per-workgroup
+ *                              column sums of gz (before its rounding to 16 bits).
+ *   wm_conv3x3_wgrad_bias    : dw [Cout][Cin][3][3] (+)= the weight gradient from (x, gz) as wm_conv3x3_wgrad (ws: the same scratch), and in
+ *                              the same reduction launch db [Cout] (+)= the column sums of bias_partials [nparts][CoutY]. */
+int wm_conv3x3_fwd_elu_supported(int Cin, int CoutP, int dtype);
+int wm_conv3x3_fwd_elu(const void* x, int ldx, const void* wp, const float* bias, int nbias, void* out, int B, int H, int W, int Cin,
+                       int dtype, int sweep_reverse, void* stream);
+int wm_conv3x3_dgrad_elufused_supported(int CinP, int dtype);
+int wm_conv3x3_dgrad_elufused_nparts(int B, int H, int W);
+int wm_conv3x3_dgrad_elufused(const void* g, const void* out, const void* wpt, void* dx, void* gz_out, float* bias_partials, int B,
+                              int H, int W, int CinP, int dtype, int sweep_reverse, void* stream);
+int wm_conv3x3_wgrad_bias(const void* x, int ldx, int CinX, const void* gz, int ldgz, int CoutY, float* ws, float* dw, int accumulate,
+                          int B, int H, int W, int Cin, int Cout, int dtype, const float* bias_partials, int nparts, float* db,
+                          int db_accumulate, void* stream);
 /* The backward of an IMAGE-FED first ConvBNRelu (3 -> 64 channels; replaces autograd's backward of conv_bn_relu.py:11-15 for the layers of
  * decoder.py:16 / discriminator.py:13, whose input image needs a gradient) in ONE pass (csrc/bwd_ws16.hip): reads g, y [B,H,W,64] (gradient
  * wrt the layer's ReLU output, its raw conv output; stats4 / coef as wm_conv3x3_dgrad_applyfused) and the layer's input x [B,H,W,16] (the
@@ -544,7 +565,8 @@ int wm_scale_dev(float* x, size_t n, const float* scale_dev, void* stream);
  * wm_gconv_wgrad: dw [Cout][Cin][KH][KW] (+)= sum_pixels dout x in; dbias [Cout] (+)= column sums of dout (may be NULL);
  *                 partial = f32 scratch of wm_gconv_wgrad_scratch_floats(..) floats.  IH/IW/KC describe `in`, OH/OW/NC `dout`.
  * wm_gcolsum    : out [Creal] (+)= column sums of x [npix][C]; scratch: wm_gcolsum_scratch_floats(npix, C) floats.
- * wm_unary_fwd / _bwd: kind 0 ReLU, 1 LeakyReLU(0.2), 2 GELU (erf), 3 ELU, 4 Sigmoid, 5 Tanh; the backward reads the INPUT x.
+ * wm_unary_fwd / _bwd: kind 0 ReLU, 1 LeakyReLU(0.2), 2 GELU (erf), 3 ELU, 4 Sigmoid, 5 Tanh; the backward reads the INPUT x --
+ *                 except kind 6 (backward only): the ELU derivative from the layer's OUTPUT, out > 0 ? 1 : out + 1 (wm_conv3x3_fwd_elu keeps no input).
  * wm_add_scaled : out = a + alpha * b.
  * wm_qfatt_fwd  : out = x + gamma[b,c] * res + beta[b,c] (gamma / beta f32 [B][ldv]); wm_qfatt_bwd: gres = gamma * g,
  *                 ggamma[b,c] = sum_p g * res, gbeta[b,c] = sum_p g (the gradient wrt x is g itself); scratch:

@@ -36,7 +36,7 @@ WM_DECL_STREAM(_f16);
                                   int tiles_per_wg, hipStream_t s, int reverse, const float* bw_stats4 = nullptr, int bw_ld = 0,            \
                                   const float* bw_coef = nullptr, const float* bw_gvec = nullptr, const void* ry = nullptr,                 \
                                   const float* r_scale = nullptr, const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr, \
-                                  const void* addend = nullptr)
+                                  const void* addend = nullptr, int act = 0)
 WM_DECL_WS(_bf16);
 WM_DECL_WS(_f16);
 // the two compilations of conv3x3_ws.hip, by activation dtype (WM_BF16 / WM_F16)
@@ -485,6 +485,46 @@ extern "C" int wm_conv3x3_dgrad_applyfused(const void* g, const void* y, const f
                                         ws_tiles_per_wg(ntiles), (hipStream_t)stream, sweep_reverse ? 1 : 0, stats4, 64, coef, nullptr, ry, r_scale, r_shift, y, dy_out);
     WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_dgrad_applyfused: no kernel for this shape");
     WM_LAUNCH_CHECK("wm_conv3x3_dgrad_applyfused");
+    return WM_OK;
+}
+
+// conv + bias + ELU as one launch, and its backward's input-gradient half with the ELU derivative, gz and the bias gradient's partial sums
+// formed while the tiles are staged (rows f1 / f2: the coupling subnets, models/invertible_net.py:326-366)
+extern "C" int wm_conv3x3_fwd_elu_supported(int Cin, int CoutP, int dtype) {
+    return (is16(dtype) && CoutP == 64 && (Cin == 64 || Cin == 32 || Cin == 16) && use_ws(Cin, CoutP, dtype)) ? 1 : 0;
+}
+extern "C" int wm_conv3x3_fwd_elu(const void* x, int ldx, const void* wp, const float* bias, int nbias, void* out, int B, int H, int W, int Cin,
+                                  int dtype, int sweep_reverse, void* stream) {
+    WM_REQUIRE(x && wp && out, WM_E_BADARG, "wm_conv3x3_fwd_elu: null pointer");
+    WM_REQUIRE(B > 0 && H > 0 && W > 0, WM_E_BADARG, "wm_conv3x3_fwd_elu: bad shape");
+    WM_REQUIRE(wm_conv3x3_fwd_elu_supported(Cin, 64, dtype), WM_E_SHAPE, "wm_conv3x3_fwd_elu: unsupported Cin=%d dtype=%d (16-bit dtypes, Cin in {16, 32, 64}, 64 output channels)", Cin, dtype);
+    WM_REQUIRE(ldx >= Cin && (ldx * 2) % 16 == 0 && nbias >= 0 && nbias <= 64, WM_E_SHAPE, "wm_conv3x3_fwd_elu: bad ldx=%d / nbias=%d", ldx, nbias);
+    WM_REQUIRE((((uintptr_t)x | (uintptr_t)wp | (uintptr_t)out) & 15) == 0, WM_E_SHAPE, "wm_conv3x3_fwd_elu: pointers must be 16-byte aligned");
+    const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
+    const int rc = wm_launch_conv3x3_ws(dtype, x, ldx, Cin, 64, wp, bias, nbias, nullptr, nullptr, out, nullptr, B, H, W, ws_wgs(ntiles),
+                                        ws_tiles_per_wg(ntiles), (hipStream_t)stream, sweep_reverse ? 1 : 0, nullptr, 0, nullptr, nullptr, nullptr,
+                                        nullptr, nullptr, nullptr, nullptr, nullptr, 1);
+    WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_fwd_elu: no kernel for this shape");
+    WM_LAUNCH_CHECK("wm_conv3x3_fwd_elu");
+    return WM_OK;
+}
+extern "C" int wm_conv3x3_dgrad_elufused_supported(int CinP, int dtype) {
+    return (is16(dtype) && (CinP == 64 || CinP == 32) && use_ws(64, CinP, dtype)) ? 1 : 0;
+}
+extern "C" int wm_conv3x3_dgrad_elufused_nparts(int B, int H, int W) { return ws_wgs(B * wm_cdiv(H, TH) * wm_cdiv(W, TW)); }
+extern "C" int wm_conv3x3_dgrad_elufused(const void* g, const void* out, const void* wpt, void* dx, void* gz_out, float* bias_partials, int B,
+                                         int H, int W, int CinP, int dtype, int sweep_reverse, void* stream) {
+    WM_REQUIRE(g && out && wpt && dx && bias_partials, WM_E_BADARG, "wm_conv3x3_dgrad_elufused: null pointer");   // (gz_out may be NULL: no weight gradient wanted)
+    WM_REQUIRE(B > 0 && H > 0 && W > 0, WM_E_BADARG, "wm_conv3x3_dgrad_elufused: bad shape");
+    WM_REQUIRE(wm_conv3x3_dgrad_elufused_supported(CinP, dtype), WM_E_SHAPE, "wm_conv3x3_dgrad_elufused: unsupported CinP=%d dtype=%d", CinP, dtype);
+    WM_REQUIRE((((uintptr_t)g | (uintptr_t)out | (uintptr_t)wpt | (uintptr_t)dx | (uintptr_t)gz_out) & 15) == 0, WM_E_SHAPE,
+               "wm_conv3x3_dgrad_elufused: pointers must be 16-byte aligned");
+    const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
+    const int rc = wm_launch_conv3x3_ws(dtype, g, 64, 64, CinP, wpt, nullptr, 0, nullptr, nullptr, dx, bias_partials, B, H, W, ws_wgs(ntiles),
+                                        ws_tiles_per_wg(ntiles), (hipStream_t)stream, sweep_reverse ? 1 : 0, nullptr, 0, nullptr, nullptr, nullptr,
+                                        nullptr, nullptr, out, gz_out, nullptr, 1);
+    WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_dgrad_elufused: no kernel for this shape");
+    WM_LAUNCH_CHECK("wm_conv3x3_dgrad_elufused");
     return WM_OK;
 }
 

@@ -90,9 +90,25 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 // ADDIN (forward, M16): the consumers add a second tensor `a.ry` [B,H,W,COUT] (same 16-bit dtype) to the accumulators before the
 // statistics and the pack -- y = conv(x) + addend.  The encoder's after-concat layer (hidden_models/encoder.py:25,40) runs as
 // conv64(features) + [conv(image) + message bias] this way: the 97-channel concat tensor is never built (csrc/concat_side.hip)
+// ACT == 1 (rows f1 / f2: the coupling subnets' conv + ELU, models/invertible_net.py:326-366): the consumers write elu(conv + bias) -- the
+// pre-activation is never stored; its backward needs only the output (elu'(z) = out > 0 ? 1 : out + 1)
+// BNBWD == 3 (the backward of such a layer): the two-stream form of BNBWD == 2 with the ELU derivative instead of the BatchNorm fold --
+// x is g (gradient wrt the ELU output), ay the layer's OUTPUT; the producers form gz = g * (out > 0 ? 1 : out + 1), publish it, write each
+// tile's own pixels to dy_out for the weight gradient and sum them per channel into `stat` [gridDim.x][COUT... 64] (the bias gradient's partials)
+// ELU of an f32 accumulator, cheap enough for the MFMA waves' epilogue (expm1f costs ~25 instructions): exp - 1 away from zero, the cubic
+// Taylor polynomial near it (|z| < 1/64: its error z^4 / 24 < 3e-9 |z|; the hardware exp's cancellation would show in f16 there)
+__device__ __forceinline__ float ws_elu(float z) {
+    const float e = __expf(z) - 1.f;
+    const float p = z * __builtin_fmaf(z, __builtin_fmaf(z, 0.16666667f, 0.5f), 1.f);
+    const float neg = __builtin_fabsf(z) < 0.015625f ? p : e;
+    return z > 0.f ? z : neg;
+}
+
 template <int CIN, int COUT, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false, int BNBWD = 0, bool BWDST = false, bool PIN = true,
-          bool ADDIN = false, bool WHOLE = false>
+          bool ADDIN = false, bool WHOLE = false, int ACT = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned long long* __restrict__ stamps = nullptr) {
+    static_assert(ACT == 0 || (!STATS && !BWDST && BNBWD == 0 && !ADDIN), "ACT: plain forward form");
+    static_assert(BNBWD != 3 || (!STATS && !BWDST && M16), "BNBWD == 3: no other reduction in the same launch");
     static_assert(!ADDIN || (M16 && !BWDST && BNBWD == 0), "ADDIN: forward form of the 16x16x32 consumers");
     static_assert(CIN == 64 || CIN == 32 || CIN == 16, "input channels");
     static_assert(!M16 || CIN % 32 == 0, "the 16x16x32 MFMA consumes 32 input channels per step");
@@ -195,13 +211,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             }
         }
         static_assert(!(BNBWD && XFORM), "one input transform at a time");
-        static_assert(BNBWD != 2 || CIN == 64, "the tensor-gradient form is built for 64-channel layers");
+        static_assert(BNBWD < 2 || CIN == 64, "the tensor-gradient forms are built for 64-channel layers");
         float kca[8];   // BNBWD == 2: ca of the 8 channels
         float kb[4][8], k3g[8];   // BNBWD: scale, shift, k2, k3 of this thread's 8 channels (wm_bn_fold); k3g = k3 + ca*gvec[sample being published]
         int gvb = -1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) k3g[e] = 0.f;
-        if (BNBWD) {
+        if (BNBWD == 1 || BNBWD == 2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int c = vec * 8 + e;
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
         const bool last_live = EDGE ? (((ptid + 256 * (XVP - 1 - KMAIN)) >> 3) < 36) : (((ptid + 256 * (XVP - 1)) / VPP) < NPIX);
         // does tile T start with the two columns its predecessor in the run ended with?
         auto reuse_of = [&](int T) {
-            if (!(EDGE && BNBWD != 2 && !(a.dbg & 64) && T > t_begin)) return false;
+            if (!(EDGE && BNBWD < 2 && !(a.dbg & 64) && T > t_begin)) return false;
             const int tt = a.reverse ? t_begin + (t_end - 1 - T) : T;
             const int col = tt - fdiv(tt, a.tilesX, a.mX) * a.tilesX;
             return a.reverse ? col != a.tilesX - 1 : col != 0;
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             for (int q = 0; q < 4; ++q) w[q] &= keep;
             if (k + 1 < XVP || last_live) *reinterpret_cast<u32x4*>(sX + lds[k]) = w;
         };
-        if constexpr (BNBWD == 2) {
+        if constexpr (BNBWD >= 2) {
             // vectors whose halo pixel is one of the tile's own 16x16 pixels: those are written out as dy
             unsigned wmask = 0;
 #pragma unroll
@@ -326,6 +342,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 if (hpy[k] >= 1 && hpy[k] <= TH && hpx[k] >= 1 && hpx[k] <= TW && (k + 1 < XVP || last_live)) wmask |= 1u << k;
             hx8 dG[XVP], dY[XVP];
             unsigned ok = 0;
+            float bsum[8];   // BNBWD == 3: this thread's part of the bias gradient (its 8 channels over the own pixels it stages)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
             auto load_both = [&](const TileGeo& g) {
                 if (is_interior(g)) {
                     const hx_t* gt = tile_ptr(g);
@@ -348,16 +367,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 for (int k = 0; k < XVP; ++k) {
                     u32x4 w = __builtin_bit_cast(u32x4, dG[k]);
                     const u32x4 wy = __builtin_bit_cast(u32x4, dY[k]);
+                    const unsigned inimg = (ok >> k) & 1u, keep = 0u - inimg;
+                    const float own = (((wmask >> k) & 1u) && inimg) ? 1.f : 0.f;
 #pragma unroll
                     for (int pq = 0; pq < 4; ++pq) {
-                        const float d0 = wm_bn_fold_dyg(HX::lo(wy[pq]), HX::lo(w[pq]), kb[0][2 * pq],
-                                                        kb[1][2 * pq], kca[2 * pq], kb[2][2 * pq], kb[3][2 * pq]);
-                        const float d1 = wm_bn_fold_dyg(HX::hi(wy[pq]), HX::hi(w[pq]),
-                                                        kb[0][2 * pq + 1], kb[1][2 * pq + 1], kca[2 * pq + 1], kb[2][2 * pq + 1], kb[3][2 * pq + 1]);
+                        float d0, d1;
+                        if (BNBWD == 3) {
+                            const float o0 = HX::lo(wy[pq]), o1 = HX::hi(wy[pq]);
+                            d0 = HX::lo(w[pq]) * (o0 > 0.f ? 1.f : o0 + 1.f);
+                            d1 = HX::hi(w[pq]) * (o1 > 0.f ? 1.f : o1 + 1.f);
+                            bsum[2 * pq] = __builtin_fmaf(d0, own, bsum[2 * pq]);
+                            bsum[2 * pq + 1] = __builtin_fmaf(d1, own, bsum[2 * pq + 1]);
+                        } else {
+                            d0 = wm_bn_fold_dyg(HX::lo(wy[pq]), HX::lo(w[pq]), kb[0][2 * pq],
+                                                kb[1][2 * pq], kca[2 * pq], kb[2][2 * pq], kb[3][2 * pq]);
+                            d1 = wm_bn_fold_dyg(HX::hi(wy[pq]), HX::hi(w[pq]),
+                                                kb[0][2 * pq + 1], kb[1][2 * pq + 1], kca[2 * pq + 1], kb[2][2 * pq + 1], kb[3][2 * pq + 1]);
+                        }
                         const hx2 pk = HX::pack2(d0, d1);
                         w[pq] = __builtin_bit_cast(unsigned, pk);
                     }
-                    const unsigned inimg = (ok >> k) & 1u, keep = 0u - inimg;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) w[q] &= keep;
                     if (k + 1 < XVP || last_live) *reinterpret_cast<u32x4*>(sX + lds[k]) = w;
@@ -380,7 +409,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 __syncthreads();
                 stamp(2);
             }
-            if (STATS || BWDST) __syncthreads();
+            if (BNBWD == 3) {   // lanes l, l + 8, ... of a wave stage the same 8 channels: fold them, one row of 64 sums per producer wave
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float u = bsum[e];
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1) u += __shfl_xor(u, o, 64);
+                    if (lane < 8) sRed[(wave - 4) * C64 + vec * 8 + e] = u;
+                }
+            }
+            if (STATS || BWDST || BNBWD == 3) __syncthreads();
             return;
         }
         hx8 dA[XVP], dB[XVP];
@@ -535,6 +573,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
                 const int nf = j >> 1, i0 = 2 * (j & 1);
                 float v0 = acc[mf][nf][i0], v1 = acc[mf][nf][i0 + 1];
                 if (ADDIN) { v0 += HX::lo(ryv[ml][j]); v1 += HX::hi(ryv[ml][j]); }
+                if (ACT == 1) { v0 = ws_elu(v0); v1 = ws_elu(v1); }
                 if (STATS) {   // scalar f32 on purpose (packed f32 VALU is slow beside MFMAs)
                     const float t0 = v0 * d[ml].mk, t1 = v1 * d[ml].mk;
                     s1[2 * j] += t0; s1[2 * j + 1] += t1;
@@ -654,6 +693,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             o[0] = ph[0]; o[1] = ph[1]; o[2] = ph[2]; o[3] = ph[3];
             o[4] = now() - t_start; o[5] = rt_end - rt_start;
         }
+        if (BNBWD == 3) {
+            __syncthreads();  // matched by the producers' final barrier: their four rows of channel sums are in sRed
+            if (tid < C64) a.stat[(size_t)blockIdx.x * C64 + tid] = sRed[tid] + sRed[C64 + tid] + sRed[2 * C64 + tid] + sRed[3 * C64 + tid];
+        }
         if (STATS || BWDST) {
             // (the lane's channel base is re-derived from an opaque copy of the thread index: the compiler otherwise keeps the pre-loop
             // value alive across the whole tile loop -- in the BWDST forms, which sit at the 256-register limit, by spilling it)
@@ -713,7 +756,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
     auto drain_step = [&](int m, int mf, const Drain& d) {
         const int nf = m / 9, j = m - nf * 9;
         if (j < 8) {
-            const float v0 = acc[mf][nf][2 * j], v1 = acc[mf][nf][2 * j + 1];
+            float v0 = acc[mf][nf][2 * j], v1 = acc[mf][nf][2 * j + 1];
+            if (ACT == 1) { v0 = ws_elu(v0); v1 = ws_elu(v1); }
             if (STATS) {   // scalar f32 on purpose (packed f32 VALU is slow beside MFMAs)
                 const float t0 = v0 * d.mk, t1 = v1 * d.mk;
                 s1[nf][j][0] += t0; s1[nf][j][1] += t1;
@@ -868,7 +912,8 @@ int WM_HSYM(wm_launch_conv3x3_ws)(const void* x, int ldx, int Cin, int CoutP, co
                            const float* in_shift, void* y, float* stat, int B, int H, int W, int wgs, int tiles_per_wg,
                            hipStream_t s, int reverse, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
                            const float* bw_gvec = nullptr, const void* ry = nullptr, const float* r_scale = nullptr,
-                           const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr, const void* addend = nullptr) {
+                           const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr, const void* addend = nullptr,
+                           int act = 0) {
     WsArgs a;
     a.dbg = g_ws_variant == 3 ? 8 : (g_ws_variant == 8 ? 64 : (g_ws_variant == 10 ? 128 : 0)); a.xcd_map = g_ws_variant != 2;
     a.x = (const hx_t*)x; a.ldx = ldx; a.wp = (const hx_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
@@ -884,6 +929,20 @@ int WM_HSYM(wm_launch_conv3x3_ws)(const void* x, int ldx, int Cin, int CoutP, co
         if (Cin != 64 || CoutP != 64 || !in_scale || !stat || ay || ry || bw_stats4) return WM_E_SHAPE;
         a.ry = (const hx_t*)addend;
         hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, true, true, true, false, 0, false, true, true>), grid, block, 0, s, a, nullptr);
+        return WM_OK;
+    }
+    if (act && ay) {   // backward of a conv + ELU layer: x = g, ay = the layer's output, dy_out = gz for the weight gradient, stat = the bias gradient's partial rows
+        if (Cin != 64 || (CoutP != 64 && CoutP != 32) || ldx != 64 || in_scale || bw_stats4 || ry || !stat || addend) return WM_E_SHAPE;
+        if (CoutP == 32) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 32, false, false, true, false, 3, false>), grid, block, 0, s, a, nullptr);
+        else hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, 3, false>), grid, block, 0, s, a, nullptr);
+        return WM_OK;
+    }
+    if (act) {   // forward conv + bias + ELU (the pre-activation is not stored)
+        if (CoutP != 64 || in_scale || stat || bw_stats4 || ry || addend) return WM_E_SHAPE;
+        if (Cin == 64) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, 0, false, true, false, false, 1>), grid, block, 0, s, a, nullptr);
+        else if (Cin == 32) hipLaunchKernelGGL((conv3x3_ws_kernel<32, 64, false, false, true, false, 0, false, true, false, false, 1>), grid, block, 0, s, a, nullptr);
+        else if (Cin == 16) hipLaunchKernelGGL((conv3x3_ws_kernel<16, 64, false, false, false, false, 0, false, true, false, false, 1>), grid, block, 0, s, a, nullptr);
+        else return WM_E_SHAPE;
         return WM_OK;
     }
     if (ay) {   // dgrad with the BatchNorm-backward apply (tensor gradient) fused; x = g, dy written out for the weight gradient

@@ -10,7 +10,8 @@
 
 namespace {
 
-enum { ACT_RELU = 0, ACT_LRELU = 1, ACT_GELU = 2, ACT_ELU = 3, ACT_SIGMOID = 4, ACT_TANH = 5 };
+enum { ACT_RELU = 0, ACT_LRELU = 1, ACT_GELU = 2, ACT_ELU = 3, ACT_SIGMOID = 4, ACT_TANH = 5,
+       ACT_ELU_OUT = 6 };   // backward only: the ELU derivative from the layer's OUTPUT (out > 0 ? 1 : out + 1) -- the fused conv + ELU keeps no pre-activation
 
 __device__ __forceinline__ float act_f(int kind, float x) {
     switch (kind) {
@@ -29,6 +30,7 @@ __device__ __forceinline__ float act_d(int kind, float x) {
         case ACT_GELU: return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
         case ACT_ELU: return x > 0.f ? 1.f : expf(x);
         case ACT_SIGMOID: { const float s = 1.f / (1.f + expf(-x)); return s * (1.f - s); }
+        case ACT_ELU_OUT: return x > 0.f ? 1.f : x + 1.f;
         default: { const float t = tanhf(x); return 1.f - t * t; }
     }
 }
@@ -480,7 +482,7 @@ extern "C" int wm_unary_fwd(const void* x, void* y, size_t n, int kind, int dtyp
     return WM_OK;
 }
 extern "C" int wm_unary_bwd(const void* x, const void* gy, void* gx, size_t n, int kind, int dtype, void* stream) {
-    WM_REQUIRE(x && gy && gx && n > 0 && kind >= 0 && kind <= 5, WM_E_BADARG, "wm_unary_bwd: bad arguments");
+    WM_REQUIRE(x && gy && gx && n > 0 && kind >= 0 && kind <= 6, WM_E_BADARG, "wm_unary_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     WM_DISPATCH_DTYPE(dtype, "wm_unary_bwd", {
         if (vec_ok(n, (int)sizeof(T), x, gy, gx))
@@ -494,7 +496,7 @@ extern "C" size_t wm_unary_bwd_colsum_scratch_floats(size_t npix, int C) { retur
 // gx = gy * act'(x) over x [npix][C]; out [Creal] f32 (+)= column sums of gx.  part: wm_unary_bwd_colsum_scratch_floats(npix, C) floats.
 extern "C" int wm_unary_bwd_colsum(const void* x, const void* gy, void* gx, size_t npix, int C, int kind, float* part, float* out, int Creal, int accumulate,
                                    int dtype, void* stream) {
-    WM_REQUIRE(x && gy && gx && part && out && npix > 0 && C > 0 && C % 16 == 0 && Creal > 0 && Creal <= C && kind >= 0 && kind <= 5, WM_E_BADARG,
+    WM_REQUIRE(x && gy && gx && part && out && npix > 0 && C > 0 && C % 16 == 0 && Creal > 0 && Creal <= C && kind >= 0 && kind <= 6, WM_E_BADARG,
                "wm_unary_bwd_colsum: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const int ns = ubc_nsplit(npix);

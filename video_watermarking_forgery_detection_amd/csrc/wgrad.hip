@@ -284,11 +284,53 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgArgs<T> a) {
 constexpr int RSPLIT = 8, RQUADS = 256 / RSPLIT;
 // Workgroups >= nred carry a rider: the BatchNorm-backward finalisation of another layer (WmBnBwdFin, 8 channels each) -- in a
 // backward sweep the sums of layer l-1 are ready when layer l's weight gradient runs, and a launch of its own would cost 5 us.
+// A second rider (the LAST workgroup when `cs.partials` is set): the column sums of per-workgroup partial rows -- the bias gradient of a
+// conv + ELU layer whose input-gradient kernel left them (wm_conv3x3_dgrad_elufused) -- folded in a fixed order.
+struct ColsumRider { const float* partials; int nparts, C; float* out; int accumulate; };
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nslabs, int CinP, int CoutP,
                                                            float* __restrict__ dw, int Cin, int Cout,
-                                                           const int* __restrict__ perm, int accumulate, int nred, WmBnBwdFin fin) {
+                                                           const int* __restrict__ perm, int accumulate, int nred, WmBnBwdFin fin, ColsumRider cs) {
     __shared__ float4 red[RSPLIT][RQUADS];
     static_assert(sizeof(float4) * RSPLIT * RQUADS >= sizeof(double) * 2 * 32 * 8, "the rider's LDS fits in the reduction's");
+    if (cs.partials && blockIdx.x == gridDim.x - 1) {
+        // thread (cq, grp): channels 4 cq .. 4 cq + 3 of the rows grp, grp + 16, ...: 16-byte loads, four in flight; the 16 groups are then
+        // folded in a fixed order (C a multiple of 4: the rows are those of a 16-bit activation)
+        float4* r4 = &red[0][0];
+        for (int c0 = 0; c0 < cs.C; c0 += 64) {
+            const int cq = threadIdx.x & 15, grp = threadIdx.x >> 4, c = c0 + 4 * cq;
+            float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+            if (c < cs.C) {
+                const float* base = cs.partials + c;
+                int k = grp;
+                for (; k + 48 < cs.nparts; k += 64) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)k * cs.C);
+                    const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)(k + 16) * cs.C);
+                    const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)(k + 32) * cs.C);
+                    const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)(k + 48) * cs.C);
+                    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+                    a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+                    a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+                    a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+                }
+                for (; k < cs.nparts; k += 16) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)k * cs.C);
+                    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+                }
+            }
+            r4[threadIdx.x] = float4{(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w)};
+            __syncthreads();
+            if (threadIdx.x < 64 && c0 + (int)threadIdx.x < cs.C) {
+                const int q = threadIdx.x >> 2, e = threadIdx.x & 3;
+                float sum = 0.f;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) sum += reinterpret_cast<const float*>(&r4[g * 16 + q])[e];
+                float* o = cs.out + c0 + threadIdx.x;
+                *o = (cs.accumulate ? *o : 0.f) + sum;
+            }
+            __syncthreads();
+        }
+        return;
+    }
     if ((int)blockIdx.x >= nred) {
         wm_bn_bwd_finalize_block(fin, (int)blockIdx.x - nred, reinterpret_cast<double*>(&red[0][0]));
         return;
@@ -353,7 +395,7 @@ static bool fin_rider_ok(const WmBnBwdFin* fin) {
 }
 // the slab reduction (+ an optional rider)
 static int launch_wgrad_reduce(float* ws, int nslabs, int CinP, int CoutP, float* dw, int Cin, int Cout, const int* perm, int accumulate,
-                               const WmBnBwdFin* fin, hipStream_t s) {
+                               const WmBnBwdFin* fin, hipStream_t s, ColsumRider cs = ColsumRider{nullptr, 0, 0, nullptr, 0}) {
     const size_t slab_elems = (size_t)9 * CinP * CoutP;
     const size_t rb = (slab_elems / 4 + RQUADS - 1) / RQUADS;
     const int blocks = (int)(rb > 2048 ? 2048 : rb);
@@ -364,8 +406,9 @@ static int launch_wgrad_reduce(float* ws, int nslabs, int CinP, int CoutP, float
         f = *fin;
         extra = wm_cdiv(fin->CP, 8);
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks + extra), dim3(256), 0, s, ws, nslabs, CinP, CoutP, dw, Cin, Cout, perm, accumulate,
-                       blocks, f);
+    if (cs.partials && (!cs.out || cs.nparts <= 0 || cs.C <= 0 || cs.C % 4 != 0 || (((uintptr_t)cs.partials) & 15) != 0)) return WM_E_BADARG;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks + extra + (cs.partials ? 1 : 0)), dim3(256), 0, s, ws, nslabs, CinP, CoutP, dw, Cin, Cout, perm,
+                       accumulate, blocks, f, cs);
     return WM_OK;
 }
 
@@ -494,6 +537,27 @@ extern "C" int wm_conv3x3_wgrad_fin(const void* x, int ldx, int CinX, const floa
     WM_REQUIRE(launch_wgrad_reduce(ws, nsl, CinP, CoutP, dw, Cin, Cout, perm_dev, accumulate, fin, s) == WM_OK, WM_E_BADARG,
                "wm_conv3x3_wgrad: bad finalisation rider");
     WM_LAUNCH_CHECK("wm_conv3x3_wgrad(reduce)");
+    return WM_OK;
+}
+// the weight gradient of a conv + ELU layer (16-bit dtypes): dw as wm_conv3x3_wgrad from (x, gz), and in the SAME reduction launch the bias
+// gradient db [Cout] (+)= the column sums of the partial rows wm_conv3x3_dgrad_elufused left (bias_partials f32 [nparts][CoutY])
+extern "C" int wm_conv3x3_wgrad_bias(const void* x, int ldx, int CinX, const void* gz, int ldgz, int CoutY, float* ws, float* dw, int accumulate,
+                                     int B, int H, int W, int Cin, int Cout, int dtype, const float* bias_partials, int nparts, float* db,
+                                     int db_accumulate, void* stream) {
+    WM_REQUIRE(x && gz && ws && dw && bias_partials && db, WM_E_BADARG, "wm_conv3x3_wgrad_bias: null pointer");
+    WM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && CinX >= Cin && CoutY >= Cout && nparts > 0, WM_E_BADARG, "wm_conv3x3_wgrad_bias: bad shape");
+    WM_REQUIRE(is16(dtype), WM_E_BADARG, "wm_conv3x3_wgrad_bias: 16-bit dtypes only (got %d)", dtype);
+    WM_REQUIRE(CinX % 8 == 0 && CoutY % 8 == 0 && ldx >= CinX && ldgz >= CoutY && (ldx * 2) % 16 == 0 && (ldgz * 2) % 16 == 0, WM_E_SHAPE,
+               "wm_conv3x3_wgrad_bias: channel counts %d/%d must be multiples of 8 and the pixel strides cover them", CinX, CoutY);
+    hipStream_t s = (hipStream_t)stream;
+    const int nsl = nslabs_ch(B, H, W, CinX, CoutY);
+    wm_launch_wgrad_ws(dtype, x, ldx, CinX, nullptr, nullptr, gz, ldgz, CoutY, ws, B, H, W, nsl, s, 0);
+    WM_LAUNCH_CHECK("wm_conv3x3_wgrad_bias");
+    const int CinP = wm_cdiv(CinX, CB) * CB, CoutP = wm_cdiv(CoutY, CB) * CB;
+    // (the rows hold CoutY sums each; the first Cout of them are the bias gradient)
+    WM_REQUIRE(launch_wgrad_reduce(ws, nsl, CinP, CoutP, dw, Cin, Cout, nullptr, accumulate, nullptr, s,
+                                   ColsumRider{bias_partials, nparts, CoutY, db, db_accumulate}) == WM_OK, WM_E_BADARG, "wm_conv3x3_wgrad_bias: bad rider");
+    WM_LAUNCH_CHECK("wm_conv3x3_wgrad_bias(reduce)");
     return WM_OK;
 }
 extern "C" int wm_conv3x3_wgrad(const void* x, int ldx, int CinX, const float* in_scale, const float* in_shift,

@@ -138,6 +138,63 @@ def _conv_backward(x, weight, g, stride, pad, need_gx, need_gw, want_bias, plan_
     return gx, gw, gb
 
 
+FUSE_ELU = True   # (tests switch it off to compare with the separate launches)
+
+
+def _elu_fused(kind, weight, stride, pad, x):
+    return (FUSE_ELU and kind == "elu" and tuple(weight.shape[2:]) == (3, 3) and stride == 1 and pad == 1 and weight.shape[0] == 64
+            and x.shape[3] == cpad(weight.shape[1]) and ops.conv3x3_fwd_elu_supported(x.shape[3], 64, x.dtype))
+
+
+class _ConvEluFn(Function):
+    """elu(nn.Conv2d(x)) for the 3x3 layers the persistent kernel takes (16-bit activations, 64 output channels, 16 / 32 / 64 input
+    channels: the coupling subnets' conv1..conv4, models/invertible_net.py:326-366) in ONE launch forwards -- only the output is kept --
+    and TWO + the slab reduction backwards: the input-gradient kernel forms gz = g * elu'(.) from (g, out) while it stages its tiles,
+    writes gz for the weight gradient and leaves the bias gradient's partial sums, which the weight gradient's reduction launch folds
+    (before: conv, ELU | ELU' + column sums, their reduce, input gradient, weight gradient, its reduce)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        ctx.plan_ok = isinstance(weight, nn.Parameter)
+        ctx.bias_ptr = bias.data_ptr() if bias is not None else 0
+        ctx.has_bias = bias is not None
+        wp = _pack3(weight, 64, x.shape[3], x.dtype, False, ctx.plan_ok)
+        out = ops.conv3x3_fwd_elu(x, wp, _pad_bias(bias, 64))
+        ctx.save_for_backward(x, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, out = ctx.saved_tensors
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        need_gx, need_gw, need_gb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        g = g.contiguous()
+        if x.shape[3] in (64, 32) and ops.conv3x3_dgrad_elufused_supported(x.shape[3], g.dtype):
+            wt = _pack3(weight, 64, x.shape[3], g.dtype, True, ctx.plan_ok)
+            gx, gz, part = ops.conv3x3_dgrad_elufused(g, out, wt, want_gz=need_gw)
+            gb = None
+        else:   # (the 16-channel first layers: their input gradient runs on the general kernel)
+            bacc = _flat_grad(ctx.bias_ptr, Cout) if need_gb else None
+            gz, gb = ops.unary_bwd_colsum(out, g, "elu_out", Cout, db_acc=bacc)
+            gx, gw, _ = _conv_backward(x, weight, gz, 1, 1, need_gx, need_gw, False, ctx.plan_ok)
+            return (gx if need_gx else None), gw, (gb if need_gb and bacc is None else None)
+        gw = None
+        if need_gw or need_gb:
+            wacc = _flat_grad(weight.data_ptr(), weight.numel())
+            bacc = _flat_grad(ctx.bias_ptr, Cout) if need_gb else None
+            if wacc is None or (need_gb and bacc is None):
+                wacc = bacc = None
+            gw = wacc.view(Cout, Cin, 3, 3) if wacc is not None else torch.empty(Cout, Cin, 3, 3, device=g.device, dtype=torch.float32)
+            gb = bacc if bacc is not None else torch.empty(Cout, device=g.device, dtype=torch.float32)
+            ops.conv3x3_wgrad_bias(x, gz, gw, wacc is not None, part, gb, bacc is not None)
+            if wacc is not None:
+                gw = gb = None
+            elif not need_gb:
+                gb = None
+        return (gx if need_gx else None), gw, gb
+
+
 class _ConvActFn(Function):
     """act(nn.Conv2d(x)) as ONE autograd node: the backward forms gz = g * act'(z) and the bias gradient (its column sums) in one pass
     over the data (ops.unary_bwd_colsum: two launches instead of three, gz not read back), then the convolution's two gradients from gz"""
@@ -370,7 +427,10 @@ class ConvAct(nn.Module):
 
     def forward(self, x):
         c = self._modules["0"]
-        return _ConvActFn.apply(x, c.effective_weight(), c.bias, c.stride, c.padding, self.kind)
+        w = c.effective_weight()
+        if _elu_fused(self.kind, w, c.stride, c.padding, x):
+            return _ConvEluFn.apply(x, w, c.bias)
+        return _ConvActFn.apply(x, w, c.bias, c.stride, c.padding, self.kind)
 
     def extra_repr(self):
         return self.kind
@@ -386,7 +446,11 @@ class FusedSequential(nn.Sequential):
         while i < len(mods):
             m = mods[i]
             if isinstance(m, Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], Act):
-                x = _ConvActFn.apply(x, m.effective_weight(), m.bias, m.stride, m.padding, mods[i + 1].kind)
+                w = m.effective_weight()
+                if _elu_fused(mods[i + 1].kind, w, m.stride, m.padding, x):
+                    x = _ConvEluFn.apply(x, w, m.bias)
+                else:
+                    x = _ConvActFn.apply(x, w, m.bias, m.stride, m.padding, mods[i + 1].kind)
                 i += 2
             else:
                 x = m(x)

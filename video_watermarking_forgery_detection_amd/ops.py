@@ -693,6 +693,59 @@ def conv3x3_wgrad(x, CinX, in_scale, in_shift, dy, dw, accumulate, perm_dev=None
     return fcoef
 
 
+def conv3x3_fwd_elu_supported(Cin, CoutP, dtype):
+    return bool(_lib.lib().wm_conv3x3_fwd_elu_supported(c_int(Cin), c_int(CoutP), c_int(dt_id(dtype))))
+
+
+def conv3x3_fwd_elu(x, wp, bias):
+    """out [B,H,W,64] = elu(conv3x3(x, wp) + bias) in one launch (16-bit dtypes; the pre-activation is not stored)"""
+    _need_cuda(x, wp)
+    B, H, W, ldx = x.shape
+    Cin = wp.shape[2]
+    assert wp.shape[1] == 64 and Cin <= ldx
+    out = torch.empty(B, H, W, 64, device=x.device, dtype=x.dtype)
+    rc = _lib.lib().wm_conv3x3_fwd_elu(_p(x), c_int(ldx), _p(wp), _p(bias), c_int(0 if bias is None else bias.numel()), _p(out), c_int(B), c_int(H),
+                                       c_int(W), c_int(Cin), c_int(dtype_id(x)), c_int(0), _stream())
+    _lib.check(rc, "wm_conv3x3_fwd_elu")
+    return out
+
+
+def conv3x3_dgrad_elufused_supported(CinP, dtype):
+    return bool(_lib.lib().wm_conv3x3_dgrad_elufused_supported(c_int(CinP), c_int(dt_id(dtype))))
+
+
+def conv3x3_dgrad_elufused(g, out, wpt, want_gz=True):
+    """backward of a conv + ELU layer, input-gradient half: gz = g * (out > 0 ? 1 : out + 1) formed while staging; returns
+    (dx [B,H,W,CinP], gz [B,H,W,64] or None, bias_partials f32 [nparts,64])"""
+    _need_cuda(g, out, wpt)
+    B, H, W, C = g.shape
+    CinP = wpt.shape[1]
+    assert C == 64 and out.shape == g.shape and out.dtype == g.dtype and g.is_contiguous() and out.is_contiguous() and wpt.shape[2] == 64
+    L = _lib.lib()
+    dx = torch.empty(B, H, W, CinP, device=g.device, dtype=g.dtype)
+    gz = torch.empty_like(g) if want_gz else None
+    part = torch.empty(L.wm_conv3x3_dgrad_elufused_nparts(c_int(B), c_int(H), c_int(W)), 64, device=g.device, dtype=torch.float32)
+    rc = L.wm_conv3x3_dgrad_elufused(_p(g), _p(out), _p(wpt), _p(dx), _p(gz), _p(part), c_int(B), c_int(H), c_int(W), c_int(CinP),
+                                     c_int(dtype_id(g)), c_int(0), _stream())
+    _lib.check(rc, "wm_conv3x3_dgrad_elufused")
+    return dx, gz, part
+
+
+def conv3x3_wgrad_bias(x, gz, dw, accumulate, bias_partials, db, db_accumulate):
+    """dw [Cout,Cin,3,3] (+)= the weight gradient from (x, gz); db [Cout] (+)= the column sums of bias_partials, in the same reduction launch"""
+    B, H, W, ldx = x.shape
+    CoutY = gz.shape[-1]
+    L = _lib.lib()
+    L.wm_conv3x3_wgrad_ws_bytes.restype = c_size_t
+    ws = torch.empty(L.wm_conv3x3_wgrad_ws_bytes(c_int(B), c_int(H), c_int(W), c_int(ldx), c_int(CoutY)) // 4, device=x.device, dtype=torch.float32)
+    Cout, Cin = dw.shape[0], dw.shape[1]
+    assert dw.is_contiguous() and db.is_contiguous() and db.numel() == Cout and bias_partials.is_contiguous() and bias_partials.shape[1] == CoutY
+    rc = L.wm_conv3x3_wgrad_bias(_p(x), c_int(ldx), c_int(ldx), _p(gz), c_int(CoutY), c_int(CoutY), _p(ws), _p(dw), c_int(1 if accumulate else 0),
+                                 c_int(B), c_int(H), c_int(W), c_int(Cin), c_int(Cout), c_int(dtype_id(x)), _p(bias_partials),
+                                 c_int(bias_partials.shape[0]), _p(db), c_int(1 if db_accumulate else 0), _stream())
+    _lib.check(rc, "wm_conv3x3_wgrad_bias")
+
+
 # ----------------------------------------------------------------------------- heads
 def pool_stats_enabled():
     return bool(_lib.lib().wm_pool_stats_enabled())
@@ -1270,6 +1323,7 @@ def diffjpeg_bwd(x, gy, rounding, factor):
 
 # ----------------------------------------------------------------------------- general layer family (include/wm_hip.h)
 ACT_KINDS = {"relu": 0, "lrelu": 1, "gelu": 2, "elu": 3, "sigmoid": 4, "tanh": 5}
+ACT_BWD_KINDS = dict(ACT_KINDS, elu_out=6)   # backward only: the ELU derivative from the layer's output (conv3x3_fwd_elu keeps no pre-activation)
 
 
 def cpad(c):
@@ -1387,7 +1441,7 @@ def unary_bwd_colsum(x, gy, kind, creal, db_acc=None):
     L = _lib.lib()
     L.wm_unary_bwd_colsum_scratch_floats.restype = c_size_t
     part = torch.empty(L.wm_unary_bwd_colsum_scratch_floats(c_size_t(npix), c_int(C)), device=x.device, dtype=torch.float32)
-    rc = L.wm_unary_bwd_colsum(_p(x), _p(gy), _p(gx), c_size_t(npix), c_int(C), c_int(ACT_KINDS[kind]), _p(part), _p(db), c_int(creal),
+    rc = L.wm_unary_bwd_colsum(_p(x), _p(gy), _p(gx), c_size_t(npix), c_int(C), c_int(ACT_BWD_KINDS[kind]), _p(part), _p(db), c_int(creal),
                                c_int(0 if db_acc is None else 1),
                                c_int(dt_id(x.dtype)), _stream())
     _lib.check(rc, "wm_unary_bwd_colsum")
