@@ -15,7 +15,7 @@ dt = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 NAMES = ["haar", "chan_copy_", "coupling_fwd", "coupling_bwd", "gconv_fwd", "gconv_wgrad", "gcolsum", "conv3x3_fwd", "conv3x3_wgrad", "unary_fwd", "unary_bwd", "qfatt_fwd", "qfatt_bwd", "spectral_norm_fwd",
          "spectral_norm_bwd", "gconv_pack", "pack_w3x3", "add_scaled", "gpool_fwd", "gpool_bwd", "pad_nchw_to_nhwc", "pad_nchw_to_nhwc_bwd", "gunpack_nchw",
-         "gunpack_nchw_bwd", "adam_step", "clip_grad_norm_"]
+         "gunpack_nchw_bwd", "adam_step", "clip_grad_norm_", "conv3x3_fwd_elu", "conv3x3_dgrad_elufused", "conv3x3_wgrad_bias", "unary_bwd_colsum", "chan_place", "chan_copy"]
 events = []
 recording = [False]
 def wrap(name, fn):
