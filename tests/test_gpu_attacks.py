@@ -127,6 +127,29 @@ def test_median_vs_definition(k):
         assert abs(xg.grad.sum().item() - xr.grad.sum().item()) < 1e-2 * gy.abs().sum().item()
 
 
+@pytest.mark.parametrize("k", [3, 5])
+def test_median_backward_four_pixel_form_is_the_one_pixel_form(k):
+    """wm_median_bwd takes the four-pixels-per-thread kernel for 16-byte aligned planes with W % 4 == 0 and the one-pixel kernel otherwise: the
+    same taps in the same order -- bit-identical, at the benchmark's size and at a size with several blocks per row, ties at the zero-padded border included"""
+    from video_watermarking_forgery_detection_amd import ops
+    for shape, seed in (((16, 3, 256, 256), 5), ((2, 3, 40, 1032), 6), ((1, 1, 8, 4), 7)):
+        x = detgen.uniform(shape, seed).cuda()
+        _, idx = ops.median_fwd(x, k)
+        n = x.numel()
+        buf = torch.empty(n + 1, device="cuda")
+        buf[1:].copy_(detgen.normal(shape, seed + 20).cuda().reshape(-1))
+        gy_unaligned = buf[1:].view(shape)             # 4 bytes off a 16-byte boundary: the one-pixel kernel
+        gy = gy_unaligned.clone()                      # the four-pixel kernel
+        assert gy_unaligned.data_ptr() % 16 != 0 and gy.data_ptr() % 16 == 0 and gy_unaligned.is_contiguous()
+        a, b = ops.median_bwd(gy, idx, k), ops.median_bwd(gy_unaligned, idx, k)
+        assert torch.equal(a, b)
+        inner = (slice(None), slice(None), slice(k, -k), slice(k, -k))   # away from the zero padding every output routes its gradient to exactly one input
+        if shape[2] > 4 * k and shape[3] > 4 * k:
+            gi = torch.zeros_like(gy); gi[inner] = gy[inner]
+            ai = ops.median_bwd(gi, idx, k)
+            assert abs(float(ai.double().sum()) - float(gi.double().sum())) < 1e-9 * float(gi.abs().double().sum()) + 1e-6
+
+
 def test_resample_full_size_properties():
     """256x256 x 16: adjoint identity <R x, g> == <x, R^T g> for both kernels, identity at ratio 1."""
     from video_watermarking_forgery_detection_amd import ops
