@@ -185,7 +185,7 @@ def emit_measurements_md():
     A(f"<!-- generated by tools/summarise_profiles.py {tag} from profiles/{tag}_*: do not edit by hand -->")
     A("| quantity | value (files under `profiles/`) |")
     A("|---|---|")
-    A(f"| step time / throughput, C2 as `bench.py` runs it by default (two chains on two streams, replayed from a hipGraph; every {b.get('kernel_events_every')}th step enqueued on one stream with its kernels bracketed by events) | **{b['ms_per_step']:.3f} ms → {b['value']:.0f} frames/s** (`{tag}_bench_c2.json`; step events: median {b['ms_per_step_median_events']:.3f} ms, fastest {b['ms_per_step_min_events']:.3f} ms); host enqueue per replayed step {b['host_enqueue_ms_median']:.2f} ms" + (f", per eager step {b['host_enqueue_ms_median_eager_steps']:.2f} ms" if b.get('host_enqueue_ms_median_eager_steps') else "") + " |")
+    A(f"| step time / throughput, C2 as `bench.py` runs it by default (two chains on two streams, replayed from a hipGraph; every {b.get('kernel_events_every')}th step enqueued on one stream with its kernels bracketed by events) | **{b['ms_per_step']:.3f} ms → {b['value']:.0f} frames/s** (`{tag}_bench_c2.json`; step events: median {b['ms_per_step_median_events']:.3f} ms, fastest {b['ms_per_step_min_events']:.3f} ms); host enqueue per replayed step {b['host_enqueue_ms_median']:.2f} ms" + " |")
     try:
         modes = open(os.path.join(dst, f"{tag}_step_modes.txt")).read().strip().splitlines()
         A("| the step's four modes, same box, interleaved, two rounds (`" + f"{tag}_step_modes.txt" + "`) | " + "<br>".join(m.replace("|", "/") for m in modes) + " |")
