@@ -288,7 +288,8 @@ int wm_conv3x3_fwd_addin(const void* x, const void* wp, const float* in_scale, c
  *   wm_conv3x3_fwd_elu       : out [B,H,W,64] = elu(conv3x3(x, wp) + bias); x [B,H,W,Cin] stride ldx, Cin in {16, 32, 64}; the pre-activation
  *                              is not stored: elu'(z) = out > 0 ? 1 : out + 1.
  *   wm_conv3x3_dgrad_elufused: g [B,H,W,64] = the gradient wrt out; forms gz = g * (out > 0 ? 1 : out + 1) while staging, writes
- *                              dx [B,H,W,CinP] = conv3x3(gz, wpt) (wpt from wm_pack_w3x3, transposed; CinP in {64, 32}), gz_out [B,H,W,64]
+ *                              dx [B,H,W,CinP] = conv3x3(gz, wpt) (wpt from wm_pack_w3x3, transposed; CinP in {64, 32}; or CinP = 16 with
+ *                              wpt packed to 32 rows, the upper 16 zero -- dx keeps its 16-channel stride), gz_out [B,H,W,64]
  *                              (NULL: not wanted) and bias_partials f32 [wm_conv3x3_dgrad_elufused_nparts(B,H,W)][64]: per-workgroup
  *                              column sums of gz (before its rounding to 16 bits).
  *   wm_conv3x3_wgrad_bias    : dw [Cout][Cin][3][3] (+)= the weight gradient from (x, gz) as wm_conv3x3_wgrad (ws: the same scratch), and in

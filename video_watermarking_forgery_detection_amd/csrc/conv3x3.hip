@@ -36,7 +36,7 @@ WM_DECL_STREAM(_f16);
                                   int tiles_per_wg, hipStream_t s, int reverse, const float* bw_stats4 = nullptr, int bw_ld = 0,            \
                                   const float* bw_coef = nullptr, const float* bw_gvec = nullptr, const void* ry = nullptr,                 \
                                   const float* r_scale = nullptr, const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr, \
-                                  const void* addend = nullptr, int act = 0)
+                                  const void* addend = nullptr, int act = 0, int ldy = 0)
 WM_DECL_WS(_bf16);
 WM_DECL_WS(_f16);
 // the two compilations of conv3x3_ws.hip, by activation dtype (WM_BF16 / WM_F16)
@@ -508,8 +508,8 @@ extern "C" int wm_conv3x3_fwd_elu(const void* x, int ldx, const void* wp, const 
     WM_LAUNCH_CHECK("wm_conv3x3_fwd_elu");
     return WM_OK;
 }
-extern "C" int wm_conv3x3_dgrad_elufused_supported(int CinP, int dtype) {
-    return (is16(dtype) && (CinP == 64 || CinP == 32) && use_ws(64, CinP, dtype)) ? 1 : 0;
+extern "C" int wm_conv3x3_dgrad_elufused_supported(int CinP, int dtype) {   // (CinP = 16: the 32-channel consumers, half of them stored)
+    return (is16(dtype) && (CinP == 64 || CinP == 32 || CinP == 16) && use_ws(64, CinP == 16 ? 32 : CinP, dtype)) ? 1 : 0;
 }
 extern "C" int wm_conv3x3_dgrad_elufused_nparts(int B, int H, int W) { return ws_wgs(B * wm_cdiv(H, TH) * wm_cdiv(W, TW)); }
 extern "C" int wm_conv3x3_dgrad_elufused(const void* g, const void* out, const void* wpt, void* dx, void* gz_out, float* bias_partials, int B,
@@ -520,9 +520,10 @@ extern "C" int wm_conv3x3_dgrad_elufused(const void* g, const void* out, const v
     WM_REQUIRE((((uintptr_t)g | (uintptr_t)out | (uintptr_t)wpt | (uintptr_t)dx | (uintptr_t)gz_out) & 15) == 0, WM_E_SHAPE,
                "wm_conv3x3_dgrad_elufused: pointers must be 16-byte aligned");
     const int ntiles = B * wm_cdiv(H, TH) * wm_cdiv(W, TW);
-    const int rc = wm_launch_conv3x3_ws(dtype, g, 64, 64, CinP, wpt, nullptr, 0, nullptr, nullptr, dx, bias_partials, B, H, W, ws_wgs(ntiles),
+    // CinP = 16: wpt is packed with 32 rows (the upper 16 zero), dx keeps its 16-channel stride
+    const int rc = wm_launch_conv3x3_ws(dtype, g, 64, 64, CinP == 16 ? 32 : CinP, wpt, nullptr, 0, nullptr, nullptr, dx, bias_partials, B, H, W, ws_wgs(ntiles),
                                         ws_tiles_per_wg(ntiles), (hipStream_t)stream, sweep_reverse ? 1 : 0, nullptr, 0, nullptr, nullptr, nullptr,
-                                        nullptr, nullptr, out, gz_out, nullptr, 1);
+                                        nullptr, nullptr, out, gz_out, nullptr, 1, CinP);
     WM_REQUIRE(rc == WM_OK, WM_E_SHAPE, "wm_conv3x3_dgrad_elufused: no kernel for this shape");
     WM_LAUNCH_CHECK("wm_conv3x3_dgrad_elufused");
     return WM_OK;

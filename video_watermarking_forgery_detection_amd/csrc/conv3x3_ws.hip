@@ -43,7 +43,8 @@ struct WsArgs {
     const hx_t* wp;            // [9][64][64]
     const float* bias; int nbias;
     const float* in_scale; const float* in_shift;
-    hx_t* y;                   // dense [B,H,W,64]
+    hx_t* y;                   // dense [B,H,W,COUT]
+    int ldy;                   // NARROW (the 32-channel consumers only): the output's pixel stride when it is below COUT -- channels >= ldy are not stored
     float* stat;                 // [gridDim.x][2][64] or null
     int B, H, W, tilesX, tilesY, ntiles, tiles_per_wg;
     int dbg;      // STAMPS build only: 1 = skip the MFMA loop, 2 = skip the stores, 4 = skip the halo loads
@@ -105,8 +106,9 @@ __device__ __forceinline__ float ws_elu(float z) {
 }
 
 template <int CIN, int COUT, bool XFORM, bool STATS, bool M16 = false, bool STAMPS = false, int BNBWD = 0, bool BWDST = false, bool PIN = true,
-          bool ADDIN = false, bool WHOLE = false, int ACT = 0>
+          bool ADDIN = false, bool WHOLE = false, int ACT = 0, bool NARROW = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned long long* __restrict__ stamps = nullptr) {
+    static_assert(!NARROW || (M16 && COUT == 32 && !BWDST && !ADDIN && !STATS), "NARROW: an input gradient towards a 16-channel (stride) tensor");
     static_assert(ACT == 0 || (!STATS && !BWDST && BNBWD == 0 && !ADDIN), "ACT: plain forward form");
     static_assert(BNBWD != 3 || (!STATS && !BWDST && M16), "BNBWD == 3: no other reduction in the same launch");
     static_assert(!ADDIN || (M16 && !BWDST && BNBWD == 0), "ADDIN: forward form of the 16x16x32 consumers");
@@ -561,8 +563,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsArgs a, unsigned l
             // WHOLE (the launcher: H and W multiples of the 16 x 16 tile): every pixel of every tile is inside the image -- the mask is the
             // constant 1 and folds out of the statistics (one multiply per element less), the stores lose their predicate
             d.inb = WHOLE ? true : (gy < a.H && gx < a.W);
+            if (NARROW) d.inb = d.inb && CPL * q < a.ldy;      // (lanes whose channels lie beyond the output's stride store nothing)
             d.mk = BWDST ? (d.inb ? 0.f : __builtin_inff()) : (d.inb ? 1.f : 0.f);
-            d.yp = a.y + (((size_t)g.b * a.H + gy) * a.W + gx) * COUT + CPL * q;
+            d.yp = a.y + (((size_t)g.b * a.H + gy) * a.W + gx) * (NARROW ? a.ldy : COUT) + CPL * q;
             return d;
         };
         unsigned pk[NPAIR];
@@ -880,7 +883,7 @@ extern "C" int wm_debug_conv3x3_ws64_phases(const void* x, const void* wp, const
     a.in_shift = in_shift; a.y = (hx_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
     a.tilesX = wm_cdiv(W, TW); a.tilesY = wm_cdiv(H, TH); a.ntiles = B * a.tilesX * a.tilesY; ws_magic(a);
     const int wgs = a.ntiles < 256 ? a.ntiles : 256;
-    a.tiles_per_wg = wm_cdiv(a.ntiles, wgs); a.reverse = 0; a.bw_stats4 = nullptr; a.bw_ld = 0; a.bw_coef = nullptr; a.bw_gvec = nullptr; a.ry = nullptr; a.r_scale = nullptr; a.r_shift = nullptr; a.ay = nullptr; a.dy_out = nullptr;
+    a.ldy = 64; a.tiles_per_wg = wm_cdiv(a.ntiles, wgs); a.reverse = 0; a.bw_stats4 = nullptr; a.bw_ld = 0; a.bw_coef = nullptr; a.bw_gvec = nullptr; a.ry = nullptr; a.r_scale = nullptr; a.r_shift = nullptr; a.ay = nullptr; a.dy_out = nullptr;
     const dim3 grid((unsigned)wm_cdiv(a.ntiles, a.tiles_per_wg)), block(512);
     if (in_scale && stat) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, true, true, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
     else hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, false, true>), grid, block, 0, (hipStream_t)stream, a, stamps);
@@ -913,8 +916,9 @@ int WM_HSYM(wm_launch_conv3x3_ws)(const void* x, int ldx, int Cin, int CoutP, co
                            hipStream_t s, int reverse, const float* bw_stats4 = nullptr, int bw_ld = 0, const float* bw_coef = nullptr,
                            const float* bw_gvec = nullptr, const void* ry = nullptr, const float* r_scale = nullptr,
                            const float* r_shift = nullptr, const void* ay = nullptr, void* dy_out = nullptr, const void* addend = nullptr,
-                           int act = 0) {
+                           int act = 0, int ldy = 0) {
     WsArgs a;
+    a.ldy = ldy > 0 ? ldy : CoutP;
     a.dbg = g_ws_variant == 3 ? 8 : (g_ws_variant == 8 ? 64 : (g_ws_variant == 10 ? 128 : 0)); a.xcd_map = g_ws_variant != 2;
     a.x = (const hx_t*)x; a.ldx = ldx; a.wp = (const hx_t*)wp; a.bias = bias; a.nbias = nbias; a.in_scale = in_scale;
     a.in_shift = in_shift; a.y = (hx_t*)y; a.stat = stat; a.B = B; a.H = H; a.W = W;
@@ -933,7 +937,10 @@ int WM_HSYM(wm_launch_conv3x3_ws)(const void* x, int ldx, int Cin, int CoutP, co
     }
     if (act && ay) {   // backward of a conv + ELU layer: x = g, ay = the layer's output, dy_out = gz for the weight gradient, stat = the bias gradient's partial rows
         if (Cin != 64 || (CoutP != 64 && CoutP != 32) || ldx != 64 || in_scale || bw_stats4 || ry || !stat || addend) return WM_E_SHAPE;
-        if (CoutP == 32) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 32, false, false, true, false, 3, false>), grid, block, 0, s, a, nullptr);
+        if (CoutP == 32 && a.ldy == 16)   // towards a 16-channel (stride) tensor: the 32-channel consumers, channels 16..31 (zero filter rows) not stored
+            hipLaunchKernelGGL((conv3x3_ws_kernel<64, 32, false, false, true, false, 3, false, true, false, false, 0, true>), grid, block, 0, s, a, nullptr);
+        else if (a.ldy != CoutP) return WM_E_SHAPE;
+        else if (CoutP == 32) hipLaunchKernelGGL((conv3x3_ws_kernel<64, 32, false, false, true, false, 3, false>), grid, block, 0, s, a, nullptr);
         else hipLaunchKernelGGL((conv3x3_ws_kernel<64, 64, false, false, true, false, 3, false>), grid, block, 0, s, a, nullptr);
         return WM_OK;
     }

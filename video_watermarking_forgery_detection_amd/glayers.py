@@ -170,9 +170,10 @@ class _ConvEluFn(Function):
         Cout, Cin = weight.shape[0], weight.shape[1]
         need_gx, need_gw, need_gb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         g = g.contiguous()
-        if x.shape[3] in (64, 32) and ops.conv3x3_dgrad_elufused_supported(x.shape[3], g.dtype):
-            wt = _pack3(weight, 64, x.shape[3], g.dtype, True, ctx.plan_ok)
-            gx, gz, part = ops.conv3x3_dgrad_elufused(g, out, wt, want_gz=need_gw)
+        if x.shape[3] in (64, 32, 16) and ops.conv3x3_dgrad_elufused_supported(x.shape[3], g.dtype):
+            # (16-channel inputs: the filter packed to 32 rows -- the upper 16 zero -- for the 32-channel consumers, which store 16)
+            wt = _pack3(weight, 64, max(x.shape[3], 32), g.dtype, True, ctx.plan_ok)
+            gx, gz, part = ops.conv3x3_dgrad_elufused(g, out, wt, want_gz=need_gw, dx_stride=x.shape[3])
             gb = None
         else:   # (the 16-channel first layers: their input gradient runs on the general kernel)
             bacc = _flat_grad(ctx.bias_ptr, Cout) if need_gb else None

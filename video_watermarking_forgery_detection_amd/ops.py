@@ -714,13 +714,15 @@ def conv3x3_dgrad_elufused_supported(CinP, dtype):
     return bool(_lib.lib().wm_conv3x3_dgrad_elufused_supported(c_int(CinP), c_int(dt_id(dtype))))
 
 
-def conv3x3_dgrad_elufused(g, out, wpt, want_gz=True):
+def conv3x3_dgrad_elufused(g, out, wpt, want_gz=True, dx_stride=None):
     """backward of a conv + ELU layer, input-gradient half: gz = g * (out > 0 ? 1 : out + 1) formed while staging; returns
-    (dx [B,H,W,CinP], gz [B,H,W,64] or None, bias_partials f32 [nparts,64])"""
+    (dx [B,H,W,CinP], gz [B,H,W,64] or None, bias_partials f32 [nparts,64]).  dx_stride = 16: wpt packed to 32 rows (upper 16 zero),
+    dx [B,H,W,16]"""
     _need_cuda(g, out, wpt)
     B, H, W, C = g.shape
-    CinP = wpt.shape[1]
+    CinP = wpt.shape[1] if dx_stride is None else dx_stride
     assert C == 64 and out.shape == g.shape and out.dtype == g.dtype and g.is_contiguous() and out.is_contiguous() and wpt.shape[2] == 64
+    assert CinP == wpt.shape[1] or (CinP == 16 and wpt.shape[1] == 32)
     L = _lib.lib()
     dx = torch.empty(B, H, W, CinP, device=g.device, dtype=g.dtype)
     gz = torch.empty_like(g) if want_gz else None
