@@ -158,3 +158,39 @@ def test_tensorboard_scalar_files(tmp_path):
         bad = bytearray(raw_mine); bad[30] ^= 1
         open(str(tmp_path / "bad"), "wb").write(bytes(bad))
         read_events(str(tmp_path / "bad"))
+
+
+def test_deferred_logs_and_attack_cycle_host_logic():
+    """host-side pieces of the round-4 model surface (no GPU): DeferredLogs reads once, on the first look, and behaves as the reference's list of
+    (name, value) pairs (train.py:109 feeds it to Progbar.add); the attack cycle names the layer a step runs and keys its captured step by it"""
+    from video_watermarking_forgery_detection_amd.models.IRNrhi_model import DeferredLogs, _AttackCycle
+    calls = []
+
+    def read():
+        calls.append(1)
+        return [("loss", 1.5), ("lr", 1e-3)]
+    d = DeferredLogs(read)
+    assert calls == []
+    assert len(d) == 2 and calls == [1]
+    assert list(d) == [("loss", 1.5), ("lr", 1e-3)] and d[0] == ("loss", 1.5) and d == [("loss", 1.5), ("lr", 1e-3)] and dict(d)["lr"] == 1e-3
+    assert calls == [1] and "loss" in repr(d)
+    assert not DeferredLogs(lambda: [])          # an empty step (the first two calls of a run) is falsy, as the reference's []
+
+    class L:
+        def __init__(self, name):
+            self.name = name
+
+        def fwd(self, x):
+            return x, None
+
+        def bwd(self, c, g):
+            return g
+    cyc = _AttackCycle([L("a"), L("b"), L("c")])
+    keys = []
+    for k in range(7):
+        cyc.k = k
+        keys.append(cyc.capture_key())
+        assert cyc.name == "abc"[k % 3]
+        y, ctx = cyc.fwd("img")
+        assert y == "img" and ctx[0].name == cyc.name
+    assert keys[0] == keys[3] == keys[6] and len(set(keys)) == 3 and all(k[0] == "cycle" for k in keys)
