@@ -406,12 +406,13 @@ def main():
     kms = timer.elapsed_ms("conv3x3_fwd")
     dms = timer.elapsed_ms("conv3x3_bwd_fused")
     # ---- two more timed regions of the SAME invocation (secondary keys of the line; north_star asks for 256x256 AND 512x512, and the headline
-    # workload drops three dead weight-gradient GEMMs the reference executes): every rank runs them, bracketed exactly like the headline region
+    # workload drops three dead weight-gradient GEMMs the reference executes), bracketed exactly like the headline region; one GPU only
     extra = {}
     if sync is not None:
         sync.profile = False
     peak_tf = 2500.0 if dtype == torch.bfloat16 else 157.3
-    if not args.no_extra and not args.keep_dead_grads and S == 256:
+    run_extra = not args.no_extra and world == 1   # (N > 1: the scaling runs time the headline region only)
+    if run_extra and not args.keep_dead_grads and S == 256:
         # (1) the reference's exact .grad state: g_loss.backward() (hidden.py:101) also leaves its gradients in the discriminator's parameters
         h.keep_dead_discriminator_grads = True
         h.skip_zero_attack_gradient = False
@@ -423,7 +424,7 @@ def main():
             "workload": f"the same step with EVERY launch of the reference's autograd: the discriminator's dead weight gradients of the generator pass (the reference's .grad state, hidden.py:67,101) and the decoder's input gradient under Jpeg's zero-gradient rounding, {S}x{S}, batch {B}/GPU",
             "steps": args.extra_steps, "warmup": 5, "ms_per_step": 1e3 * dte / args.extra_steps, "value": world * B * args.extra_steps / dte, "unit": "frames/s",
             "step_gflop_per_frame": gf, "step_flops_frac_of_peak": gf * 1e9 * B * args.extra_steps / dte / (peak_tf * 1e12)}
-    if not args.no_extra and S == 256 and dtype == torch.bfloat16:
+    if run_extra and S == 256 and dtype == torch.bfloat16:
         # (2) BASELINE.json configs[3]'s per-GPU shard: 512x512, 8 frames per GPU
         S2, B2 = 512, 8
         torch.manual_seed(10)
