@@ -418,6 +418,65 @@ __global__ __launch_bounds__(256) void resample_bwd_x_kernel(const float* __rest
     }
 }
 
+// The x pass with the output row staged in the LDS (round 4): the block loads a row of gy once, coalesced -- the clamp's mask applied while it
+// does -- and every thread then reads its MAXC candidates from there: 1-2 global loads per thread and row instead of up to 2 MAXC predicated
+// ones behind a branch each (31.7 -> us for bicubic 0.7x at B=16, 3 x 256 x 256).  Same weights, same order of the sum: bit-identical.
+constexpr int RS_MAXOW = 1024;
+template <int KIND, int MAXC>
+__global__ __launch_bounds__(256) void resample_bwd_x_lds_kernel(const float* __restrict__ gy, const float* __restrict__ yc, float* __restrict__ tmp,
+                                                                 int N, int W, int w0, int ws, int OH, int OW) {
+    __shared__ float srow[2][RS_MAXOW];
+    const float sw = (float)ws / (float)OW;
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    const bool active = w < W;
+    const int iw = w - w0;
+    int xlo = 0, xhi = -1;
+    float wxs[MAXC];
+    const bool in_x = active && iw >= 0 && iw < ws;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) wxs[c] = 0.f;
+    if (in_x) {
+        axis_range<KIND>(iw, ws, OW, sw, xlo, xhi);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) wxs[c] = (xlo + c <= xhi) ? axis_weight<KIND>(xlo + c, iw, ws, sw) : 0.f;
+    }
+    const bool wide = xhi - xlo + 1 > MAXC;
+    int it = 0;
+    for (int n = blockIdx.z; n < N; n += gridDim.z) {
+        for (int oy = blockIdx.y; oy < OH; oy += gridDim.y, ++it) {
+            const float* gr = gy + ((size_t)n * OH + oy) * OW;
+            const float* yr = yc ? yc + ((size_t)n * OH + oy) * OW : nullptr;
+            float* sr = srow[it & 1];     // two buffers: the barrier of row k + 1 separates the reads of row k from the writes of row k + 2
+            for (int i = threadIdx.x; i < OW; i += 256) {
+                float gg = gr[i];
+                if (yr) {  // clamp(0,1) passed the gradient only strictly inside the interval
+                    const float v = yr[i];
+                    if (!(v > 0.f && v < 1.f)) gg = 0.f;
+                }
+                sr[i] = gg;
+            }
+            __syncthreads();
+            if (!active) continue;
+            float row = 0.f;
+            if (in_x) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    const int ox = min(xlo + c, OW - 1);
+                    const float gg = wxs[c] != 0.f ? sr[ox] : 0.f;   // (a term the gather form skips contributes exactly nothing here either)
+                    row += wxs[c] * gg;
+                }
+                if (wide)
+                    for (int ox = xlo + MAXC; ox <= xhi; ++ox) {
+                        const float wx = axis_weight<KIND>(ox, iw, ws, sw);
+                        if (wx == 0.f) continue;
+                        row += wx * sr[ox];
+                    }
+            }
+            tmp[((size_t)n * OH + oy) * W + w] = row;
+        }
+    }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void resample_bwd_y_kernel(const float* __restrict__ tmp, float* __restrict__ gx, int N, int H, int W, int h0,
                                                              int hs, int OH) {
@@ -507,7 +566,11 @@ extern "C" int wm_resample_bwd_sep(const float* gy, const float* y_clamped, floa
     hipStream_t s = (hipStream_t)stream;
     // candidate columns of one input pixel: axis_range's [lo, hi] spans at most 4 / scale + 5 outputs (scale = ws / OW)
     const int span = (int)(4.0 * (double)OW / (double)ws) + 5;
-#define WM_RS_X(KIND_, MAXC_) hipLaunchKernelGGL((resample_bwd_x_kernel<KIND_, MAXC_>), gx_grid, block, 0, s, gy, y_clamped, tmp, N, W, w0, ws, OH, OW)
+#define WM_RS_X(KIND_, MAXC_)                                                                                                                   \
+    do {                                                                                                                                       \
+        if (OW <= RS_MAXOW) hipLaunchKernelGGL((resample_bwd_x_lds_kernel<KIND_, MAXC_>), gx_grid, block, 0, s, gy, y_clamped, tmp, N, W, w0, ws, OH, OW); \
+        else hipLaunchKernelGGL((resample_bwd_x_kernel<KIND_, MAXC_>), gx_grid, block, 0, s, gy, y_clamped, tmp, N, W, w0, ws, OH, OW);           \
+    } while (0)
     if (kind == WM_BILINEAR) {
         if (span <= 8) WM_RS_X(WM_BILINEAR, 8); else if (span <= 12) WM_RS_X(WM_BILINEAR, 12); else WM_RS_X(WM_BILINEAR, 24);
         hipLaunchKernelGGL(resample_bwd_y_kernel<WM_BILINEAR>, gy_grid, block, 0, s, (const float*)tmp, gx, N, H, W, h0, hs, OH);
