@@ -292,3 +292,89 @@ def test_failed_capture_falls_back_to_the_eager_step_with_a_warning():
     a, b = _state(eager), _state(graph)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("two", [False, True])
+def test_replayed_steps_without_a_host_read_in_between(two):
+    """A loop that does not look at the losses every step (bench.py) lets the host run ahead of the GPU: step k + 1's inputs and Adam constants
+    are staged while step k's replay is still queued.  Twelve such steps must leave the model exactly where the eagerly enqueued, per-step
+    synchronised run leaves it (round 4: a reused pinned staging buffer handed step k the constants of step k + 1)."""
+    from video_watermarking_forgery_detection_amd import noise_layers as NL
+    eager, graph = _make(128, NL.Identity(), torch.bfloat16), _make(128, NL.Identity(), torch.bfloat16).enable_graph()
+    graph.two_streams = two
+    batches = [(detgen.uniform((16, 3, 128, 128), 900 + i).cuda(), (detgen.uniform((16, 30), 950 + i) > 0.5).float().cuda()) for i in range(12)]
+    for x, m in batches:
+        le, _ = eager.train_on_batch([x, m])
+        dict(le)                                   # the eager run reads every step
+        torch.cuda.synchronize()
+    kept = [graph.train_on_batch([x, m])[0] for x, m in batches]     # nothing is read until all twelve are enqueued
+    torch.cuda.synchronize()
+    assert dict(kept[-1]) == dict(le)
+    a, b = _state(eager), _state(graph)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_jpeg_kernels_beside_the_sixteen_channel_backward_kernels():
+    """The two-chain schedule runs the attack (chain B) beside the discriminator's passes (chain A), whose image-fed first layer uses
+    bwd_ws16 / the 16-channel weight gradient: the only kernels with transposing LDS reads that were small enough to share a CU with the
+    JPEG kernels -- whose results came out wrong (a quarter-wave of one register: two pixels of an 8x8 block) in 22-30 of 30 launches
+    while such a workgroup was resident beside them (round 4; cause not understood, nothing written out of bounds).  The two kernels now
+    request LDS up to 137,472 B (csrc/wgrad_ws.hip WM_LDS_PAD16), so that a JPEG workgroup no longer fits on their CU.  Fixed operands, the
+    solo result is the reference; forward and backward, all three quantisation modes + DiffJPEG."""
+    from video_watermarking_forgery_detection_amd import ops
+    from video_watermarking_forgery_detection_amd import noise_layers as NL
+    B, H, W, C, dt = 16, 256, 256, 64, torch.bfloat16
+    x = detgen.uniform((B, 3, H, W), 1).cuda()
+    gy = detgen.normal((B, 3, H, W), 2).cuda()
+    g = detgen.normal((B, H, W, C), 3).cuda().to(dt); y = detgen.normal((B, H, W, C), 4).cuda().to(dt)
+    stats = detgen.uniform((4, C), 5).cuda() + 0.5
+    coef = detgen.uniform((3, C), 6).cuda() * 0.01; coef[0] += 1.0
+    x16 = detgen.normal((B, H, W, 16), 7).cuda().to(dt); x16[..., 3:] = 0
+    w16 = detgen.normal((C, 3, 3, 3), 8, std=0.05).cuda(); dw16 = torch.zeros(C, 3, 3, 3, device="cuda")
+    wpt16 = ops.pack_w3x3(w16, C, 16, dt, transpose=True)
+    dwf = torch.zeros(C, 16, 3, 3, device="cuda")
+
+    def neighbours():
+        ops.conv3x3_bwd_fused16(g, y, stats, coef, wpt16, x16, dw16, False)
+        ops.conv3x3_wgrad(x16, 16, None, None, g, dwf, False)
+        ops.conv3x3_bwd_fused16(g, y, stats, coef, wpt16, x16, dw16, False)
+
+    probes = {}
+    for name, L in (("Jpeg", NL.Jpeg(50)), ("JpegSS", NL.JpegSS(50)), ("JpegMask", NL.JpegMask(50))):
+        probes[name + " fwd"] = (lambda L=L: ops.jpeg_fwd(x, L._mode, L._tables, 0))
+        probes[name + " bwd"] = (lambda L=L: ops.jpeg_bwd(x, gy, L._mode, L._tables, 0))
+    probes["DiffJPEG fwd"] = lambda: ops.diffjpeg_fwd(x, 1, 1.0)
+    probes["DiffJPEG bwd"] = lambda: ops.diffjpeg_bwd(x, gy, 1, 1.0)
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    for name, fn in probes.items():
+        solo = fn()
+        torch.cuda.synchronize()
+        for it in range(8):
+            sA.wait_stream(torch.cuda.current_stream()); sB.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(sA):
+                neighbours()
+            with torch.cuda.stream(sB):
+                out = fn()
+            torch.cuda.synchronize()
+            assert torch.equal(out, solo), (name, it, int((out != solo).sum()))
+
+
+def test_two_chain_training_under_a_differentiable_jpeg_is_the_one_stream_run():
+    """the schedule-level form of the test above (tools/train_sanity_modes.py found it): JpegSS at the benchmark's size, six steps, the
+    two-chain order three times over -- every run must end exactly where the one-stream run ends (round 4: one in two did not)."""
+    from video_watermarking_forgery_detection_amd import noise_layers as NL
+
+    def run(two):
+        h = _make(256, NL.JpegSS(50), torch.bfloat16)
+        h.two_streams = two
+        for i in range(6):
+            h.train_on_batch([detgen.uniform((16, 3, 256, 256), 40 + i).cuda(), (detgen.uniform((16, 30), 60 + i) > 0.5).float().cuda()])
+            torch.cuda.synchronize()
+        return _state(h)
+
+    ref = run(False)
+    for r in range(3):
+        got = run(True)
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), (r, k)

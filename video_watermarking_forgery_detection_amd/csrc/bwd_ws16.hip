@@ -290,6 +290,9 @@ void WM_HSYM(wm_launch_bwd_ws16)(const void* g, const void* y, const float* stat
     a.x = (const hx_t*)x; a.dx = (hx_t*)dx; a.ws = ws;
     a.B = B; a.H = H; a.W = W; a.tilesX = W / TW; a.tilesY = H / TH; a.ntiles = B * a.tilesX * a.tilesY;
     a.reverse = wm_sweep_dir(reverse);
-    if (premasked) hipLaunchKernelGGL((bwd_ws16_kernel<true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((bwd_ws16_kernel<false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+    // (dynamic LDS for the allocation's size alone: see wgrad_ws.hip WM_LDS_PAD16 -- a workgroup of the JPEG kernels must not fit beside this
+    //  kernel on a CU.  It costs this kernel its second workgroup per CU.)
+    constexpr int PAD = 137472 - (SW_BYTES + 2 * BUF_BYTES + (C * 8 + 32) * 4);
+    if (premasked) hipLaunchKernelGGL((bwd_ws16_kernel<true>), dim3((unsigned)nwg), dim3(256), PAD, s, a);
+    else hipLaunchKernelGGL((bwd_ws16_kernel<false>), dim3((unsigned)nwg), dim3(256), PAD, s, a);
 }

@@ -285,8 +285,12 @@ class _StepGraph:
         if self.h.amp is not None:
             return   # under the scaler the step counts live on the device already (wm_adam_step_amp)
         vals = [v for o in opts for v in o.hyper(o.step_count + 1)]
-        self.hyper_host.copy_(torch.tensor(vals, dtype=torch.float32))
-        self.hyper.copy_(self.hyper_host, non_blocking=True)
+        # a FRESH pinned tensor per replay: the copy below is asynchronous, and a host that runs ahead of the GPU (a loop that does not read
+        # the losses every step: bench.py) would overwrite a reused staging buffer with the NEXT step's constants before this step's copy
+        # has run -- found in round 4 by tools/train_sanity_modes.py (the per-step tests synchronise and never saw it).  The caching host
+        # allocator hands a pinned block out again only after the copies that read it have completed.
+        host = torch.tensor(vals, dtype=torch.float32).pin_memory()
+        self.hyper.copy_(host, non_blocking=True)
 
     def step(self, images, messages):
         h = self.h
@@ -297,7 +301,6 @@ class _StepGraph:
             dev = images.device
             self.img, self.msg = torch.empty_like(images), torch.empty_like(messages)
             self.hyper = torch.zeros(4, device=dev, dtype=torch.float32)
-            self.hyper_host = torch.empty(4, dtype=torch.float32, pin_memory=True)
             self.img.copy_(images); self.msg.copy_(messages)
             self._seen = {"img": (images, images._version), "msg": (messages, messages._version)}
             opts = (h.optimizer_discrim, h.optimizer_enc_dec)
