@@ -632,7 +632,7 @@ extern "C" int wm_conv3x3_bwd_fused16_supported(int B, int H, int W, int dtype) 
 }
 extern "C" int wm_conv3x3_bwd_fused16_nwg(int B, int H, int W) {
     const long n = (long)B * (H / 8) * (W / 16);
-    return (int)(n < 2 * WM_MAX_WGS ? n : 2 * WM_MAX_WGS);   // two workgroups per CU
+    return (int)(n < WM_MAX_WGS ? n : WM_MAX_WGS);   // one workgroup per CU (round 4: the kernel's LDS request no longer lets two share one, bwd_ws16.hip)
 }
 extern "C" int wm_conv3x3_bwd_fused16(const void* g, const void* y, const float* stats4, const float* coef, const void* wpt, const void* x,
                                       void* dx, float* ws, float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, int dtype,
