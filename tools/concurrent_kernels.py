@@ -43,10 +43,19 @@ sc = torch.rand(C, device=dev) + 0.5; sh = torch.randn(C, device=dev) * 0.3
 xr = torch.randn(B, H, W, C, device=dev).to(dt)
 w64 = torch.randn(C, C, 3, 3, device=dev) * 0.05
 wp64 = ops.pack_w3x3(w64, C, C, dt)
+gy3 = torch.randn(B, 3, H, W, device=dev)
+g16 = torch.randn(B, H, W, 16, device=dev).to(dt)
+flat = torch.randn(1 << 20, device=dev); fg = torch.randn(1 << 20, device=dev)
+hw = torch.randn(3, 64, device=dev) * 0.1; hb = torch.zeros(3, device=dev)
 victims = {
     "jpeg_fwd (mask)": lambda: ops.jpeg_fwd(x, L._mode, L._tables, 0),
-    "jpeg_fwd (SS)": lambda: ops.jpeg_fwd(x, NL.JpegSS(50)._mode, NL.JpegSS(50)._tables, 0),
+    "jpeg_bwd (SS)": lambda: ops.jpeg_bwd(x, gy3, NL.JpegSS(50)._mode, NL.JpegSS(50)._tables, 0),
     "diffjpeg_fwd": lambda: ops.diffjpeg_fwd(x, 1, 1.0),
+    "resample_bwd bicubic (LDS x pass)": lambda: ops.resample_bwd(gy3[:, :, :179, :179].contiguous(), None, (256, 256), (0, 256, 0, 256), ops.BICUBIC),
+    "median_bwd4": lambda: ops.median_bwd(gy3, torch.zeros(B, 3, H, W, dtype=torch.int8, device=dev), 3),
+    "image_grad_mse": lambda: ops.image_grad_mse(g16, x, img, 1e-3)[0],
+    "conv1x1 head fwd": lambda: (lambda r: r if isinstance(r, torch.Tensor) else r[0])(ops.conv1x1_head_fwd(xr, sc, sh, hw, hb)),
+    "first-layer fwd <16,64> + stats": lambda: torch.cat([t.float().reshape(-1) for t in ops.conv3x3_fwd(x16, ops.pack_w3x3(w16, 64, 16, dt), None, None, None, want_stats=True)]),
 }
 for name, fn in victims.items():
     try:
@@ -57,7 +66,7 @@ for name, fn in victims.items():
     for it in range(30):
         sA.wait_stream(torch.cuda.current_stream()); sB.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(sA):
-            heavy("bwd_ws16"); heavy("bwd_ws16"); heavy("bwd_ws16")
+            heavy("bwd_ws16"); heavy("wgrad_ws16<16>"); heavy("bwd_ws16")
         with torch.cuda.stream(sB):
             out = fn()
         torch.cuda.synchronize()
