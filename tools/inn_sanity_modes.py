@@ -1,0 +1,31 @@
+import hashlib, os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+from video_watermarking_forgery_detection_amd import glayers as G, ops
+from video_watermarking_forgery_detection_amd.models.invertible_net import Inveritible_Decolorization_PAMI, ResBlock
+def run(graph, fuse):
+    G.FUSE_ELU = fuse
+    torch.manual_seed(0)
+    net = Inveritible_Decolorization_PAMI(dims_in=[[4, 128, 128]], block_num=[2, 2, 2], subnet_constructor=ResBlock, dtype=torch.bfloat16).cuda()
+    with torch.no_grad():
+        for n_, p in net.named_parameters():
+            if "conv5" in n_ and p.dim() == 4: p.normal_(0, 0.01)     # (the reference zero-initialises conv5: nothing would flow)
+    opt = G.FlatAdamW(net, lr=1e-4)
+    G.set_pack_plan(ops.PackPlan())
+    x = torch.rand(4, 4, 128, 128, device="cuda")
+    def fb():
+        y = net(x); back, mid = net(y, rev=True)
+        loss = ((y - x) ** 2).mean() + ((back - x) ** 2).mean()
+        opt.zero_grad(); loss.backward(); return loss
+    fb(); opt.step()
+    g = G.CapturedStep(fb) if graph else None
+    for i in range(10):
+        if g is not None: g.replay()
+        else: fb()
+        opt.step()
+    torch.cuda.synchronize()
+    h = hashlib.sha256()
+    for p in net.parameters(): h.update(p.detach().float().cpu().numpy().tobytes())
+    G.set_pack_plan(None); G.FUSE_ELU = True
+    return h.hexdigest()[:12]
+print("eager fused", run(False, True)); print("graph fused", run(True, True)); print("graph fused again", run(True, True)); print("eager unfused", run(False, False))
