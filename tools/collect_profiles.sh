@@ -56,6 +56,7 @@ cd $ROOT
 if [ -x tools/micro/mfma_rate ]; then tools/micro/mfma_rate > $OUT/mfma_coissue_micro.txt 2>&1; fi
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lit_stats -o l -- python3 $ROOT/tools/bench_literal.py 4 bf16 6 > $OUT/lit_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/inn_stats -o i -- python3 $ROOT/tools/bench_inn.py 8 bf16 4 > $OUT/inn_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_stats -o c -- python3 $ROOT/tools/bench_c5.py train_hidden_c5_fp16.yml f16 44 > $OUT/c5_stats.log 2>&1
 bash $ROOT/tools/pmc_bwd.sh > $OUT/bwd_sq_counters.txt 2>&1
 bash $ROOT/tools/pmc_fwd.sh > $OUT/fwd_sq_counters.txt 2>&1

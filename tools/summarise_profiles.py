@@ -157,6 +157,7 @@ if os.path.exists(_sq) and os.path.exists(_sq1):
         g.write("\n" + open(_sq1).read())
 for sub, base, steps, cmd in (("lit_stats", f"{tag}_literal_step_kernel_stats", 8.0, "python3 tools/bench_literal.py 4 bf16 6   (8 steps: the reference's literal IRNrhi step, 24 frames 256x256, bf16)"),
                               ("s512_stats", f"{tag}_bench_512_b8_kernel_stats", 13.0, "python3 bench.py --no-cpu-baseline --no-extra --one-stream --no-graph --size 512 --batch 8 --steps 10 --warmup 3   (13 steps of 8 frames 512x512, one stream)"),
+                              ("inn_stats", f"{tag}_inn_step_kernel_stats", 7.0, "python3 tools/bench_inn.py 8 bf16 4   (7 steps enqueued: the invertible embedder, 8 frames 4x256x256, embed + extract + backward + AdamW, bf16)"),
                               ("c5_stats", f"{tag}_c5_fp16_kernel_stats", 42.0, "python3 tools/bench_c5.py train_hidden_c5_fp16.yml f16 44   (42 steps with work, 16 frames 256x256 each, UNet head, f16 + device GradScaler)")):
     try:
         stats_summary(sub, base, steps, cmd)
