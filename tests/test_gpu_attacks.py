@@ -128,6 +128,30 @@ def test_median_vs_definition(k):
 
 
 @pytest.mark.parametrize("k", [3, 5])
+def test_median_forward_four_pixel_form_is_the_one_pixel_form(k):
+    """wm_median_fwd takes the four-pixels-per-thread kernel for 16-byte aligned planes with W % 4 == 0 and the one-pixel kernel otherwise:
+    the value AND the tap index plane byte for byte -- on continuous data (one tap equals the median: the short way to the index), on
+    data quantised to 5 / 2 levels and on saturated images (ties everywhere: the rank form), at the zero-padded border, one block per
+    row and several; against the oracle's restatement as well."""
+    from video_watermarking_forgery_detection_amd import ops
+    for shape, seed in (((16, 3, 256, 256), 5), ((2, 3, 40, 1032), 6), ((1, 1, 8, 4), 7), ((3, 2, 5, 12), 8)):
+        u = detgen.uniform(shape, seed)
+        for name, xc in (("continuous", u), ("five levels", torch.round(u * 4) / 4), ("two levels", torch.round(u)),
+                         ("saturated", (u * 3 - 1).clamp(0, 1)), ("constant", torch.full(shape, 0.25))):
+            n = xc.numel()
+            buf = torch.empty(n + 1, device="cuda")
+            buf[1:].copy_(xc.cuda().reshape(-1))
+            x_unaligned = buf[1:].view(shape)              # 4 bytes off a 16-byte boundary: the one-pixel kernel
+            x = x_unaligned.clone()                        # the four-pixel kernel
+            assert x_unaligned.data_ptr() % 16 != 0 and x.data_ptr() % 16 == 0
+            (ya, ia), (yb, ib) = ops.median_fwd(x, k), ops.median_fwd(x_unaligned, k)
+            assert torch.equal(ya, yb), (shape, name)
+            assert torch.equal(ia, ib), (shape, name, int((ia != ib).sum()))
+            if n <= 2 * 3 * 40 * 1032:
+                assert torch.equal(ya.cpu(), attacks_ref.median_blur(xc, k)), (shape, name)
+
+
+@pytest.mark.parametrize("k", [3, 5])
 def test_median_backward_four_pixel_form_is_the_one_pixel_form(k):
     """wm_median_bwd takes the four-pixels-per-thread kernel for 16-byte aligned planes with W % 4 == 0 and the one-pixel kernel otherwise: the
     same taps in the same order -- bit-identical, at the benchmark's size and at a size with several blocks per row, ties at the zero-padded border included"""

@@ -99,6 +99,80 @@ __global__ __launch_bounds__(256) void median_fwd_kernel(const float* __restrict
     }
 }
 
+// The same result, four adjacent output pixels per thread (W % 4 == 0, 16-byte aligned planes): a window row is one float4 and the R columns
+// either side of it (bounds decided per row, not per tap: the form above spends 25 exec-masked loads on one pixel), the four windows
+// are views of those K x (4 + 2R) registers, and the tap index takes the short way when exactly one tap equals the median (then no
+// value below it is missing from the count: lt = K2/2, the wanted tap is that one) -- ties (zero padding, saturated images) fall back
+// to the rank form above, so the index plane is the same byte for byte.
+template <int K>
+__global__ __launch_bounds__(256) void median_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, int8_t* __restrict__ idx,
+                                                          int N, int H, int W) {
+    constexpr int K2 = K * K, R = K / 2, RW = 4 + 2 * R;
+    const int W4 = W >> 2;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= H * W4) return;
+    const int h = item / W4, w4 = (item - h * W4) * 4;
+    const bool lo = w4 > 0, hi = w4 + 4 < W;
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        const float* p = x + (size_t)n * H * W;
+        float r[K][RW];
+#pragma unroll
+        for (int dh = 0; dh < K; ++dh) {
+            const int hh = h + dh - R;
+#pragma unroll
+            for (int q = 0; q < RW; ++q) r[dh][q] = 0.f;
+            if (hh >= 0 && hh < H) {
+                const float* q = p + (size_t)hh * W + w4;
+                const float4 c = *reinterpret_cast<const float4*>(q);
+                r[dh][R] = c.x; r[dh][R + 1] = c.y; r[dh][R + 2] = c.z; r[dh][R + 3] = c.w;
+                if constexpr (R == 2) {
+                    if (lo) { const float2 l = *reinterpret_cast<const float2*>(q - 2); r[dh][0] = l.x; r[dh][1] = l.y; }
+                    if (hi) { const float2 g = *reinterpret_cast<const float2*>(q + 4); r[dh][6] = g.x; r[dh][7] = g.y; }
+                } else {
+                    if (lo) r[dh][0] = q[-1];
+                    if (hi) r[dh][5] = q[4];
+                }
+            }
+        }
+        float med[4];
+        unsigned selw = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s[K2];
+#pragma unroll
+            for (int t = 0; t < K2; ++t) s[t] = r[t / K][j + t % K];
+            med[j] = median_select<K2>(s);
+            if (idx) {
+                int cnt = 0, sel = 0;
+#pragma unroll
+                for (int t = K2 - 1; t >= 0; --t) {
+                    const bool eq = r[t / K][j + t % K] == med[j];
+                    sel = eq ? t : sel;
+                    cnt += eq ? 1 : 0;
+                }
+                if (cnt != 1) {
+                    int lt = 0;
+#pragma unroll
+                    for (int t = 0; t < K2; ++t) lt += r[t / K][j + t % K] < med[j] ? 1 : 0;
+                    const int want = K2 / 2 - lt;
+                    int seen = 0;
+                    sel = 0;
+#pragma unroll
+                    for (int t = 0; t < K2; ++t) {
+                        const bool eq = r[t / K][j + t % K] == med[j];
+                        if (eq && seen == want) sel = t;
+                        seen += eq ? 1 : 0;
+                    }
+                }
+                selw |= (unsigned)sel << (8 * j);
+            }
+        }
+        const size_t o = (size_t)n * H * W + (size_t)h * W + w4;
+        *reinterpret_cast<float4*>(y + o) = float4{med[0], med[1], med[2], med[3]};
+        if (idx) *reinterpret_cast<unsigned*>(idx + o) = selw;
+    }
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void median_bwd_kernel(const float* __restrict__ gy, const int8_t* __restrict__ idx,
                                                          float* __restrict__ gx, int N, int H, int W) {
@@ -338,6 +412,13 @@ extern "C" int wm_stencil3_fwd(const float* x, float* y, int N, int H, int W, co
 extern "C" int wm_median_fwd(const float* x, float* y, int8_t* idx, int N, int H, int W, int k, void* stream) {
     WM_REQUIRE(x && y && N > 0 && H > 0 && W > 0, WM_E_BADARG, "wm_median_fwd: bad arguments");
     WM_REQUIRE(k == 3 || k == 5, WM_E_SHAPE, "wm_median_fwd: kernel size must be 3 or 5 (got %d)", k);
+    if (W % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && (((uintptr_t)idx) & 3) == 0 && (long long)H * (W / 4) < (1LL << 31)) {
+        const dim3 grid4((unsigned)(((long long)H * (W / 4) + 255) / 256), (unsigned)(N < 65535 ? N : 65535)), block4(256);
+        if (k == 3) hipLaunchKernelGGL(median_fwd4_kernel<3>, grid4, block4, 0, (hipStream_t)stream, x, y, idx, N, H, W);
+        else hipLaunchKernelGGL(median_fwd4_kernel<5>, grid4, block4, 0, (hipStream_t)stream, x, y, idx, N, H, W);
+        WM_LAUNCH_CHECK("wm_median_fwd");
+        return WM_OK;
+    }
     const dim3 grid((unsigned)((W + 255) / 256), (unsigned)(H < 65535 ? H : 65535), (unsigned)(N < 65535 ? N : 65535)), block(256);
     if (k == 3) hipLaunchKernelGGL(median_fwd_kernel<3>, grid, block, 0, (hipStream_t)stream, x, y, idx, N, H, W);
     else hipLaunchKernelGGL(median_fwd_kernel<5>, grid, block, 0, (hipStream_t)stream, x, y, idx, N, H, W);
