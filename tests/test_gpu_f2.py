@@ -201,6 +201,57 @@ def test_captured_step_replays_the_eager_step():
     assert torch.equal(y_e, y2) and torch.equal(opt.grad, g2) and torch.equal(loss_e.detach(), l2.detach())
 
 
+@pytest.mark.parametrize("subnet", ["res", "dense"])
+def test_coupling_subnets_on_two_streams_are_the_one_stream_step(subnet):
+    """invertible_net.PARALLEL_SUBNETS: the s / t subnets of every coupling on two streams (forward forked by _pair, backward by autograd's
+    per-node streams) -- outputs, the reverse pass and the whole flat gradient bit for bit the one-stream step's, enqueued and replayed from
+    a hipGraph, over several steps with the optimiser in between (a block re-issued under a reader on the other stream would show here)."""
+    from video_watermarking_forgery_detection_amd import glayers as G
+    from video_watermarking_forgery_detection_amd.models import invertible_net as inn
+    PAMI, ResBlock, DenseBlock = _mods()
+
+    def run(par, graph):
+        inn.PARALLEL_SUBNETS = par
+        try:
+            torch.manual_seed(1)
+            net = detgen.fill_f2(PAMI(dims_in=[[4, 64, 64]], block_num=[2, 1, 1], subnet_constructor=ResBlock if subnet == "res" else DenseBlock,
+                                      dtype=torch.bfloat16)).to(DEV)
+            opt = G.FlatAdamW(net, lr=1e-3)
+            xs = torch.zeros(3, 4, 64, 64, device=DEV)
+            outs = {}
+
+            def fwd_bwd():
+                y = net(xs)
+                back, mid = net(y, rev=True)
+                loss = ((y - xs) ** 2).mean() + (back ** 2).mean() + (mid ** 2).mean()
+                opt.zero_grad()
+                loss.backward()
+                return y, back, loss
+
+            xs.copy_(detgen.uniform((3, 4, 64, 64), 40).to(DEV))
+            step = G.CapturedStep(fwd_bwd) if graph else None
+            got = []
+            for i in range(4):
+                xs.copy_(detgen.uniform((3, 4, 64, 64), 41 + i).to(DEV))
+                y, back, loss = step.replay() if graph else fwd_bwd()
+                torch.cuda.synchronize()
+                got.append((y.detach().clone(), back.detach().clone(), loss.detach().clone(), opt.grad.clone()))
+                opt.step()
+            torch.cuda.synchronize()
+            return got, [p.detach().clone() for p in net.parameters()]
+        finally:
+            inn.PARALLEL_SUBNETS = True
+
+    base, pbase = run(False, False)
+    assert float(base[0][3].abs().max()) > 0
+    for par, graph in ((True, False), (True, True), (False, True)):
+        got, params = run(par, graph)
+        for i, (a, b) in enumerate(zip(base, got)):
+            for name, u, v in zip(("y", "back", "loss", "grad"), a, b):
+                assert torch.equal(u, v), (par, graph, i, name, float((u.float() - v.float()).abs().max()))
+        assert all(torch.equal(u, v) for u, v in zip(pbase, params)), (par, graph)
+
+
 def test_captured_step_refuses_an_fn_that_leaks_its_autograd_graph():
     """the fn shape that ended round 2's capture in a segmentation fault inside hipStreamEndCapture (gpurun_out/inn3.log): a first eager
     call on the default stream, an fn that rebinds outer names to tensors requiring grad (so every call's autograd graph lives until the

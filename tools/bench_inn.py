@@ -14,6 +14,8 @@ dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[sys.ar
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 SIZE = int(os.environ.get("INN_SIZE", "256"))
 BLOCKS = [int(v) for v in os.environ.get("INN_BLOCKS", "8,8,8").split(",")]
+from video_watermarking_forgery_detection_amd.models import invertible_net as _inn
+_inn.PARALLEL_SUBNETS = os.environ.get("INN_PAR", "1") == "1"     # a coupling's s / t subnets side by side on two streams
 net = Inveritible_Decolorization_PAMI(dims_in=[[4, SIZE, SIZE]], block_num=BLOCKS, subnet_constructor=ResBlock, dtype=dt).cuda()   # the reference's init: every subnet ends in a zero conv
 opt = G.FlatAdamW(net, lr=1e-5)
 if os.environ.get("INN_PLAN", "1") == "1":
@@ -52,5 +54,5 @@ except (OSError, KeyError, ValueError):
     gf = None
 _med = ms[len(ms) // 2]
 _peak = 157.3 if dt == torch.float32 else 2500.0
-print(json.dumps({"step_gflop": gf, "tflops": gf / _med if gf else None, "flops_frac_of_mfma_peak": gf / _med / _peak if gf else None, "graph": GRAPH, "frames_per_step": bs, "dtype": str(dt).split(".")[1], "ms_per_step_median": ms[len(ms) // 2], "ms_per_step_min": ms[0],
+print(json.dumps({"step_gflop": gf, "tflops": gf / _med if gf else None, "flops_frac_of_mfma_peak": gf / _med / _peak if gf else None, "graph": GRAPH, "parallel_subnets": _inn.PARALLEL_SUBNETS, "frames_per_step": bs, "dtype": str(dt).split(".")[1], "ms_per_step_median": ms[len(ms) // 2], "ms_per_step_min": ms[0],
                   "frames_per_s": bs / ms[len(ms) // 2] * 1e3, "params": sum(p.numel() for p in net.parameters()), "loss": float(loss.detach())}))

@@ -3,8 +3,10 @@ sys.path.insert(0, os.getcwd())
 import torch
 from video_watermarking_forgery_detection_amd import glayers as G, ops
 from video_watermarking_forgery_detection_amd.models.invertible_net import Inveritible_Decolorization_PAMI, ResBlock
-def run(graph, fuse):
+from video_watermarking_forgery_detection_amd.models import invertible_net as _inn
+def run(graph, fuse, par=False):
     G.FUSE_ELU = fuse
+    _inn.PARALLEL_SUBNETS = par
     torch.manual_seed(0)
     net = Inveritible_Decolorization_PAMI(dims_in=[[4, 128, 128]], block_num=[2, 2, 2], subnet_constructor=ResBlock, dtype=torch.bfloat16).cuda()
     with torch.no_grad():
@@ -26,6 +28,7 @@ def run(graph, fuse):
     torch.cuda.synchronize()
     h = hashlib.sha256()
     for p in net.parameters(): h.update(p.detach().float().cpu().numpy().tobytes())
-    G.set_pack_plan(None); G.FUSE_ELU = True
+    G.set_pack_plan(None); G.FUSE_ELU = True; _inn.PARALLEL_SUBNETS = False
     return h.hexdigest()[:12]
 print("eager fused", run(False, True)); print("graph fused", run(True, True)); print("graph fused again", run(True, True)); print("eager unfused", run(False, False))
+print("eager fused, s / t subnets on two streams", run(False, True, True)); print("graph fused, two streams", run(True, True, True)); print("graph fused, two streams, again", run(True, True, True))

@@ -116,6 +116,36 @@ class DenseBlock(nn.Module):
         return self.conv5(cat)
 
 
+PARALLEL_SUBNETS = True      # the s / t subnets of a coupling side by side on two streams (see _pair); False = one stream, the same results bit for bit
+_SIDE_STREAMS = {}
+
+
+def _pair(f, g, x):
+    """(f(x), g(x)).  With PARALLEL_SUBNETS on a GPU, f runs on a side stream forked from the caller's and joined before the pair is
+    used: the two subnets of a coupling share their input and nothing else, and at the embedder's sizes (8k-131k pixels per layer) a
+    launch fills 32-256 workgroups for ~10 us of fixed cost -- two of them side by side cost little more than one.  Autograd runs every
+    backward node on its forward's stream and synchronises the edges between streams itself, so the backward forks the same way.  Every
+    tensor crossing streams is recorded on its reader's stream (the allocator re-issues a block only after that stream has passed);
+    the kernels are the same launches and autograd sums every gradient in the same order: the result is the one-stream one bit for bit
+    (tests/test_gpu_f2.py; tools/inn_sanity_modes.py over 10 optimiser steps, eager and replayed).  The FIRST subnet is the one that goes
+    to the side stream: a hipGraph replay runs the two branches side by side only when the forked branch is enqueued first (measured:
+    104.7 -> 83.8 ms per replayed step that way, 108 ms with the second subnet forked instead -- profiles/r04_experiments.txt)."""
+    if not (PARALLEL_SUBNETS and x.is_cuda):
+        return f(x), g(x)
+    main = torch.cuda.current_stream()
+    side = _SIDE_STREAMS.get(x.device.index)
+    if side is None:
+        side = _SIDE_STREAMS[x.device.index] = torch.cuda.Stream(device=x.device)
+    side.wait_stream(main)
+    x.record_stream(side)
+    with torch.cuda.stream(side):
+        a = f(x)                  # (f's nodes before g's, as in the sequential order: autograd then sums the gradients of x in the same order)
+    b = g(x)
+    main.wait_stream(side)
+    a.record_stream(main)
+    return a, b
+
+
 class RNVPCouplingBlock(nn.Module):
     """:122-175: y1 = e(s2(x2)) * x1 + t2(x2), y2 = e(s1(y1)) * x2 + t1(y1), e(s) = exp(clamp * (2 sigmoid(s) - 1)) + 1e-4; rev undoes it"""
 
@@ -136,11 +166,11 @@ class RNVPCouplingBlock(nn.Module):
         n1, n2 = self.split_len1, self.split_len2
         x1, x2 = G.chan_slice(x, 0, n1), G.chan_slice(x, n1, n2)
         if not rev:
-            y1 = G.coupling(x1, self.s2(x2), self.t2(x2), self.clamp, self.affine_eps, False)
-            y2 = G.coupling(x2, self.s1(y1), self.t1(y1), self.clamp, self.affine_eps, False)
+            y1 = G.coupling(x1, *_pair(self.s2, self.t2, x2), self.clamp, self.affine_eps, False)
+            y2 = G.coupling(x2, *_pair(self.s1, self.t1, y1), self.clamp, self.affine_eps, False)
         else:
-            y2 = G.coupling(x2, self.s1(x1), self.t1(x1), self.clamp, self.affine_eps, True)
-            y1 = G.coupling(x1, self.s2(y2), self.t2(y2), self.clamp, self.affine_eps, True)
+            y2 = G.coupling(x2, *_pair(self.s1, self.t1, x1), self.clamp, self.affine_eps, True)
+            y1 = G.coupling(x1, *_pair(self.s2, self.t2, y2), self.clamp, self.affine_eps, True)
         return G.chan_cat(y1, n1, y2, n2)
 
 
