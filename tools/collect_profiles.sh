@@ -51,12 +51,12 @@ cd $ROOT
 (python3 tools/bench_c5.py train_hidden_c3.yml bf16 130 && python3 tools/bench_c5.py train_hidden_c3.yml bf16 130 deferred && python3 tools/bench_c5.py train_hidden_c3.yml f16 130 && python3 tools/bench_c5.py train_hidden_c5.yml bf16 130 &&
  python3 tools/bench_c5.py train_hidden_c5_fp16.yml f16 130) 2> $OUT/c3_c5.err | grep '^{' > $OUT/c3_c5_steps.jsonl
 (python3 tools/bench_literal.py 4 bf16 12 && python3 tools/bench_literal.py 4 f16 12) 2> $OUT/literal.err | grep '^{' > $OUT/literal_steps.jsonl
-(python3 tools/bench_inn.py 8 bf16 6 && python3 tools/bench_inn.py 8 bf16 6 graph && python3 tools/bench_inn.py 8 f16 6 graph) 2> $OUT/inn.err | grep '^{' > $OUT/inn_steps.jsonl
+(python3 tools/bench_inn.py 8 bf16 6 && python3 tools/bench_inn.py 8 bf16 6 graph && python3 tools/bench_inn.py 8 f16 6 graph && INN_PAR=0 python3 tools/bench_inn.py 8 bf16 6 graph) 2> $OUT/inn.err | grep '^{' > $OUT/inn_steps.jsonl
 (python3 tools/phase_bwd.py 0 && python3 tools/phase_bwd.py 256 && python3 tools/phase_bwd.py 8 && python3 tools/phase_bwd.py 1048832) 2>&1 | grep -v amdgpu.ids > $OUT/bwd_phase_cycles.txt
 if [ -x tools/micro/mfma_rate ]; then tools/micro/mfma_rate > $OUT/mfma_coissue_micro.txt 2>&1; fi
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lit_stats -o l -- python3 $ROOT/tools/bench_literal.py 4 bf16 6 > $OUT/lit_stats.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/inn_stats -o i -- python3 $ROOT/tools/bench_inn.py 8 bf16 4 > $OUT/inn_stats.log 2>&1
+INN_PAR=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/inn_stats -o i -- python3 $ROOT/tools/bench_inn.py 8 bf16 4 > $OUT/inn_stats.log 2>&1   # (one stream: every kernel alone)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_stats -o c -- python3 $ROOT/tools/bench_c5.py train_hidden_c5_fp16.yml f16 44 > $OUT/c5_stats.log 2>&1
 bash $ROOT/tools/pmc_bwd.sh > $OUT/bwd_sq_counters.txt 2>&1
 bash $ROOT/tools/pmc_fwd.sh > $OUT/fwd_sq_counters.txt 2>&1

@@ -157,7 +157,7 @@ if os.path.exists(_sq) and os.path.exists(_sq1):
         g.write("\n" + open(_sq1).read())
 for sub, base, steps, cmd in (("lit_stats", f"{tag}_literal_step_kernel_stats", 8.0, "python3 tools/bench_literal.py 4 bf16 6   (8 steps: the reference's literal IRNrhi step, 24 frames 256x256, bf16)"),
                               ("s512_stats", f"{tag}_bench_512_b8_kernel_stats", 13.0, "python3 bench.py --no-cpu-baseline --no-extra --one-stream --no-graph --size 512 --batch 8 --steps 10 --warmup 3   (13 steps of 8 frames 512x512, one stream)"),
-                              ("inn_stats", f"{tag}_inn_step_kernel_stats", 7.0, "python3 tools/bench_inn.py 8 bf16 4   (7 steps enqueued: the invertible embedder, 8 frames 4x256x256, embed + extract + backward + AdamW, bf16)"),
+                              ("inn_stats", f"{tag}_inn_step_kernel_stats", 7.0, "INN_PAR=0 python3 tools/bench_inn.py 8 bf16 4   (7 steps enqueued on one stream -- every kernel alone: the invertible embedder, 8 frames 4x256x256, embed + extract + backward + AdamW, bf16)"),
                               ("c5_stats", f"{tag}_c5_fp16_kernel_stats", 42.0, "python3 tools/bench_c5.py train_hidden_c5_fp16.yml f16 44   (42 steps with work, 16 frames 256x256 each, UNet head, f16 + device GradScaler)")):
     try:
         stats_summary(sub, base, steps, cmd)
@@ -245,7 +245,7 @@ def emit_measurements_md():
     inn = _jsonl(f"{tag}_inn_steps.jsonl")
     if inn:
         A(f"| the invertible embedder's step (`{tag}_inn_steps.jsonl`) | " + "<br>".join(
-            f"{r['dtype']}, {r['frames_per_step']} frames, {'replayed' if r.get('graph') else 'enqueued'}: {r['ms_per_step_median']:.1f} ms = {r['tflops']:.0f} TFLOP/s ({100 * r['flops_frac_of_mfma_peak']:.1f} % of peak)" for r in inn) + " |")
+            f"{r['dtype']}, {r['frames_per_step']} frames, {'replayed' if r.get('graph') else 'enqueued'}{'' if r.get('parallel_subnets', True) else ', the subnets on one stream'}: {r['ms_per_step_median']:.1f} ms = {r['tflops']:.0f} TFLOP/s ({100 * r['flops_frac_of_mfma_peak']:.1f} % of peak)" for r in inn) + " |")
     try:
         rows = [r for r in csv.DictReader(l for l in open(os.path.join(dst, f"{tag}_attack_roofline.csv")) if not l.startswith("#"))]
         def short(n):
